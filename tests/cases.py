@@ -1,0 +1,120 @@
+"""Shared case tables: golden-fixture case name -> how to build it in the oracle and in the product.
+
+The case names and constructor arguments mirror tests/golden/make_golden.py (which built the same
+blocks from the reference itself).
+"""
+import numpy as np
+import torch
+
+from oracle import nets as O
+
+BLOCK_SHAPES = {
+    'fast_stem': [(2, 3, 16, 32)], 'fast_pw_act': [(2, 48, 8, 16)], 'fast_pw_noact': [(2, 64, 8, 16)],
+    'fast_dw_s1': [(2, 48, 8, 16)], 'fast_dw_s2': [(2, 32, 8, 16)], 'fast_dw_d4': [(2, 32, 8, 16)],
+    'fast_ds_s2': [(2, 32, 8, 16)], 'fast_ds_s1': [(2, 32, 8, 16)], 'fast_bneck_res': [(2, 32, 8, 16)],
+    'fast_bneck_s2': [(2, 32, 8, 16)], 'fast_bneck_mod': [(2, 32, 8, 16)], 'fast_ppm': [(2, 64, 8, 16)],
+    'fast_ppm_odd': [(3, 32, 8, 20)], 'fast_fusion': [(2, 48, 2, 4), (2, 32, 8, 16)],
+    'fast_classifier': [(2, 32, 8, 16)],
+    'ctx_stem': [(2, 3, 16, 32)], 'ctx_dense3x3': [(2, 32, 8, 16)], 'ctx_pw': [(2, 32, 8, 16)],
+    'ctx_dw_s2': [(2, 64, 8, 16)], 'ctx_bneck_e1': [(2, 32, 8, 16)], 'ctx_bneck_e6': [(2, 32, 8, 16)],
+    'ctx_linear_bneck': [(2, 32, 8, 16)], 'ctx_fusion': [(2, 48, 2, 4), (2, 32, 8, 16)],
+    'ctx_classifier': [(2, 32, 8, 16)],
+}
+
+
+def oracle_block(name):
+    return {
+        'fast_stem': lambda: O.unit(3, 32, 3, stride=2),
+        'fast_pw_act': lambda: O.unit(48, 96, 1),
+        'fast_pw_noact': lambda: O.unit(64, 32, 1, act=False),
+        'fast_dw_s1': lambda: O.unit(48, 48, 3, depthwise=True),
+        'fast_dw_s2': lambda: O.unit(32, 32, 3, stride=2, depthwise=True),
+        'fast_dw_d4': lambda: O.unit(32, 32, 3, dilation=4, depthwise=True),
+        'fast_ds_s2': lambda: O.separable(32, 48, stride=2),
+        'fast_ds_s1': lambda: O.separable(32, 32),
+        'fast_bneck_res': lambda: O._FastResidual(32, 32, expansion=6),
+        'fast_bneck_s2': lambda: O._FastResidual(32, 48, stride=2, expansion=6),
+        'fast_bneck_mod': lambda: O.stack(O._FastResidual, 32, 48, 3, 2),
+        'fast_ppm': lambda: O.Pyramid(64, 64),
+        'fast_ppm_odd': lambda: O.Pyramid(32, 32),
+        'fast_fusion': lambda: O.FastFusion(48, 32, 64, 4),
+        'fast_classifier': lambda: O.fast_head(32, 19),
+        'ctx_stem': lambda: O.unit(3, 32, 3, stride=2),
+        'ctx_dense3x3': lambda: O.unit(32, 32, 3),
+        'ctx_pw': lambda: O.unit(32, 64, 1),
+        'ctx_dw_s2': lambda: O.unit(64, 64, 3, stride=2, depthwise=True),
+        'ctx_bneck_e1': lambda: O._CtxResidual(32, 32, expansion=1),
+        'ctx_bneck_e6': lambda: O._CtxResidual(32, 32, expansion=6),
+        'ctx_linear_bneck': lambda: O.stack(O._CtxResidual, 32, 48, 3, 2),
+        'ctx_fusion': lambda: O.CtxFusion(48, 32, 64),
+        'ctx_classifier': lambda: O.ctx_head(32, 19),
+    }[name]()
+
+
+def product_block(name):
+    from torch_semantic_segmentation_amd.models import fastscnn as F, contextnet as C
+    return {
+        'fast_stem': lambda: F.Conv2dBlock(3, 32, kernel_size=3, padding=1, stride=2),
+        'fast_pw_act': lambda: F.Conv2dBlock(48, 96, kernel_size=1),
+        'fast_pw_noact': lambda: F.Conv2dBlock(64, 32, kernel_size=1, use_activation=False),
+        'fast_dw_s1': lambda: F.DWConv2dBlock(48, 48, kernel_size=3, padding=1),
+        'fast_dw_s2': lambda: F.DWConv2dBlock(32, 32, kernel_size=3, padding=1, stride=2),
+        'fast_dw_d4': lambda: F.DWConv2dBlock(32, 32, kernel_size=3, padding=4, dilation=4),
+        'fast_ds_s2': lambda: F.DSConv2dBlock(32, 48, kernel_size=3, padding=1, stride=2),
+        'fast_ds_s1': lambda: F.DSConv2dBlock(32, 32, kernel_size=3, padding=1),
+        'fast_bneck_res': lambda: F.BottleneckBlock(32, 32, expansion=6),
+        'fast_bneck_s2': lambda: F.BottleneckBlock(32, 48, stride=2, expansion=6),
+        'fast_bneck_mod': lambda: F.BottleneckModule(32, 48, expansion=6, repeats=3, stride=2),
+        'fast_ppm': lambda: F.PyramidPoolingModule(64, 64),
+        'fast_ppm_odd': lambda: F.PyramidPoolingModule(32, 32),
+        'fast_fusion': lambda: F.FeatureFusionModule((48, 32), 64, scale_factor=4),
+        'fast_classifier': lambda: F.Classifier(32, 19),
+        'ctx_stem': lambda: C.ConvBlock(3, 32, 3, padding=1, stride=2),
+        'ctx_dense3x3': lambda: C.ConvBlock(32, 32, 3, padding=1),
+        'ctx_pw': lambda: C.ConvBlock(32, 64, 1),
+        'ctx_dw_s2': lambda: C.DWConvBlock(64, 64, kernel_size=3, padding=1, stride=2),
+        'ctx_bneck_e1': lambda: C.BottleneckBlock(32, 32, expansion=1),
+        'ctx_bneck_e6': lambda: C.BottleneckBlock(32, 32, expansion=6),
+        'ctx_linear_bneck': lambda: C.LinearBottleneck(32, 48, 3, stride=2),
+        'ctx_fusion': lambda: C.FeatureFusionModule((48, 32), 64),
+        'ctx_classifier': lambda: C.Classifier(32, 19),
+    }[name]()
+
+
+MODEL_NAMES = ('fastscnn', 'contextnet12', 'contextnet14', 'contextnet18')
+EVAL_SHAPE = (2, 3, 64, 128)
+TRAIN_SHAPE = (2, 3, 64, 128)
+
+
+def product_model(name, in_channels=3, out_channels=19):
+    from torch_semantic_segmentation_amd.models import fastscnn as F, contextnet as C
+    return {'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12,
+            'contextnet14': C.contextnet14, 'contextnet18': C.contextnet18}[name](in_channels, out_channels)
+
+
+def block_inputs(name):
+    from oracle.recipe import lattice_input
+    return [lattice_input(*s).mul(1.0 + 0.25 * i) for i, s in enumerate(BLOCK_SHAPES[name])]
+
+
+def block_cotangent(shape):
+    from oracle.recipe import lattice_input
+    return lattice_input(*shape).flip(1) * 0.5 + 0.1
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|_max, tiny): the north-star's 'rel' metric, on whole tensors."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def load_npz(path):
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0

@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference, CPU).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The reference's Python never travels; only the arrays written here do.  Weights and inputs are
+closed-form (oracle/recipe.py: formula_state, lattice_input, lattice_target), so each fixture stores
+outputs only.  Dropout is forced to p=0 for train-mode fixtures (CPU mt19937 masks are not
+reproducible on a GPU; SURVEY.md §7 "hard parts").
+
+Fixture families:
+  G1 blocks_*.npz : per-block forward / dX / dW for every block type of rows A-H and K-P
+  G2 eval_*.npz   : whole-model eval logits (pre-upsample, strided full-res sample) + argmax mask
+  G3 train_*.npz  : 2 train steps (CE(ignore 255) + AdamW): loss, per-parameter grad norms, a few
+                    full gradients, BN running stats, post-step parameter norms
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+from oracle.recipe import formula_state, lattice_input, lattice_target, train_step  # noqa: E402
+import importlib                                                                  # noqa: E402
+ref_fast = importlib.import_module('torch_semantic_segmentation.models.fastscnn')
+ref_ctx = importlib.import_module('torch_semantic_segmentation.models.contextnet')
+
+torch.set_num_threads(4)
+torch.use_deterministic_algorithms(True)
+
+
+def zero_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, nn.Dropout):
+            mod.p = 0.0
+
+
+def np32(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------- G1: blocks
+
+def block_cases():
+    """name -> (constructor thunk, input shapes).  Shapes are (B,C,H,W); two inputs for fusion."""
+    f, c = ref_fast, ref_ctx
+    return {
+        # FastSCNN rows A-H
+        'fast_stem':        (lambda: f.Conv2dBlock(3, 32, kernel_size=3, padding=1, stride=2), [(2, 3, 16, 32)]),
+        'fast_pw_act':      (lambda: f.Conv2dBlock(48, 96, kernel_size=1), [(2, 48, 8, 16)]),
+        'fast_pw_noact':    (lambda: f.Conv2dBlock(64, 32, kernel_size=1, use_activation=False), [(2, 64, 8, 16)]),
+        'fast_dw_s1':       (lambda: f.DWConv2dBlock(48, 48, kernel_size=3, padding=1), [(2, 48, 8, 16)]),
+        'fast_dw_s2':       (lambda: f.DWConv2dBlock(32, 32, kernel_size=3, padding=1, stride=2), [(2, 32, 8, 16)]),
+        'fast_dw_d4':       (lambda: f.DWConv2dBlock(32, 32, kernel_size=3, padding=4, dilation=4), [(2, 32, 8, 16)]),
+        'fast_ds_s2':       (lambda: f.DSConv2dBlock(32, 48, kernel_size=3, padding=1, stride=2), [(2, 32, 8, 16)]),
+        'fast_ds_s1':       (lambda: f.DSConv2dBlock(32, 32, kernel_size=3, padding=1), [(2, 32, 8, 16)]),
+        'fast_bneck_res':   (lambda: f.BottleneckBlock(32, 32, expansion=6), [(2, 32, 8, 16)]),
+        'fast_bneck_s2':    (lambda: f.BottleneckBlock(32, 48, stride=2, expansion=6), [(2, 32, 8, 16)]),
+        'fast_bneck_mod':   (lambda: f.BottleneckModule(32, 48, expansion=6, repeats=3, stride=2), [(2, 32, 8, 16)]),
+        'fast_ppm':         (lambda: f.PyramidPoolingModule(64, 64), [(2, 64, 8, 16)]),
+        'fast_ppm_odd':     (lambda: f.PyramidPoolingModule(32, 32), [(3, 32, 8, 20)]),
+        'fast_fusion':      (lambda: f.FeatureFusionModule((48, 32), 64, scale_factor=4), [(2, 48, 2, 4), (2, 32, 8, 16)]),
+        'fast_classifier':  (lambda: f.Classifier(32, 19), [(2, 32, 8, 16)]),
+        # ContextNet rows K-P
+        'ctx_stem':         (lambda: c.ConvBlock(3, 32, 3, padding=1, stride=2), [(2, 3, 16, 32)]),
+        'ctx_dense3x3':     (lambda: c.ConvBlock(32, 32, 3, padding=1), [(2, 32, 8, 16)]),
+        'ctx_pw':           (lambda: c.ConvBlock(32, 64, 1), [(2, 32, 8, 16)]),
+        'ctx_dw_s2':        (lambda: c.DWConvBlock(64, 64, kernel_size=3, padding=1, stride=2), [(2, 64, 8, 16)]),
+        'ctx_bneck_e1':     (lambda: c.BottleneckBlock(32, 32, expansion=1), [(2, 32, 8, 16)]),
+        'ctx_bneck_e6':     (lambda: c.BottleneckBlock(32, 32, expansion=6), [(2, 32, 8, 16)]),
+        'ctx_linear_bneck': (lambda: c.LinearBottleneck(32, 48, 3, stride=2), [(2, 32, 8, 16)]),
+        'ctx_fusion':       (lambda: c.FeatureFusionModule((48, 32), 64), [(2, 48, 2, 4), (2, 32, 8, 16)]),
+        'ctx_classifier':   (lambda: c.Classifier(32, 19), [(2, 32, 8, 16)]),
+    }
+
+
+def run_block(make, shapes, training):
+    m = make()
+    m.load_state_dict(formula_state(m), strict=True)
+    zero_dropout(m)
+    m.train(training)
+    xs = [lattice_input(*s).mul(1.0 + 0.25 * i).requires_grad_(True) for i, s in enumerate(shapes)]
+    out = m(*xs)
+    # a fixed, non-trivial cotangent
+    cot = lattice_input(*out.shape).flip(1) * 0.5 + 0.1
+    out.backward(cot)
+    rec = {'out': np32(out)}
+    for i, x in enumerate(xs):
+        rec['dx%d' % i] = np32(x.grad)
+    for name, p in m.named_parameters():
+        rec['dw.' + name] = np32(p.grad)
+    if training:
+        for name, b in m.named_buffers():
+            if name.endswith('running_mean') or name.endswith('running_var'):
+                rec['buf.' + name] = np32(b)
+    return rec
+
+
+def gen_blocks():
+    for mode in ('train', 'eval'):
+        blob = {}
+        for name, (make, shapes) in block_cases().items():
+            rec = run_block(make, shapes, training=(mode == 'train'))
+            for k, v in rec.items():
+                blob['%s/%s' % (name, k)] = v
+        path = os.path.join(HERE, 'blocks_%s.npz' % mode)
+        np.savez_compressed(path, **blob)
+        print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(blob), 'arrays')
+
+
+# ----------------------------------------------------------------------------- G2: whole-model eval
+
+MODELS = {
+    'fastscnn': lambda: ref_fast.fastscnn(3, 19),
+    'contextnet12': lambda: ref_ctx.contextnet12(3, 19),
+    'contextnet14': lambda: ref_ctx.contextnet14(3, 19),
+    'contextnet18': lambda: ref_ctx.contextnet18(3, 19),
+}
+EVAL_SHAPE = (2, 3, 64, 128)
+
+
+def gen_eval():
+    blob = {}
+    for name, make in MODELS.items():
+        m = make()
+        m.load_state_dict(formula_state(m, gain=1.0), strict=True)
+        m.eval()
+        low = {}
+        h = m.classifier.register_forward_hook(lambda _m, _i, o: low.__setitem__('v', o))
+        with torch.no_grad():
+            logits = m(lattice_input(*EVAL_SHAPE))
+        h.remove()
+        top2 = logits.topk(2, dim=1).values
+        blob[name + '/low'] = np32(low['v'])
+        blob[name + '/sub'] = np32(logits[:, :, ::4, ::4])
+        blob[name + '/argmax'] = logits.argmax(1).to(torch.uint8).numpy()
+        blob[name + '/gap'] = np32(top2[:, 0] - top2[:, 1])
+        blob[name + '/sum_abs'] = np.array([logits.sum().item(), logits.abs().sum().item()])
+        print(name, 'logit range', logits.min().item(), logits.max().item(),
+              'min top-2 gap', (top2[:, 0] - top2[:, 1]).min().item())
+    path = os.path.join(HERE, 'eval_models.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------- G3: train steps
+
+TRAIN_SHAPE = (2, 3, 64, 128)
+FULL_GRADS = {
+    'fastscnn': ['downsample.0.0.weight', 'downsample.1.0.weight', 'features.0.0.conv1.0.weight',
+                 'features.0.1.conv2.1.weight', 'features.3.conv.0.weight', 'fusion.lowres.1.0.weight',
+                 'classifier.3.weight', 'classifier.3.bias'],
+    'contextnet14': ['spatial.0.0.weight', 'spatial.1.0.weight', 'context.7.0.weight',
+                     'context.3.0.conv2.1.bias', 'feature_fusion.highres.0.weight',
+                     'classifier.5.weight', 'classifier.5.bias'],
+}
+
+
+def gen_train():
+    blob = {}
+    for name in ('fastscnn', 'contextnet14'):
+        m = MODELS[name]()
+        m.load_state_dict(formula_state(m), strict=True)
+        zero_dropout(m)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+        x = lattice_input(*TRAIN_SHAPE)
+        y = lattice_target(TRAIN_SHAPE[0], TRAIN_SHAPE[2], TRAIN_SHAPE[3])
+        losses = []
+        for step in range(2):
+            losses.append(train_step(m, opt, loss_fn, x, y))
+            if step == 0:
+                names = [n for n, _ in m.named_parameters()]
+                blob[name + '/grad_norms'] = np.array(
+                    [p.grad.double().norm().item() for _, p in m.named_parameters()])
+                for n in FULL_GRADS[name]:
+                    blob[name + '/grad.' + n] = np32(m.get_parameter(n).grad)
+                blob[name + '/param_norms_after1'] = np.array(
+                    [p.detach().double().norm().item() for _, p in m.named_parameters()])
+                for n, b in m.named_buffers():
+                    if n.endswith('running_mean') or n.endswith('running_var'):
+                        blob[name + '/buf_norm.' + n] = np.array(b.double().norm().item())
+                assert names == [n for n, _ in m.named_parameters()]
+        blob[name + '/losses'] = np.array(losses)
+        blob[name + '/param_norms_after2'] = np.array(
+            [p.detach().double().norm().item() for _, p in m.named_parameters()])
+        print(name, 'losses', losses)
+    path = os.path.join(HERE, 'train_steps.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024))
+
+
+if __name__ == '__main__':
+    gen_blocks()
+    gen_eval()
+    gen_train()

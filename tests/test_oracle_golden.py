@@ -1,0 +1,103 @@
+"""CPU: the oracle restatement reproduces the reference-generated golden vectors (bit for bit)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import nets as O
+from oracle.recipe import formula_state, lattice_input, lattice_target, train_step
+from tests import cases
+
+torch.set_num_threads(4)
+
+
+@pytest.fixture(scope='module')
+def blocks(golden_dir):
+    return {m: cases.load_npz(os.path.join(golden_dir, 'blocks_%s.npz' % m)) for m in ('train', 'eval')}
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+@pytest.mark.parametrize('name', sorted(cases.BLOCK_SHAPES))
+def test_block_bit_identical(blocks, name, mode):
+    g = blocks[mode]
+    m = cases.oracle_block(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_dropout(m)
+    m.train(mode == 'train')
+    xs = [x.requires_grad_(True) for x in cases.block_inputs(name)]
+    out = m(*xs)
+    out.backward(cases.block_cotangent(out.shape))
+    assert np.array_equal(out.detach().numpy(), g[name + '/out'])
+    for i, x in enumerate(xs):
+        assert np.array_equal(x.grad.numpy(), g['%s/dx%d' % (name, i)])
+    for pname, p in m.named_parameters():
+        assert np.array_equal(p.grad.numpy(), g['%s/dw.%s' % (name, pname)]), pname
+    if mode == 'train':
+        for bname, b in m.named_buffers():
+            if bname.endswith(('running_mean', 'running_var')):
+                assert np.array_equal(b.numpy(), g['%s/buf.%s' % (name, bname)]), bname
+
+
+@pytest.mark.parametrize('name', cases.MODEL_NAMES)
+def test_model_eval_bit_identical(golden_dir, name):
+    g = cases.load_npz(os.path.join(golden_dir, 'eval_models.npz'))
+    m = O.build(name)
+    m.load_state_dict(formula_state(m, gain=1.0), strict=True)
+    m.eval()
+    with torch.no_grad():
+        logits = m(lattice_input(*cases.EVAL_SHAPE))
+    assert np.array_equal(logits[:, :, ::4, ::4].numpy(), g[name + '/sub'])
+    assert np.array_equal(logits.argmax(1).to(torch.uint8).numpy(), g[name + '/argmax'])
+    s = np.array([logits.sum().item(), logits.abs().sum().item()])
+    assert np.array_equal(s, g[name + '/sum_abs'])
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_train_steps_bit_identical(golden_dir, name):
+    g = cases.load_npz(os.path.join(golden_dir, 'train_steps.npz'))
+    m = O.build(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_dropout(m)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+    x = lattice_input(*cases.TRAIN_SHAPE)
+    y = lattice_target(cases.TRAIN_SHAPE[0], cases.TRAIN_SHAPE[2], cases.TRAIN_SHAPE[3])
+    losses = [train_step(m, opt, loss_fn, x, y)]
+    norms = np.array([p.grad.double().norm().item() for p in m.parameters()])
+    assert np.array_equal(norms, g[name + '/grad_norms'])
+    for key in g:
+        if key.startswith(name + '/grad.'):
+            pname = key[len(name) + 6:]
+            assert np.array_equal(m.get_parameter(pname).grad.numpy(), g[key]), pname
+    losses.append(train_step(m, opt, loss_fn, x, y))
+    assert np.array_equal(np.array(losses), g[name + '/losses'])
+    after2 = np.array([p.detach().double().norm().item() for p in m.parameters()])
+    assert np.array_equal(after2, g[name + '/param_norms_after2'])
+
+
+def test_state_dict_contract():
+    """Key/shape contract quoted in SURVEY.md §5 (266 / 314 keys, parameter counts)."""
+    f = O.build('fastscnn')
+    c = O.build('contextnet14')
+    assert len(f.state_dict()) == 266 and sum(p.numel() for p in f.parameters()) == 1137795
+    assert len(c.state_dict()) == 314 and sum(p.numel() for p in c.parameters()) == 1024019
+    assert f.state_dict()['downsample.0.0.weight'].shape == (32, 3, 3, 3)
+    assert f.state_dict()['classifier.3.bias'].shape == (19,)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference'), reason='reference only exists in the build container')
+def test_oracle_keys_equal_reference():
+    import importlib
+    import sys
+    sys.path.insert(0, '/root/reference')
+    try:
+        rf = importlib.import_module('torch_semantic_segmentation.models.fastscnn')
+        rc = importlib.import_module('torch_semantic_segmentation.models.contextnet')
+    finally:
+        sys.path.remove('/root/reference')
+    for ours, theirs in ((O.build('fastscnn'), rf.fastscnn(3, 19)), (O.build('contextnet12'), rc.contextnet12(3, 19))):
+        a, b = ours.state_dict(), theirs.state_dict()
+        assert list(a) == list(b)
+        assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
