@@ -1,0 +1,202 @@
+/* libtss_hip.so -- C ABI of the MI355X (gfx950) hot path of torch_semantic_segmentation.
+ *
+ * The reference (bernardomig/torch_semantic_segmentation) has no native code: its FastSCNN / ContextNet
+ * convolution stacks run through torch.nn leaf modules -> ATen -> MIOpen/cuDNN.  Each entry point below
+ * replaces the ATen dispatch made by one of those leaf-module call sites; the citation after "replaces:"
+ * is the reference interface (file:line under torch_semantic_segmentation/, "TSS/").
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (the library never
+ *     allocates, frees or retains tensor memory), `stream` is a hipStream_t passed as void*.
+ *   - activations are NHWC ("channels_last"): a tensor is P = B*H*W pixel rows of C channels, row pitch
+ *     `ld*` in ELEMENTS (>= C, multiple of 8) so channel slices of a wider buffer can be addressed.
+ *   - dtype: TSS_F32 (parity path, exact-f32 MFMA) or TSS_BF16 (performance path, f32 accumulate).
+ *     Parameters, statistics and gradients of parameters are always f32 (statistics: f64 sums).
+ *   - deferred BatchNorm: a conv output is stored RAW; the BatchNorm(+ReLU) that follows it is applied by
+ *     the CONSUMER on load through per-channel (in_scale, in_shift, in_relu).  In backward, the tensor `e`
+ *     is d(loss)/d(BN output) (already ReLU-masked) and the BN backward g = ga*e + gb*y_raw + gd is applied
+ *     on load from per-channel coefficients produced by tss_bn_bwd_finalize.
+ *   - every function returns TSS_OK or a negative TSS_ERR_* code; launches are asynchronous on `stream`,
+ *     there is no internal synchronisation and no global mutable state besides the optional profiler.
+ */
+#ifndef TSS_HIP_H
+#define TSS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSS_OK 0
+#define TSS_ERR_DTYPE (-1)  /* unknown dtype code */
+#define TSS_ERR_SHAPE (-2)  /* unsupported shape / pitch (e.g. channels not a multiple of 8) */
+#define TSS_ERR_ALIGN (-3)  /* pointer not 16-byte aligned */
+#define TSS_ERR_HIP (-4)    /* hipGetLastError() != hipSuccess after the launch; see tss_last_error() */
+
+#define TSS_F32 0
+#define TSS_BF16 1
+
+/* kernel ids for the profiler (tss_prof_*) */
+enum {
+  TSS_K_PWCONV_FWD = 0, TSS_K_PWCONV_BWD_DATA, TSS_K_PWCONV_BWD_WEIGHT,
+  TSS_K_CONV3X3_FWD, TSS_K_CONV3X3_BWD_DATA, TSS_K_CONV3X3_BWD_WEIGHT,
+  TSS_K_STEM_FWD, TSS_K_STEM_BWD_WEIGHT,
+  TSS_K_DWCONV_FWD, TSS_K_DWCONV_BWD_DATA, TSS_K_DWCONV_BWD_WEIGHT,
+  TSS_K_BN_FINALIZE, TSS_K_BN_BWD_FINALIZE, TSS_K_JOIN_FWD, TSS_K_JOIN_BWD,
+  TSS_K_DROPOUT, TSS_K_BIAS_GRAD, TSS_K_ADAMW,
+  TSS_K_BILINEAR_FWD, TSS_K_BILINEAR_BWD, TSS_K_BILINEAR_PLANAR_FWD,
+  TSS_K_UPSAMPLE_HEAD_FWD, TSS_K_UPSAMPLE_HEAD_BWD_ROWS, TSS_K_UPSAMPLE_HEAD_BWD_COLS,
+  TSS_K_POOL_FWD, TSS_K_POOL_BWD, TSS_K_COPY,
+  TSS_K_CE_FWD, TSS_K_CE_BWD, TSS_K_ARGMAX,
+  TSS_K_COUNT
+};
+
+/* ---- library / diagnostics --------------------------------------------------------------------------- */
+int tss_version(void);                 /* ABI version of this header */
+const char* tss_last_error(void);      /* text of the last HIP error seen by this library (thread-local) */
+const char* tss_arch(void);            /* "gfx950" */
+
+/* ---- profiler: HIP events around every launch, on the launch stream --------------------------------- */
+int tss_prof_enable(int on);           /* 1: record events for every launch from now on; 0: stop */
+int tss_prof_reset(void);
+int tss_prof_collect(void);            /* synchronises recorded events and folds them into the per-kernel table */
+int tss_prof_get(int kernel_id, long* launches, double* total_ms, double* alg_bytes, double* flops);
+const char* tss_prof_name(int kernel_id);    /* operator name, e.g. "pwconv_fwd" */
+const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launches, e.g. "convgemm_kernel" */
+
+/* ---- pointwise (1x1) convolution --------------------------------------------------------------------
+ * replaces: nn.Conv2d(k=1, bias=False) (+BatchNorm2d, ReLU fused as described above) built by
+ *           Conv2dBlock TSS/models/fastscnn.py:164-173, DSConv2dBlock :194, ConvBlock TSS/models/contextnet.py:168-177
+ *           and the biased classifier conv TSS/models/fastscnn.py:97, TSS/models/contextnet.py:86.
+ * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional, [2N] f64, caller-zeroed) += sum(y), sum(y^2). */
+int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                   const float* w, const float* bias, void* y, long ldy, double* stats,
+                   long P, int K, int N, int dtype, void* stream);
+/* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*e + gb*yraw + gd  (gb,gd,yraw NULL: g = ga*e or e);
+ * bstats (optional, [2K] f64) += sum(e_in), sum(e_in * xraw).  xraw/in_* NULL: plain dX, no mask. */
+int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                        const float* ga, const float* gb, const float* gd, const float* w,
+                        const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                        void* e_in, long ldei, double* bstats,
+                        long P, int K, int N, int dtype, void* stream);
+/* dw[n][k] += sum_p g[p][n] * act(x[p][k])   (f32 atomics onto the caller's buffer) */
+int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                          const float* ga, const float* gb, const float* gd,
+                          const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                          float* dw, long P, int K, int N, int dtype, void* stream);
+
+/* ---- dense 3x3 convolution, padding = dilation ------------------------------------------------------
+ * replaces: nn.Conv2d(128,128,3,padding=1) of ConvBlock TSS/models/contextnet.py:55 (and any Conv2dBlock k=3, Cin%8==0).
+ * fwd takes the weight re-laid out as [9][N][Cin], bwd_data as [9][Cin][N] (tss_permute_w3x3); bwd_weight
+ * accumulates straight into the torch layout [N][Cin][3][3]. */
+int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, void* stream);
+int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                    const float* w_tnc, void* y, long ldy, double* stats,
+                    int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream);
+int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gd, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream);  /* stride 1 */
+int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd,
+                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           float* dw, int B, int Hin, int Win, int Cin, int N, int stride, int dil,
+                           int dtype, void* stream);
+
+/* ---- stem: 3x3 stride-s conv on the NCHW image (Cin*9 <= 64), NHWC output ----------------------------
+ * replaces: nn.Conv2d(in_channels,32,3,stride=2,padding=1) TSS/models/fastscnn.py:30, TSS/models/contextnet.py:38,48. */
+int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
+                    int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream);
+int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd,
+                           const void* x_nchw, int x_is_f32, float* dw,
+                           int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream);
+
+/* ---- depthwise 3x3 convolution, padding = dilation, weight [C][3][3] --------------------------------
+ * replaces: nn.Conv2d(groups=in_channels) of DWConv2dBlock TSS/models/fastscnn.py:176-185, DSConv2dBlock :191-192,
+ *           DWConvBlock TSS/models/contextnet.py:150-165. */
+int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                      const float* w, void* y, long ldy, double* stats,
+                      int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd, const float* w,
+                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           void* e_in, long ldei, double* bstats,
+                           int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                             const float* ga, const float* gb, const float* gd,
+                             const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                             float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+
+/* ---- BatchNorm2d bookkeeping (eps, momentum, running stats exactly as torch.nn.BatchNorm2d) ----------
+ * replaces: nn.BatchNorm2d in every block above (training: batch statistics + running update; eval: running stats). */
+int tss_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream);
+int tss_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream);
+int tss_bn_bwd_finalize(const double* bstats, double count, const float* mean, const float* invstd,
+                        const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,
+                        float* ga, float* gb, float* gd, int C, void* stream);
+
+/* ---- join: out = relu?(affA(a) + affB(b)) ------------------------------------------------------------
+ * replaces: the trailing BatchNorm2d(+ReLU) of a block, `x + input` / F.relu of BottleneckBlock
+ *           TSS/models/fastscnn.py:158-161, TSS/models/contextnet.py:145-147 and F.relu(lowres + highres)
+ *           TSS/models/fastscnn.py:89, TSS/models/contextnet.py:126. */
+int tss_join_fwd(const void* a, long lda, const float* sa, const float* ba,
+                 const void* b, long ldb, const float* sb, const float* bb,
+                 void* out, long ldo, int relu, long P, int C, int dtype, void* stream);
+/* e = dout * relu'(out) (written if e != NULL); stats_x (optional, [2C] f64) += sum(e), sum(e * x_raw) */
+int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
+                 const void* a_raw, long lda, double* stats_a, const void* b_raw, long ldb, double* stats_b,
+                 void* e, long lde, long P, int C, int dtype, void* stream);
+
+/* ---- dropout / bias gradient / optimizer ------------------------------------------------------------
+ * replaces: nn.Dropout(0.1) TSS/models/fastscnn.py:96, TSS/models/contextnet.py:85 (Philox; mask recomputed in backward);
+ *           torch.optim.AdamW.step() as called by TSS/engine.py:38 (single flat tensor, torch arithmetic). */
+int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot, void* stream);
+int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float p,
+                const unsigned long long* seed_slot, int dtype, void* stream);
+int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtype, void* stream);
+int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                   const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                   float* state, float grad_scale, void* stream);
+
+/* ---- resampling -------------------------------------------------------------------------------------
+ * replaces: F.interpolate(mode='bilinear', align_corners=True) TSS/models/fastscnn.py:63-64,119-120,
+ *           nn.UpsamplingBilinear2d :74, TSS/models/contextnet.py:65-67,74-76,119-121;
+ *           nn.AdaptiveAvgPool2d TSS/models/fastscnn.py:108; torch.cat :122 (tss_copy_nhwc into a channel slice). */
+int tss_bilinear_nhwc_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, int Win, int Hout, int Wout,
+                          int C, int dtype, void* stream);
+int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
+                          int C, int dtype, void* stream);
+int tss_bilinear_planar_fwd(const void* x, int x_dtype, void* y, int y_dtype, long planes, int Hin, int Win,
+                            int Hout, int Wout, void* stream);
+/* logits head: NHWC low-res logits (pitch ldl) -> NCHW-contiguous full-res logits, and its backward */
+int tss_upsample_head_fwd(const void* low, long ldl, void* y, int B, int N, int h, int w, int H, int W,
+                          int dtype, void* stream);
+int tss_upsample_head_bwd(const void* dy, const float* gscale, float* tmp, void* dlow, long ldl,
+                          int B, int N, int h, int w, int H, int W, int dtype, void* stream);
+int tss_adaptive_pool_fwd(const void* x, long ldx, void* y, long ldy, int B, int H, int W, int C, int bins,
+                          int dtype, void* stream);
+int tss_adaptive_pool_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int H, int W, int C, int bins,
+                          int dtype, void* stream);
+int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream);
+
+/* ---- caller side: loss and evaluation metrics --------------------------------------------------------
+ * replaces: nn.CrossEntropyLoss(ignore_index=255) scripts/train_fastscnn.py:132 as called by TSS/engine.py:30;
+ *           argmax + ConfusionMatrix update of create_segmentation_evaluator TSS/engine.py:65-77. */
+int tss_cross_entropy_fwd(const void* logits, const long long* target, float* lse, double* acc,
+                          float* loss, float* inv_count, long B, int C, long HW, int ignore_index,
+                          int dtype, void* stream);
+int tss_cross_entropy_bwd(const void* logits, const long long* target, const float* lse, const float* inv_count,
+                          const float* grad_out, void* dlogits, long B, int C, long HW, int ignore_index,
+                          int dtype, void* stream);
+int tss_argmax_confusion(const void* logits, const long long* target, unsigned char* pred,
+                         unsigned long long* confusion, long B, int C, long HW, int ignore_index,
+                         int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSS_HIP_H */

@@ -52,7 +52,9 @@ def oracle_block(name):
 
 
 def product_block(name):
-    from torch_semantic_segmentation_amd.models import fastscnn as F, contextnet as C
+    import importlib
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    C = importlib.import_module('torch_semantic_segmentation_amd.models.contextnet')
     return {
         'fast_stem': lambda: F.Conv2dBlock(3, 32, kernel_size=3, padding=1, stride=2),
         'fast_pw_act': lambda: F.Conv2dBlock(48, 96, kernel_size=1),
@@ -87,7 +89,9 @@ TRAIN_SHAPE = (2, 3, 64, 128)
 
 
 def product_model(name, in_channels=3, out_channels=19):
-    from torch_semantic_segmentation_amd.models import fastscnn as F, contextnet as C
+    import importlib
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    C = importlib.import_module('torch_semantic_segmentation_amd.models.contextnet')
     return {'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12,
             'contextnet14': C.contextnet14, 'contextnet18': C.contextnet18}[name](in_channels, out_channels)
 

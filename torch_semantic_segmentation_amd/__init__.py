@@ -1,0 +1,7 @@
+"""MI355X-native hot path of torch_semantic_segmentation: FastSCNN / ContextNet conv stacks as hand-written
+HIP kernels (libtss_hip.so, include/tss_hip.h) behind the reference's nn.Module API."""
+from . import models                                         # noqa: F401
+from .models import set_compute_dtype                        # noqa: F401
+from .ops import CrossEntropyLoss, cross_entropy, argmax_confusion  # noqa: F401
+
+__version__ = '0.1.0'

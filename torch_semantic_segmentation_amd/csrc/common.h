@@ -1,0 +1,135 @@
+// Shared device/host helpers for the gfx950 kernels of the FastSCNN / ContextNet hot path.
+// Everything here is CDNA4-only: 64-lane waves, MFMA 16x16 tiles, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tss_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define TSS_WAVE 64
+#define TSS_MAX_PERSISTENT_BLOCKS 1024  // 256 CUs x 4: enough waves in flight for HBM-bound loops
+
+// ---------------------------------------------------------------------------------------------
+// 8-wide channel vectors: the unit of every NHWC access (16 B of bf16, 32 B of f32 per lane).
+template <typename T> struct V8;
+
+template <> struct V8<float> {
+  static __device__ __forceinline__ void load(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float v[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  static __device__ __forceinline__ float round(float x) { return x; }
+};
+
+template <> struct V8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float v[8]) {
+    const uint4 r = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float v[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(p) = o;
+  }
+  static __device__ __forceinline__ float round(float x) { return (float)(bf16_t)x; }
+};
+
+// 4-wide access used by the MFMA epilogues (one lane owns 4 consecutive channels of one pixel).
+template <typename T> struct V4;
+template <> struct V4<float> {
+  static __device__ __forceinline__ void load(const float* p, float v[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+};
+template <> struct V4<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float v[4]) {
+    const uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float v[4]) {
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x4*>(p) = o;
+  }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+
+// ---------------------------------------------------------------------------------------------
+// Reductions.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware tile order (MI355X: 8 XCDs, blocks are dealt round-robin, so b and b+8 share an L2).
+// Every XCD owns one contiguous band of the tile range and its resident blocks sweep that band
+// together (slot-interleaved), so neighbouring tiles, which share halo rows or operand panels, are
+// in flight on the same 4 MiB L2 at about the same time.  Placement changes speed only, never
+// results.  The grid must be a multiple of 8 blocks (tss::persistent_blocks guarantees it).
+struct TileRange { int begin, end, step; };
+__device__ __forceinline__ TileRange xcd_tiles(int ntiles) {
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int slots = gridDim.x >> 3;
+  const int per = (ntiles + 7) >> 3;
+  const int b0 = xcd * per;
+  int b1 = b0 + per;
+  if (b1 > ntiles) b1 = ntiles;
+  TileRange r;
+  r.begin = b0 + slot; r.end = b1; r.step = slots;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side: error mapping + optional per-kernel profiling (HIP events on the launch stream).
+namespace tss {
+
+int check_last(const char* what);
+
+struct ProfScope {
+  ProfScope(int kernel_id, hipStream_t stream, double alg_bytes, double flops);
+  ~ProfScope();
+  int slot;
+  hipStream_t stream;
+};
+
+// Grid for a persistent, tile-looping kernel: a multiple of 8 (one slot per XCD), at most `cap`.
+inline int persistent_blocks(long tiles, int cap = TSS_MAX_PERSISTENT_BLOCKS) {
+  long b = tiles < 1 ? 1 : tiles;
+  if (b > cap) b = cap;
+  return (int)((b + 7) / 8 * 8);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace tss
+
+#define TSS_REQUIRE(cond, code) do { if (!(cond)) return (code); } while (0)

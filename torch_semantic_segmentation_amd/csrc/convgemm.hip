@@ -1,0 +1,455 @@
+// MFMA contraction kernel shared by every dense (non-depthwise) convolution of the hot path:
+//
+//   out[p][n] = sum_k A(p, k) * Wt(n, k)            p = output pixel (NHWC row), n = output channel
+//
+//   * pointwise 1x1 forward        A = relu?(x*scale+shift)                (deferred BN of the producer)
+//   * pointwise 1x1 backward-data  A = ga*e + gb*y + gd                    (deferred BN-backward of this conv)
+//   * dense 3x3 forward/backward   the same two prologues, gathered over 9 taps (im2col-free)
+//   * 3-channel stem 3x3 stride 2  A gathered from the NCHW image, K = Cin*9 zero-padded to the MFMA step
+//
+// The product is computed transposed (D = W_tile x A_tile^T) so that one lane ends up owning 4
+// consecutive channels of one pixel: NHWC stores are 8/16 B per lane and per-channel statistics are a
+// 16-lane reduction.  Blocks are persistent over 128-pixel tiles; per-channel sum / sum-of-squares
+// (forward) or sum(e) / sum(e*x) (backward) are accumulated in registers across tiles and leave the
+// block as one f64 atomic per channel.  bf16 uses v_mfma_f32_16x16x32_bf16, f32 (parity path) uses
+// v_mfma_f32_16x16x4_f32 which is an exact fmaf chain.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128;   // pixels per tile (4 waves x 32)
+constexpr int NCH = 128;  // output channels per block
+constexpr int NT = 256;
+
+enum { A_PW = 0, A_TAPS = 1, A_STEM = 2 };
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KC = 128, KSTEP = 32, RS = KC + 8;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ Frag ld(const bf16_t* row, int ks, int q) {
+    return *reinterpret_cast<const bf16x8*>(row + ks * 32 + q * 8);
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KC = 64, KSTEP = 4, RS = KC + 4;
+  typedef float Frag;
+  static __device__ __forceinline__ Frag ld(const float* row, int ks, int q) { return row[ks * 4 + q]; }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+struct GemmArgs {
+  long P;                 // output rows (pixels)
+  int KD, ND, ntaps, mode;
+  // A operand
+  const void* a0; long lda0;
+  const void* a1; long lda1;
+  const float* c0; const float* c1; const float* c2;
+  int a_relu, a0_f32;
+  int Hin, Win, Hout, Wout, stride, dil, tap_sign, Cin;
+  // weights: element (n, k, tap) at w[n*wrs + k*wcs + tap*wts]
+  const float* w; long wrs, wcs, wts;
+  const float* bias;
+  // output + forward statistics
+  void* y; long ldy; double* stats;
+  // backward epilogue: mask / second moment source
+  const void* xm; long ldxm; const float* ms; const float* mb; int m_relu;
+  int gslots;             // tile slots per XCD per channel chunk
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
+  typedef Mma<T> M;
+  constexpr int KC = M::KC, RS = M::RS, KSTEP = M::KSTEP;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Xs = reinterpret_cast<T*>(smem);
+  T* Ws = Xs + BM * RS;
+  float* Cs = reinterpret_cast<float*>(Ws + NCH * RS);  // [3][KC]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int nchunks = (g.ND + NCH - 1) / NCH;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nc = slot % nchunks, gslot = slot / nchunks;
+  const long ntiles = (g.P + BM - 1) / BM;
+  const long per = (ntiles + 7) >> 3;
+  const long t_begin = xcd * per + gslot;
+  long t_end = xcd * per + per;
+  if (t_end > ntiles) t_end = ntiles;
+
+  const int n0 = nc * NCH;
+  const int ncw = (g.ND - n0 < NCH) ? (g.ND - n0) : NCH;
+  const int nfr = (ncw + 15) >> 4;
+  const int nrows = nfr * 16;
+
+  const int kcpt = (g.KD + KC - 1) / KC;  // k-chunks per tap
+  const int nkc = g.ntaps * kcpt;
+  const bool w_resident = (nkc == 1);
+  bool w_loaded = false;
+
+  float st1[8][4], st2[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
+
+  const long HWo = (long)g.Hout * g.Wout;
+
+  for (long tile = t_begin; tile < t_end; tile += g.gslots) {
+    const long p0 = tile * BM;
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int tap = kc / kcpt;
+      const int k0 = (kc - tap * kcpt) * KC;
+      const int kw = (g.KD - k0 < KC) ? (g.KD - k0) : KC;
+      const int kwp = (kw + KSTEP - 1) / KSTEP * KSTEP;
+      __syncthreads();  // all MFMA reads of the previous chunk are done
+
+      if (g.mode != A_STEM) {
+        for (int j = tid; j < kw; j += NT) {
+          Cs[j] = g.c0 ? g.c0[k0 + j] : 1.f;
+          Cs[KC + j] = g.c1 ? g.c1[k0 + j] : 0.f;
+          Cs[2 * KC + j] = g.c2 ? g.c2[k0 + j] : 0.f;
+        }
+      }
+      if (!w_resident || !w_loaded) {
+        const float* wt = g.w + tap * g.wts;
+        if (g.wcs == 1 && (kw & 3) == 0 && (g.wrs & 3) == 0) {
+          const int vpr = kwp >> 2;  // float4 per row
+          for (int idx = tid; idx < nrows * vpr; idx += NT) {
+            const int n = idx / vpr, jv = idx - n * vpr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < ncw && jv * 4 < kw) v = *reinterpret_cast<const float4*>(wt + (long)(n0 + n) * g.wrs + k0 + jv * 4);
+            T* d = Ws + n * RS + jv * 4;
+            d[0] = (T)v.x; d[1] = (T)v.y; d[2] = (T)v.z; d[3] = (T)v.w;
+          }
+        } else if (g.wrs == 1 && (ncw & 3) == 0 && (g.wcs & 3) == 0) {
+          const int vpc = nrows >> 2;  // float4 per contraction column
+          for (int idx = tid; idx < kwp * vpc; idx += NT) {
+            const int j = idx / vpc, nv = idx - j * vpc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < kw && nv * 4 < ncw) v = *reinterpret_cast<const float4*>(wt + (long)(k0 + j) * g.wcs + n0 + nv * 4);
+            T* d = Ws + (nv * 4) * RS + j;
+            d[0] = (T)v.x; d[RS] = (T)v.y; d[2 * RS] = (T)v.z; d[3 * RS] = (T)v.w;
+          }
+        } else {
+          for (int idx = tid; idx < nrows * kwp; idx += NT) {
+            const int n = idx / kwp, j = idx - n * kwp;
+            float v = 0.f;
+            if (n < ncw && j < kw) v = wt[(long)(n0 + n) * g.wrs + (long)(k0 + j) * g.wcs];
+            Ws[n * RS + j] = (T)v;
+          }
+        }
+        w_loaded = true;
+      }
+      __syncthreads();  // coefficients (and weights) visible
+
+      // ---- stage the A tile: Xs[row][j] = A(p0+row, k0+j), zero beyond kw / P / image borders
+      if (g.mode == A_STEM) {
+        const float* src32 = reinterpret_cast<const float*>(g.a0);
+        const T* srcT = reinterpret_cast<const T*>(g.a0);
+        for (int idx = tid; idx < BM * kwp; idx += NT) {
+          const int row = idx & (BM - 1), j = idx >> 7;  // BM == 128: pixels fastest -> row reads coalesce
+          const long p = p0 + row;
+          float v = 0.f;
+          if (p < g.P && j < kw) {
+            const int c = j / 9, t9 = j - c * 9, ky = t9 / 3, kx = t9 - ky * 3;
+            const long b = p / HWo; const long rem = p - b * HWo;
+            const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+            const int iy = oy * g.stride + (ky - 1) * g.dil, ix = ox * g.stride + (kx - 1) * g.dil;
+            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
+              const long off = ((b * g.Cin + c) * g.Hin + iy) * (long)g.Win + ix;
+              v = g.a0_f32 ? src32[off] : (float)srcT[off];
+            }
+          }
+          Xs[row * RS + j] = (T)v;
+        }
+      } else {
+        const int nvec = (kwp + 7) >> 3;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const T* a0 = reinterpret_cast<const T*>(g.a0);
+        const T* a1 = reinterpret_cast<const T*>(g.a1);
+        for (int idx = tid; idx < BM * nvec; idx += NT) {
+          const int row = idx / nvec, cv = idx - row * nvec;
+          const long p = p0 + row;
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          long q = -1;
+          if (p < g.P) {
+            if (g.mode == A_PW) {
+              q = p;
+            } else {
+              const long b = p / HWo; const long rem = p - b * HWo;
+              const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+              const int iy = oy * g.stride + g.tap_sign * (ky - 1) * g.dil;
+              const int ix = ox * g.stride + g.tap_sign * (kx - 1) * g.dil;
+              if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+            }
+          }
+          if (q >= 0 && cv * 8 < kw) {
+            float x0[8];
+            V8<T>::load(a0 + q * g.lda0 + k0 + cv * 8, x0);
+            const float* cc = Cs + cv * 8;
+            if (a1) {
+              float x1[8];
+              V8<T>::load(a1 + q * g.lda1 + k0 + cv * 8, x1);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = cc[j] * x0[j] + cc[KC + j] * x1[j] + cc[2 * KC + j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = cc[j] * x0[j] + cc[2 * KC + j];
+            }
+            if (g.a_relu) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (cv * 8 + j >= kw) v[j] = 0.f;
+          }
+          V8<T>::store(Xs + row * RS + cv * 8, v);
+        }
+      }
+      __syncthreads();
+
+      // ---- MFMA: D[n][p] += W[n][k] * A[p][k]
+      const T* xrow0 = Xs + (wave * 32 + fr) * RS;
+      const T* xrow1 = xrow0 + 16 * RS;
+      const T* wrow = Ws + fr * RS;
+      const int nks = kwp / KSTEP;
+      for (int ks = 0; ks < nks; ++ks) {
+        const typename M::Frag x0 = M::ld(xrow0, ks, fq);
+        const typename M::Frag x1 = M::ld(xrow1, ks, fq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (i < nfr) {
+            const typename M::Frag wf = M::ld(wrow + i * 16 * RS, ks, fq);
+            acc[0][i] = M::mma(wf, x0, acc[0][i]);
+            acc[1][i] = M::mma(wf, x1, acc[1][i]);
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: lane owns pixel (fr) x channels n..n+3
+    T* yo = reinterpret_cast<T*>(g.y);
+    const T* xm = reinterpret_cast<const T*>(g.xm);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const long p = p0 + wave * 32 + m * 16 + fr;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < nfr) {
+          const int n = n0 + i * 16 + fq * 4;
+          if (p < g.P && n < g.ND) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[m][i][r];
+            if (g.bias) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] += (n + r < g.ND) ? g.bias[n + r] : 0.f;
+            }
+            if (xm) {
+              float xr[4];
+              V4<T>::load(xm + p * g.ldxm + n, xr);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (g.m_relu) {
+                  const float a = g.ms ? (xr[r] * g.ms[n + r] + g.mb[n + r]) : xr[r];
+                  if (!(a > 0.f)) v[r] = 0.f;
+                }
+                v[r] = V8<T>::round(v[r]);
+                st1[i][r] += v[r];
+                st2[i][r] += v[r] * xr[r];
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = V8<T>::round(v[r]);
+                st1[i][r] += v[r];
+                st2[i][r] += v[r] * v[r];
+              }
+            }
+            V4<T>::store(yo + p * g.ldy + n, v);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- per-channel statistics: 16-lane reduce, 4-wave reduce through LDS, one f64 atomic per channel
+  if (g.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [4][2][NCH], aliases Xs
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = st1[i][r], b = st2[i][r];
+#pragma unroll
+        for (int mk = 1; mk <= 8; mk <<= 1) { a += __shfl_xor(a, mk, 64); b += __shfl_xor(b, mk, 64); }
+        if (fr == 0) {
+          red[(wave * 2 + 0) * NCH + i * 16 + fq * 4 + r] = a;
+          red[(wave * 2 + 1) * NCH + i * 16 + fq * 4 + r] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < ncw) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) { a += red[(wv * 2 + 0) * NCH + tid]; b += red[(wv * 2 + 1) * NCH + tid]; }
+      atomicAdd(g.stats + n0 + tid, a);
+      atomicAdd(g.stats + g.ND + n0 + tid, b);
+    }
+  }
+}
+
+template <typename T> size_t smem_bytes() {
+  return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 3 * Mma<T>::KC * sizeof(float);
+}
+
+int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
+  if (g.P <= 0) return TSS_OK;
+  const int nchunks = (g.ND + NCH - 1) / NCH;
+  const long ntiles = (g.P + BM - 1) / BM;
+  long gs = (ntiles + 7) / 8;
+  long cap = 64 / nchunks;  // <= 512 blocks: 2 per CU, matching the 2-blocks/CU LDS budget
+  if (cap < 1) cap = 1;
+  if (gs > cap) gs = cap;
+  g.gslots = (int)gs;
+  const int grid = 8 * nchunks * (int)gs;
+  const double flops = 2.0 * (double)g.P * g.KD * g.ntaps * g.ND;
+  tss::ProfScope prof(kernel_id, stream, alg_bytes, flops);
+  if (dtype == TSS_BF16) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<bf16_t>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<bf16_t>());
+      attr = true;
+    }
+    hipLaunchKernelGGL(convgemm_kernel<bf16_t>, dim3(grid), dim3(NT), smem_bytes<bf16_t>(), stream, g);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<float>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<float>());
+      attr = true;
+    }
+    hipLaunchKernelGGL(convgemm_kernel<float>, dim3(grid), dim3(NT), smem_bytes<float>(), stream, g);
+  }
+  return tss::check_last("convgemm");
+}
+
+inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                   const float* w, const float* bias, void* y, long ldy, double* stats,
+                   long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (ldx % 8) == 0 && (ldy % 4) == 0 && ldx >= K && ldy >= (N + 3) / 4 * 4,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y) && tss::aligned16(w), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.P = P; g.KD = K; g.ND = N; g.ntaps = 1; g.mode = A_PW;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c2 = in_shift; g.a_relu = in_relu;
+  g.Hout = 1; g.Wout = 1;
+  g.w = w; g.wrs = K; g.wcs = 1; g.wts = 0; g.bias = bias;
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  return launch(g, dtype, TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * esz(dtype));
+}
+
+int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                        const float* ga, const float* gb, const float* gd, const float* w,
+                        const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                        void* e_in, long ldei, double* bstats,
+                        long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldei % 4) == 0 && ldei >= K,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!xraw || ((ldx % 4) == 0 && ldx >= K), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(w), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.P = P; g.KD = N; g.ND = K; g.ntaps = 1; g.mode = A_PW;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gd;
+  g.Hout = 1; g.Wout = 1;
+  g.w = w; g.wrs = 1; g.wcs = K; g.wts = 0;  // Wt(k_out, n) = w[n*K + k_out]
+  g.y = e_in; g.ldy = ldei; g.stats = bstats;
+  g.xm = xraw; g.ldxm = ldx; g.ms = in_scale; g.mb = in_shift; g.m_relu = in_relu;
+  const double bytes = (double)P * (N * (yraw ? 2 : 1) + K * (xraw ? 2 : 1)) * esz(dtype);
+  return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
+}
+
+int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                    const float* w_tnc, void* y, long ldy, double* stats,
+                    int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && stride >= 1 && dil >= 1,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.tap_sign = 1; g.Cin = Cin;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;  // pad = dil, k = 3
+  g.P = (long)B * g.Hout * g.Wout; g.KD = Cin; g.ND = N; g.ntaps = 9; g.mode = A_TAPS;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c2 = in_shift; g.a_relu = in_relu;
+  g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin;  // [tap][n][c]
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  const double bytes = ((double)B * Hin * Win * Cin + (double)g.P * N) * esz(dtype);
+  return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes);
+}
+
+int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gd, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream) {
+  // stride-1 dense 3x3 only (the hot path has no strided dense conv with Cin > 3)
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (N % 8) == 0 && (Cin % 4) == 0 && (lde % 8) == 0 && lde >= N && (ldei % 4) == 0 && ldei >= Cin,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  GemmArgs g = {};
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = -1; g.Cin = N;
+  g.P = (long)B * H * W; g.KD = N; g.ND = Cin; g.ntaps = 9; g.mode = A_TAPS;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gd;
+  g.w = w_tcn; g.wrs = N; g.wcs = 1; g.wts = (long)Cin * N;  // [tap][ci][co]
+  g.y = e_in; g.ldy = ldei; g.stats = bstats;
+  g.xm = xraw; g.ldxm = ldx; g.ms = in_scale; g.mb = in_shift; g.m_relu = in_relu;
+  const double bytes = (double)g.P * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * esz(dtype);
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes);
+}
+
+int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
+                    int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin >= 1 && Cin * 9 <= Mma<float>::KC && N > 0 && (ldy % 4) == 0 && ldy >= N && stride >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(y), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = 1; g.tap_sign = 1; g.Cin = Cin;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  g.P = (long)B * g.Hout * g.Wout; g.KD = Cin * 9; g.ND = N; g.ntaps = 1; g.mode = A_STEM;
+  g.a0 = x_nchw; g.a0_f32 = x_is_f32;
+  g.w = w; g.wrs = (long)Cin * 9; g.wcs = 1; g.wts = 0;
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  const double bytes = (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype)) + (double)g.P * N * esz(dtype);
+  return launch(g, dtype, TSS_K_STEM_FWD, (hipStream_t)stream, bytes);
+}
+
+}  // extern "C"

@@ -1,0 +1,374 @@
+// Depthwise 3x3 convolution (stride 1/2, dilation 1/4, padding = dilation), NHWC, HBM-bound.
+//
+// One lane owns 8 consecutive channels (one 16-byte bf16 vector) of one pixel; consecutive lanes own
+// consecutive channel vectors, so every load/store instruction of a wave covers whole contiguous
+// NHWC rows.  Blocks are persistent and sweep the image in XCD bands (common.h: xcd_tiles) so the
+// three input rows a tile shares with its vertical neighbours are served by the same L2.
+//   forward        y = dw(relu?(x*scale+shift))          + per-channel sum / sum-of-squares of y
+//   backward-data  e_in = relu'(.) * dw^T(ga*e+gb*y+gd)  + per-channel sum(e_in), sum(e_in*x)
+//   backward-weight dW[c][tap] += sum_p g(p,c) * a(p+tap, c)
+// The producer's BatchNorm(+ReLU) is applied on load and this conv's BatchNorm backward is applied on
+// load of (e, y): neither normalised activations nor input gradients of BN ever touch HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int NT_MAX = 256;
+
+struct DwArgs {
+  const void* x; long ldx; const float* xs; const float* xb; int x_relu;
+  const float* w;  // [C][9]
+  void* y; long ldy; double* stats;
+  const void* e; long lde; const void* yraw; long ldyr; const float* ga; const float* gb; const float* gd;
+  float* dw;
+  int B, Hin, Win, C, stride, dil, Hout, Wout;
+  int CV, NPL;
+};
+
+template <typename T> struct StatAcc { typedef float type; };
+template <> struct StatAcc<float> { typedef double type; };
+
+// Block-level per-channel reduction of two 8-channel partials per thread, then f64 atomics.
+template <typename A>
+__device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double* stats, int C, int CV, int NPL,
+                                            int cg, int pl, bool active, unsigned char* smem) {
+  A* red = reinterpret_cast<A*>(smem);  // [NPL][2][C]
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(pl * 2 + 0) * C + cg * 8 + j] = s1[j];
+      red[(pl * 2 + 1) * C + cg * 8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int which = i / C, c = i - which * C;
+    double a = 0.0;
+    for (int q = 0; q < NPL; ++q) a += (double)red[(q * 2 + which) * C + c];
+    atomicAdd(stats + which * C + c, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
+  typedef typename StatAcc<T>::type A;
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* y = reinterpret_cast<T*>(g.y);
+
+  float wt[9][8], sc[8], sh[8];
+  A s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; sc[j] = 1.f; sh[j] = 0.f; }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
+      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+    }
+  }
+  const long P = (long)g.B * g.Hout * g.Wout;
+  const long ntiles = (P + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long p = (long)tile * g.NPL + pl;
+    if (!active || p >= P) continue;
+    const int ox = (int)(p % g.Wout);
+    const long t2 = p / g.Wout;
+    const int oy = (int)(t2 % g.Hout);
+    const long b = t2 / g.Hout;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * g.stride + (ky - 1) * g.dil;
+      if (iy < 0 || iy >= g.Hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * g.stride + (kx - 1) * g.dil;
+        if (ix < 0 || ix >= g.Win) continue;
+        float v[8];
+        V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = v[j] * sc[j] + sh[j];
+          if (g.x_relu) a = a > 0.f ? a : 0.f;
+          acc[j] += a * wt[ky * 3 + kx][j];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[j] = V8<T>::round(acc[j]);
+      s1[j] += (A)acc[j];
+      s2[j] += (A)acc[j] * (A)acc[j];
+    }
+    V8<T>::store(y + p * g.ldy + c0, acc);
+  }
+  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
+  typedef typename StatAcc<T>::type A;
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* out = reinterpret_cast<T*>(g.y);
+
+  float wt[9][8], ca[8], cb[8], cd[8], sc[8], sh[8];
+  A s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; ca[j] = 1.f; cb[j] = 0.f; cd[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
+      if (g.ga) ca[j] = g.ga[c0 + j];
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; cd[j] = g.gd[c0 + j]; }
+      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+    }
+  }
+  const long P = (long)g.B * g.Hin * g.Win;  // one item per INPUT pixel
+  const long ntiles = (P + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long p = (long)tile * g.NPL + pl;
+    if (!active || p >= P) continue;
+    const int ix = (int)(p % g.Win);
+    const long t2 = p / g.Win;
+    const int iy = (int)(t2 % g.Hin);
+    const long b = t2 / g.Hin;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ny = iy - (ky - 1) * g.dil;  // = oy * stride
+      if (ny < 0 || (ny % g.stride) != 0) continue;
+      const int oy = ny / g.stride;
+      if (oy >= g.Hout) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int nx = ix - (kx - 1) * g.dil;
+        if (nx < 0 || (nx % g.stride) != 0) continue;
+        const int ox = nx / g.stride;
+        if (ox >= g.Wout) continue;
+        const long q = (b * g.Hout + oy) * (long)g.Wout + ox;
+        float ev[8];
+        V8<T>::load(e + q * g.lde + c0, ev);
+        if (yr) {
+          float yv[8];
+          V8<T>::load(yr + q * g.ldyr + c0, yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (ca[j] * ev[j] + cb[j] * yv[j] + cd[j]) * wt[ky * 3 + kx][j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (ca[j] * ev[j]) * wt[ky * 3 + kx][j];
+        }
+      }
+    }
+    if (g.x) {
+      float xv[8];
+      V8<T>::load(x + p * g.ldx + c0, xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (g.x_relu && !(xv[j] * sc[j] + sh[j] > 0.f)) acc[j] = 0.f;
+        acc[j] = V8<T>::round(acc[j]);
+        s1[j] += (A)acc[j];
+        s2[j] += (A)acc[j] * (A)xv[j];
+      }
+    }
+    V8<T>::store(out + p * g.ldy + c0, acc);
+  }
+  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
+  __shared__ float sdw[768 * 9];  // C <= 768 on the hot path (checked by the host wrapper)
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const T* x = reinterpret_cast<const T*>(g.x);
+
+  for (int i = tid; i < g.C * 9; i += blockDim.x) sdw[i] = 0.f;
+  float acc[9][8], ca[8], cb[8], cd[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ca[j] = 1.f; cb[j] = 0.f; cd[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t][j] = 0.f;
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (g.ga) ca[j] = g.ga[c0 + j];
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; cd[j] = g.gd[c0 + j]; }
+      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+    }
+  }
+  const long P = (long)g.B * g.Hout * g.Wout;
+  const long ntiles = (P + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long p = (long)tile * g.NPL + pl;
+    if (!active || p >= P) continue;
+    const int ox = (int)(p % g.Wout);
+    const long t2 = p / g.Wout;
+    const int oy = (int)(t2 % g.Hout);
+    const long b = t2 / g.Hout;
+    float gv[8];
+    V8<T>::load(e + p * g.lde + c0, gv);
+    if (yr) {
+      float yv[8];
+      V8<T>::load(yr + p * g.ldyr + c0, yv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = ca[j] * gv[j] + cb[j] * yv[j] + cd[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = ca[j] * gv[j];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * g.stride + (ky - 1) * g.dil;
+      if (iy < 0 || iy >= g.Hin) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * g.stride + (kx - 1) * g.dil;
+        if (ix < 0 || ix >= g.Win) continue;
+        float v[8];
+        V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = v[j] * sc[j] + sh[j];
+          if (g.x_relu) a = a > 0.f ? a : 0.f;
+          acc[ky * 3 + kx][j] += gv[j] * a;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(c0 + j) * 9 + t], acc[t][j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < g.C * 9; i += blockDim.x) atomicAdd(g.dw + i, sdw[i]);
+}
+
+int geometry(DwArgs& g, int* threads) {
+  if (g.C <= 0 || (g.C % 8) != 0 || g.C > 768) return TSS_ERR_SHAPE;
+  g.CV = g.C / 8;
+  g.NPL = NT_MAX / g.CV;
+  if (g.NPL < 1) return TSS_ERR_SHAPE;
+  *threads = (g.CV * g.NPL + 63) / 64 * 64;
+  return TSS_OK;
+}
+
+inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                      const float* w, void* y, long ldy, double* stats,
+                      int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((ldx % 8) == 0 && (ldy % 8) == 0 && ldx >= C && ldy >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  DwArgs g = {};
+  g.x = x; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu; g.w = w;
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  int threads;
+  const int rc = geometry(g, &threads);
+  if (rc) return rc;
+  const long P = (long)B * g.Hout * g.Wout;
+  if (P == 0) return TSS_OK;
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 2048);
+  tss::ProfScope prof(TSS_K_DWCONV_FWD, (hipStream_t)stream,
+                      ((double)B * Hin * Win + (double)P) * C * esz(dtype), 18.0 * P * C);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  return tss::check_last("dwconv_fwd");
+}
+
+int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd, const float* w,
+                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           void* e_in, long ldei, double* bstats,
+                           int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldei % 8) == 0 && ldei >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!xraw || ((ldx % 8) == 0 && ldx >= C), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in), TSS_ERR_ALIGN);
+  DwArgs g = {};
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd; g.w = w;
+  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.y = e_in; g.ldy = ldei; g.stats = bstats;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  int threads;
+  const int rc = geometry(g, &threads);
+  if (rc) return rc;
+  const long P = (long)B * Hin * Win;
+  if (P == 0) return TSS_OK;
+  const long Po = (long)B * g.Hout * g.Wout;
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 2048);
+  tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
+                      ((double)Po * (yraw ? 2 : 1) + (double)P * (xraw ? 2 : 1)) * C * esz(dtype), 18.0 * Po * C);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  return tss::check_last("dwconv_bwd_data");
+}
+
+int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                             const float* ga, const float* gb, const float* gd,
+                             const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                             float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldx % 8) == 0 && ldx >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
+  DwArgs g = {};
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
+  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu; g.dw = dw;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  int threads;
+  const int rc = geometry(g, &threads);
+  if (rc) return rc;
+  const long P = (long)B * g.Hout * g.Wout;
+  if (P == 0) return TSS_OK;
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 512);
+  tss::ProfScope prof(TSS_K_DWCONV_BWD_WEIGHT, (hipStream_t)stream,
+                      ((double)P * (yraw ? 2 : 1) + (double)B * Hin * Win) * C * esz(dtype), 18.0 * P * C);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  return tss::check_last("dwconv_bwd_weight");
+}
+
+}  // extern "C"

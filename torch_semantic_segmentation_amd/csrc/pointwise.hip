@@ -1,0 +1,450 @@
+// Small per-channel / elementwise kernels of the hot path (all HBM- or latency-bound):
+//   * BatchNorm statistics -> affine ("finalize"), eval affine, BatchNorm-backward coefficients
+//   * join: out = relu?(affA(a) + affB(b))   -- the only place a normalised activation is written
+//   * join backward: e = dout * relu'(out) plus the per-channel sums the two BN-backwards need
+//   * dropout (counter-based Philox, mask recomputed in backward), bias gradient, 3x3 weight
+//     re-layout, fused flat AdamW
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------------------------------ BN
+__global__ void bn_finalize_kernel(const double* sums, double count, const float* gamma, const float* beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   long long* num_batches, float* mean_out, float* invstd_out,
+                                   float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches) *num_batches += 1;
+  if (c >= C) return;
+  const double mean = sums[c] / count;
+  double var = sums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float m = (float)mean;
+  mean_out[c] = m;
+  invstd_out[c] = invstd;
+  scale[c] = g * invstd;
+  shift[c] = b - m * (g * invstd);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* mean_out, float* invstd_out,
+                                      float* scale, float* shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(running_var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  mean_out[c] = running_mean[c];
+  invstd_out[c] = invstd;
+  scale[c] = g * invstd;
+  shift[c] = b - running_mean[c] * (g * invstd);
+}
+
+// bstats = [sum(e), sum(e*y)] over the N = count elements of each channel.
+// training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N  =>  g = ga*e + gb*y + gd
+// frozen  : g = k*e
+__global__ void bn_bwd_finalize_kernel(const double* bstats, double count, const float* mean, const float* invstd,
+                                       const float* gamma, int training, int accumulate,
+                                       float* dgamma, float* dbeta, float* ga, float* gb, float* gd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double se = bstats[c], sey = bstats[C + c];
+  const double mu = mean[c], r = invstd[c];
+  const double dg = r * (sey - mu * se);
+  const double db = se;
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
+  const double k = (gamma ? (double)gamma[c] : 1.0) * r;
+  if (training) {
+    const double c1 = db / count, c2 = dg / count;
+    ga[c] = (float)k;
+    gb[c] = (float)(-k * c2 * r);
+    gd[c] = (float)(-k * c1 + k * c2 * r * mu);
+  } else {
+    ga[c] = (float)k; gb[c] = 0.f; gd[c] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ join
+struct JoinArgs {
+  const void* a; long lda; const float* sa; const float* ba;
+  const void* b; long ldb; const float* sb; const float* bb;
+  void* out; long ldo; int relu;
+  // backward
+  const void* dout; long lddo; void* e; long lde; double* stats_a; double* stats_b;
+  long P; int C, CV, NPL;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  if (pl >= g.NPL) return;
+  const int c0 = cg * 8;
+  const T* a = reinterpret_cast<const T*>(g.a);
+  const T* b = reinterpret_cast<const T*>(g.b);
+  T* out = reinterpret_cast<T*>(g.out);
+  float sa[8], ba[8], sb[8], bb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sa[j] = g.sa ? g.sa[c0 + j] : 1.f; ba[j] = g.sa ? g.ba[c0 + j] : 0.f;
+    sb[j] = g.sb ? g.sb[c0 + j] : 1.f; bb[j] = g.sb ? g.bb[c0 + j] : 0.f;
+  }
+  const long stride = (long)gridDim.x * g.NPL;
+  for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
+    float v[8];
+    V8<T>::load(a + p * g.lda + c0, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sa[j] + ba[j];
+    if (b) {
+      float u[8];
+      V8<T>::load(b + p * g.ldb + c0, u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += u[j] * sb[j] + bb[j];
+    }
+    if (g.relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    }
+    V8<T>::store(out + p * g.ldo + c0, v);
+  }
+}
+
+template <typename T> struct StatAcc { typedef float type; };
+template <> struct StatAcc<float> { typedef double type; };
+
+template <typename T>
+__global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
+  typedef typename StatAcc<T>::type A;
+  __shared__ __align__(16) unsigned char smem[NT * 8 * 3 * sizeof(double)];
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* dout = reinterpret_cast<const T*>(g.dout);
+  const T* out = reinterpret_cast<const T*>(g.out);
+  const T* a = reinterpret_cast<const T*>(g.a);
+  const T* b = reinterpret_cast<const T*>(g.b);
+  T* e = reinterpret_cast<T*>(g.e);
+  A s0[8], sA[8], sB[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0; sA[j] = 0; sB[j] = 0; }
+  const long stride = (long)gridDim.x * g.NPL;
+  if (active) {
+    for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
+      float v[8];
+      V8<T>::load(dout + p * g.lddo + c0, v);
+      if (g.relu) {
+        float o[8];
+        V8<T>::load(out + p * g.ldo + c0, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!(o[j] > 0.f)) v[j] = 0.f;
+      }
+      if (e) V8<T>::store(e + p * g.lde + c0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s0[j] += (A)v[j];
+      if (g.stats_a) {
+        float u[8];
+        V8<T>::load(a + p * g.lda + c0, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sA[j] += (A)v[j] * (A)u[j];
+      }
+      if (g.stats_b) {
+        float u[8];
+        V8<T>::load(b + p * g.ldb + c0, u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sB[j] += (A)v[j] * (A)u[j];
+      }
+    }
+  }
+  if (!g.stats_a && !g.stats_b) return;
+  // block reduce: red[pl][3][C]
+  A* red = reinterpret_cast<A*>(smem);
+  const int C = g.C;
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      red[(pl * 3 + 0) * C + c0 + j] = s0[j];
+      red[(pl * 3 + 1) * C + c0 + j] = sA[j];
+      red[(pl * 3 + 2) * C + c0 + j] = sB[j];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * C; i += blockDim.x) {
+    const int which = i / C, c = i - which * C;
+    double s = 0.0;
+    for (int q = 0; q < g.NPL; ++q) s += (double)red[(q * 3 + which) * C + c];
+    if (which == 0) {
+      if (g.stats_a) atomicAdd(g.stats_a + c, s);
+      if (g.stats_b) atomicAdd(g.stats_b + c, s);
+    } else if (which == 1) {
+      if (g.stats_a) atomicAdd(g.stats_a + C + c, s);
+    } else {
+      if (g.stats_b) atomicAdd(g.stats_b + C + c, s);
+    }
+  }
+}
+
+int join_geometry(JoinArgs& g, int* threads, int* grid) {
+  if (g.C <= 0 || (g.C % 8) != 0 || g.C > NT * 8) return TSS_ERR_SHAPE;
+  g.CV = g.C / 8;
+  g.NPL = NT / g.CV;
+  *threads = (g.CV * g.NPL + 63) / 64 * 64;
+  const long tiles = (g.P + g.NPL - 1) / g.NPL;
+  long gsz = tiles < 2048 ? tiles : 2048;
+  if (gsz < 1) gsz = 1;
+  *grid = (int)gsz;
+  return TSS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ dropout
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__global__ void dropout_tick_kernel(unsigned long long* counter, unsigned long long* slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { *slot = *counter; *counter += 1ull; }
+}
+
+// y = x * keep / (1 - p); the same kernel serves backward (x := grad).  One Philox call per 4 elements,
+// keyed by (seed slot, logical element index / 4) so the mask is independent of the launch geometry.
+template <typename T>
+__global__ __launch_bounds__(NT) void dropout_kernel(const T* x, long ldx, T* y, long ldy, long P, int C,
+                                                     float p, const unsigned long long* seed_slot) {
+  const unsigned long long seed = *seed_slot;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x5EEDu;
+  const float inv = 1.f / (1.f - p);
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const int CV = C / 8;
+  const long total = P * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / CV;
+    const int cv = (int)(i - pix * CV);
+    float v[8];
+    V8<T>::load(x + pix * ldx + cv * 8, v);
+    uint32_t r0[4], r1[4];
+    const uint64_t ctr = (uint64_t)(pix * C + cv * 8) >> 2;
+    philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r0);
+    philox4x32((uint32_t)(ctr + 1), (uint32_t)((ctr + 1) >> 32), k0, k1, r1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (r0[j] >= thresh) ? v[j] * inv : 0.f;
+      v[4 + j] = (r1[j] >= thresh) ? v[4 + j] * inv : 0.f;
+    }
+    V8<T>::store(y + pix * ldy + cv * 8, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ misc
+template <typename T>
+__global__ __launch_bounds__(NT) void colsum_kernel(const T* e, long lde, long P, int N, float* out) {
+  // out[n] += sum_p e[p][n]; threads = (pixel lane, channel), N <= 64
+  __shared__ float red[NT];
+  const int nl = threadIdx.x % 64, pl = threadIdx.x / 64;
+  float s = 0.f;
+  if (nl < N)
+    for (long p = (long)blockIdx.x * 4 + pl; p < P; p += (long)gridDim.x * 4) s += (float)e[p * lde + nl];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && nl < N) atomicAdd(out + nl, red[nl] + red[64 + nl] + red[128 + nl] + red[192 + nl]);
+}
+
+__global__ void permute_w3x3_kernel(const float* w, float* w_tnc, float* w_tcn, int N, int Cin) {
+  const long total = (long)N * Cin * 9;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const long nc = i / 9;
+    const int c = (int)(nc % Cin), n = (int)(nc / Cin);
+    const float v = w[i];
+    if (w_tnc) w_tnc[((long)tap * N + n) * Cin + c] = v;
+    if (w_tcn) w_tcn[((long)tap * Cin + c) * N + n] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ AdamW
+// state = {step, bias_correction1, bias_correction2_sqrt}; torch.optim.AdamW arithmetic, single tensor.
+__global__ void adamw_tick_kernel(float* state, float beta1, float beta2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float step = state[0] + 1.f;
+    state[0] = step;
+    state[1] = 1.f - powf(beta1, step);
+    state[2] = sqrtf(1.f - powf(beta2, step));
+  }
+}
+
+__global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, float* m, float* v, long n,
+                                                   const float* lr_ptr, float beta1, float beta2, float eps,
+                                                   float weight_decay, const float* state, float grad_scale) {
+  const float lr = *lr_ptr;
+  const float bc1 = state[1], bc2s = state[2];
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * weight_decay);
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    pi -= step_size * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+
+inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int tss_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream) {
+  TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 40.0 * C, 0);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
+                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
+                     scale, shift, C);
+  return tss::check_last("bn_finalize");
+}
+
+int tss_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream) {
+  TSS_REQUIRE(C > 0, TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 32.0 * C, 0);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, mean_out, invstd_out, scale, shift, C);
+  return tss::check_last("bn_eval_affine");
+}
+
+int tss_bn_bwd_finalize(const double* bstats, double count, const float* mean, const float* invstd,
+                        const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,
+                        float* ga, float* gb, float* gd, int C, void* stream) {
+  TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, bstats, count,
+                     mean, invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gd, C);
+  return tss::check_last("bn_bwd_finalize");
+}
+
+int tss_join_fwd(const void* a, long lda, const float* sa, const float* ba,
+                 const void* b, long ldb, const float* sb, const float* bb,
+                 void* out, long ldo, int relu, long P, int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((lda % 8) == 0 && lda >= C && (ldo % 8) == 0 && ldo >= C && (!b || ((ldb % 8) == 0 && ldb >= C)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(a) && tss::aligned16(out) && tss::aligned16(b), TSS_ERR_ALIGN);
+  JoinArgs g = {};
+  g.a = a; g.lda = lda; g.sa = sa; g.ba = ba; g.b = b; g.ldb = ldb; g.sb = sb; g.bb = bb;
+  g.out = out; g.ldo = ldo; g.relu = relu; g.P = P; g.C = C;
+  int threads, grid;
+  const int rc = join_geometry(g, &threads, &grid);
+  if (rc) return rc;
+  if (P == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_JOIN_FWD, (hipStream_t)stream, (double)P * C * (b ? 3 : 2) * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(join_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(join_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  return tss::check_last("join_fwd");
+}
+
+int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
+                 const void* a_raw, long lda, double* stats_a, const void* b_raw, long ldb, double* stats_b,
+                 void* e, long lde, long P, int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((lddo % 8) == 0 && lddo >= C && (!relu || (out && (ldo % 8) == 0 && ldo >= C)), TSS_ERR_SHAPE);
+  TSS_REQUIRE((!stats_a || (a_raw && (lda % 8) == 0 && lda >= C)) && (!stats_b || (b_raw && (ldb % 8) == 0 && ldb >= C)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!e || ((lde % 8) == 0 && lde >= C), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dout) && tss::aligned16(e), TSS_ERR_ALIGN);
+  JoinArgs g = {};
+  g.dout = dout; g.lddo = lddo; g.out = const_cast<void*>(out); g.ldo = ldo; g.relu = relu;
+  g.a = a_raw; g.lda = lda; g.stats_a = stats_a; g.b = b_raw; g.ldb = ldb; g.stats_b = stats_b;
+  g.e = e; g.lde = lde; g.P = P; g.C = C;
+  int threads, grid;
+  const int rc = join_geometry(g, &threads, &grid);
+  if (rc) return rc;
+  if (P == 0) return TSS_OK;
+  const int nt = 1 + (relu ? 1 : 0) + (e ? 1 : 0) + (stats_a ? 1 : 0) + (stats_b ? 1 : 0);
+  tss::ProfScope prof(TSS_K_JOIN_BWD, (hipStream_t)stream, (double)P * C * nt * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(join_bwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(join_bwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  return tss::check_last("join_bwd");
+}
+
+int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot, void* stream) {
+  hipLaunchKernelGGL(dropout_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, seed_slot);
+  return tss::check_last("dropout_tick");
+}
+
+int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float p,
+                const unsigned long long* seed_slot, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && (ldx % 8) == 0 && (ldy % 8) == 0 && ldx >= C && ldy >= C && p >= 0.f && p < 1.f, TSS_ERR_SHAPE);
+  if (P == 0) return TSS_OK;
+  const long total = P * (C / 8);
+  long grid = (total + NT - 1) / NT;
+  if (grid > 2048) grid = 2048;
+  tss::ProfScope prof(TSS_K_DROPOUT, (hipStream_t)stream, 2.0 * P * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, (bf16_t*)y, ldy, P, C, p, seed_slot);
+  else
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)x, ldx, (float*)y, ldy, P, C, p, seed_slot);
+  return tss::check_last("dropout");
+}
+
+int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(N > 0 && N <= 64 && lde >= N, TSS_ERR_SHAPE);
+  if (P == 0) return TSS_OK;
+  long grid = (P + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  tss::ProfScope prof(TSS_K_BIAS_GRAD, (hipStream_t)stream, (double)P * N * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)e, lde, P, N, dbias);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, (const float*)e, lde, P, N, dbias);
+  return tss::check_last("bias_grad");
+}
+
+int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, void* stream) {
+  TSS_REQUIRE(N > 0 && Cin > 0, TSS_ERR_SHAPE);
+  const long total = (long)N * Cin * 9;
+  long grid = (total + NT - 1) / NT;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(permute_w3x3_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, w, w_tnc, w_tcn, N, Cin);
+  return tss::check_last("permute_w3x3");
+}
+
+int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                   const float* lr, float beta1, float beta2, float eps, float weight_decay,
+                   float* state /*[3]: step, bc1, sqrt(bc2)*/, float grad_scale, void* stream) {
+  TSS_REQUIRE(n >= 0, TSS_ERR_SHAPE);
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+  if (n == 0) return tss::check_last("adamw_tick");
+  long grid = (n + NT - 1) / NT;
+  if (grid > 2048) grid = 2048;
+  tss::ProfScope prof(TSS_K_ADAMW, (hipStream_t)stream, 28.0 * n, 12.0 * n);
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale);
+  return tss::check_last("adamw");
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// Host-side support: HIP error mapping and the optional per-launch profiler.
+// The profiler brackets every kernel launch with two HIP events recorded on the launch stream, so the
+// durations it reports are device times of exactly the kernels bench.py attributes bytes to.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct KernelInfo { const char* name; const char* symbol; };
+const KernelInfo kInfo[TSS_K_COUNT] = {
+    {"pwconv_fwd", "convgemm_kernel"}, {"pwconv_bwd_data", "convgemm_kernel"}, {"pwconv_bwd_weight", "wgrad_kernel"},
+    {"conv3x3_fwd", "convgemm_kernel"}, {"conv3x3_bwd_data", "convgemm_kernel"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
+    {"stem3x3_fwd", "convgemm_kernel"}, {"stem3x3_bwd_weight", "wgrad_kernel"},
+    {"dwconv3x3_fwd", "dw_fwd_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_kernel"}, {"dwconv3x3_bwd_weight", "dw_bwd_weight_kernel"},
+    {"bn_finalize", "bn_finalize_kernel"}, {"bn_bwd_finalize", "bn_bwd_finalize_kernel"},
+    {"join_fwd", "join_fwd_kernel"}, {"join_bwd", "join_bwd_kernel"},
+    {"dropout", "dropout_kernel"}, {"bias_grad", "colsum_kernel"}, {"adamw", "adamw_kernel"},
+    {"bilinear_nhwc_fwd", "bilinear_nhwc_fwd_kernel"}, {"bilinear_nhwc_bwd", "bilinear_nhwc_bwd_kernel"},
+    {"bilinear_planar_fwd", "bilinear_planar_fwd_kernel"},
+    {"upsample_head_fwd", "upsample_head_fwd_kernel"}, {"upsample_head_bwd_rows", "upsample_head_bwd_rows_kernel"},
+    {"upsample_head_bwd_cols", "upsample_head_bwd_cols_kernel"},
+    {"adaptive_pool_fwd", "adaptive_pool_fwd_kernel"}, {"adaptive_pool_bwd", "adaptive_pool_bwd_kernel"},
+    {"copy_nhwc", "copy_nhwc_kernel"},
+    {"cross_entropy_fwd", "ce_fwd_kernel"}, {"cross_entropy_bwd", "ce_bwd_kernel"}, {"argmax_confusion", "argmax_confusion_kernel"},
+};
+
+struct Rec { int kid; hipEvent_t a, b; double bytes, flops; };
+struct Total { long launches; double ms, bytes, flops; };
+
+std::mutex g_mu;
+bool g_enabled = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+Total g_tot[TSS_K_COUNT];
+thread_local char g_err[256] = "";
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+}  // namespace
+
+namespace tss {
+
+int check_last(const char* what) {
+  const hipError_t err = hipGetLastError();
+  if (err == hipSuccess) return TSS_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(err));
+  return TSS_ERR_HIP;
+}
+
+ProfScope::ProfScope(int kernel_id, hipStream_t s, double alg_bytes, double flops) : slot(-1), stream(s) {
+  if (!g_enabled) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r;
+  r.kid = kernel_id; r.bytes = alg_bytes; r.flops = flops;
+  r.a = get_event(); r.b = get_event();
+  (void)hipEventRecord(r.a, stream);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+}  // namespace tss
+
+extern "C" {
+
+int tss_version(void) { return 1; }
+const char* tss_last_error(void) { return g_err; }
+const char* tss_arch(void) { return "gfx950"; }
+
+int tss_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_enabled = on != 0;
+  return TSS_OK;
+}
+
+int tss_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (Rec& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+  g_recs.clear();
+  for (int i = 0; i < TSS_K_COUNT; ++i) g_tot[i] = Total{0, 0.0, 0.0, 0.0};
+  return TSS_OK;
+}
+
+int tss_prof_collect(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (Rec& r : g_recs) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return TSS_ERR_HIP;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return TSS_ERR_HIP;
+    Total& t = g_tot[r.kid];
+    t.launches += 1; t.ms += ms; t.bytes += r.bytes; t.flops += r.flops;
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return TSS_OK;
+}
+
+int tss_prof_get(int kernel_id, long* launches, double* total_ms, double* alg_bytes, double* flops) {
+  if (kernel_id < 0 || kernel_id >= TSS_K_COUNT) return TSS_ERR_SHAPE;
+  std::lock_guard<std::mutex> lk(g_mu);
+  const Total& t = g_tot[kernel_id];
+  if (launches) *launches = t.launches;
+  if (total_ms) *total_ms = t.ms;
+  if (alg_bytes) *alg_bytes = t.bytes;
+  if (flops) *flops = t.flops;
+  return TSS_OK;
+}
+
+const char* tss_prof_name(int kernel_id) {
+  return (kernel_id >= 0 && kernel_id < TSS_K_COUNT) ? kInfo[kernel_id].name : "";
+}
+const char* tss_prof_symbol(int kernel_id) {
+  return (kernel_id >= 0 && kernel_id < TSS_K_COUNT) ? kInfo[kernel_id].symbol : "";
+}
+
+}  // extern "C"

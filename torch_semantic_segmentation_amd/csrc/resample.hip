@@ -1,0 +1,462 @@
+// Bilinear resampling (align_corners=True everywhere on the hot path) and adaptive average pooling.
+//
+// Index arithmetic follows torch's upsample_bilinear2d exactly: scale = (in-1)/(out-1) in f32 (0 when
+// out == 1), src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+// Backward kernels are gathers (no atomics, deterministic): every input pixel re-evaluates the forward
+// index function over the window of outputs that can touch it, so forward and backward agree bit for
+// bit on which outputs a source pixel feeds.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap ac_tap(float scale, int dst, int in) {
+  const float src = scale * (float)dst;
+  Tap t;
+  t.i0 = (int)src;
+  if (t.i0 > in - 1) t.i0 = in - 1;
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+// outputs whose taps can include source index i: a conservative window [lo, hi]
+__device__ __forceinline__ void ac_window(float scale, int i, int out, int* lo, int* hi) {
+  if (scale <= 0.f) { *lo = 0; *hi = out - 1; return; }
+  int l = (int)floorf((float)(i - 1) / scale) - 1;
+  int h = (int)ceilf((float)(i + 1) / scale) + 1;
+  *lo = l < 0 ? 0 : l;
+  *hi = h > out - 1 ? out - 1 : h;
+}
+// weight with which output `dst` reads source index i (0 if it does not)
+__device__ __forceinline__ float ac_weight(float scale, int dst, int in, int i) {
+  const Tap t = ac_tap(scale, dst, in);
+  float w = 0.f;
+  if (t.i0 == i) w += t.l0;
+  if (t.i1 == i) w += t.l1;
+  return w;
+}
+
+// ---------------------------------------------------------------------------- NHWC <-> NHWC
+template <typename T>
+__global__ __launch_bounds__(NT) void bilinear_nhwc_fwd_kernel(const T* x, long ldx, T* y, long ldy, int B, int Hin,
+                                                               int Win, int Hout, int Wout, int C) {
+  const int CV = C / 8;
+  const long total = (long)B * Hout * Wout * CV;
+  const float sy = ac_scale(Hin, Hout), sx = ac_scale(Win, Wout);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wout); p /= Wout;
+    const int oy = (int)(p % Hout);
+    const long b = p / Hout;
+    const Tap ty = ac_tap(sy, oy, Hin), tx = ac_tap(sx, ox, Win);
+    const T* base = x + (b * Hin * (long)Win) * ldx + cv * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    V8<T>::load(base + ((long)ty.i0 * Win + tx.i0) * ldx, v00);
+    V8<T>::load(base + ((long)ty.i0 * Win + tx.i1) * ldx, v01);
+    V8<T>::load(base + ((long)ty.i1 * Win + tx.i0) * ldx, v10);
+    V8<T>::load(base + ((long)ty.i1 * Win + tx.i1) * ldx, v11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = ty.l0 * (tx.l0 * v00[j] + tx.l1 * v01[j]) + ty.l1 * (tx.l0 * v10[j] + tx.l1 * v11[j]);
+    V8<T>::store(y + ((b * Hout + oy) * (long)Wout + ox) * ldy + cv * 8, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_kernel(const T* dy, long lddy, T* dx, long lddx, int B, int Hin,
+                                                               int Win, int Hout, int Wout, int C) {
+  const int CV = C / 8;
+  const long total = (long)B * Hin * Win * CV;
+  const float sy = ac_scale(Hin, Hout), sx = ac_scale(Win, Wout);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ix = (int)(p % Win); p /= Win;
+    const int iy = (int)(p % Hin);
+    const long b = p / Hin;
+    int ylo, yhi, xlo, xhi;
+    ac_window(sy, iy, Hout, &ylo, &yhi);
+    ac_window(sx, ix, Wout, &xlo, &xhi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = ac_weight(sy, oy, Hin, iy);
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float w = wy * ac_weight(sx, ox, Win, ix);
+        if (w == 0.f) continue;
+        float v[8];
+        V8<T>::load(dy + ((b * Hout + oy) * (long)Wout + ox) * lddy + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+      }
+    }
+    V8<T>::store(dx + ((b * Hin + iy) * (long)Win + ix) * lddx + cv * 8, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------- planar NCHW -> NCHW (image downscale)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(NT) void bilinear_planar_fwd_kernel(const TI* x, TO* y, long planes, int Hin, int Win,
+                                                                 int Hout, int Wout) {
+  const long total = planes * Hout * Wout;
+  const float sy = ac_scale(Hin, Hout), sx = ac_scale(Win, Wout);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % Wout);
+    long p = i / Wout;
+    const int oy = (int)(p % Hout);
+    const long pl = p / Hout;
+    const Tap ty = ac_tap(sy, oy, Hin), tx = ac_tap(sx, ox, Win);
+    const TI* base = x + pl * Hin * (long)Win;
+    const float v00 = (float)base[(long)ty.i0 * Win + tx.i0], v01 = (float)base[(long)ty.i0 * Win + tx.i1];
+    const float v10 = (float)base[(long)ty.i1 * Win + tx.i0], v11 = (float)base[(long)ty.i1 * Win + tx.i1];
+    y[i] = (TO)(ty.l0 * (tx.l0 * v00 + tx.l1 * v01) + ty.l1 * (tx.l0 * v10 + tx.l1 * v11));
+  }
+}
+
+// ---------------------------------------------------------------------------- logits head: NHWC(low) -> NCHW planes
+// One thread = 8 consecutive output x of one (b, class, output row): <= 3 source columns x 2 rows.
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample_head_fwd_kernel(const T* low, long ldl, T* y, int B, int N, int h, int w,
+                                                               int H, int W) {
+  const int W8 = W / 8;
+  const long total = (long)B * N * H * W8;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xg = (int)(i % W8);
+    long p = i / W8;
+    const int oy = (int)(p % H); p /= H;
+    const int n = (int)(p % N);
+    const long b = p / N;
+    const Tap ty = ac_tap(sy, oy, h);
+    const T* r0 = low + ((b * h + ty.i0) * (long)w) * ldl + n;
+    const T* r1 = low + ((b * h + ty.i1) * (long)w) * ldl + n;
+    float o[8];
+    int cached = -1;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;  // column i0 (rows 0,1) and column i1 (rows 0,1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const Tap tx = ac_tap(sx, xg * 8 + j, w);
+      if (tx.i0 != cached) {
+        a0 = (float)r0[(long)tx.i0 * ldl]; a1 = (float)r1[(long)tx.i0 * ldl];
+        b0 = (float)r0[(long)tx.i1 * ldl]; b1 = (float)r1[(long)tx.i1 * ldl];
+        cached = tx.i0;
+      }
+      o[j] = ty.l0 * (tx.l0 * a0 + tx.l1 * b0) + ty.l1 * (tx.l0 * a1 + tx.l1 * b1);
+    }
+    V8<T>::store(y + ((b * N + n) * (long)H + oy) * W + xg * 8, o);
+  }
+}
+
+// backward pass 1 (rows): tmp[b][n][iy][ox] = sum_oy wy(oy, iy) * dy[b][n][oy][ox] * gscale
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample_head_bwd_rows_kernel(const T* dy, float* tmp, const float* gscale,
+                                                                    long planes, int h, int H, int W) {
+  const int W8 = W / 8;
+  const long total = planes * h * W8;
+  const float sy = ac_scale(h, H);
+  const float gs = gscale ? *gscale : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xg = (int)(i % W8);
+    long p = i / W8;
+    const int iy = (int)(p % h);
+    const long pl = p / h;
+    int lo, hi;
+    ac_window(sy, iy, H, &lo, &hi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
+      const float wy = ac_weight(sy, oy, h, iy);
+      if (wy == 0.f) continue;
+      float v[8];
+      V8<T>::load(dy + (pl * H + oy) * (long)W + xg * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wy * v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= gs;
+    V8<float>::store(tmp + (pl * h + iy) * (long)W + xg * 8, acc);
+  }
+}
+// backward pass 2 (columns): dlow[b][iy][ix][n] = sum_ox wx(ox, ix) * tmp[b][n][iy][ox]
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample_head_bwd_cols_kernel(const float* tmp, T* dlow, long ldl, int B, int N,
+                                                                    int h, int w, int W) {
+  const long total = (long)B * N * h * w;
+  const float sx = ac_scale(w, W);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % w);
+    long p = i / w;
+    const int iy = (int)(p % h); p /= h;
+    const int n = (int)(p % N);
+    const long b = p / N;
+    int lo, hi;
+    ac_window(sx, ix, W, &lo, &hi);
+    const float* row = tmp + ((b * N + n) * (long)h + iy) * W;
+    float acc = 0.f;
+    for (int ox = lo; ox <= hi; ++ox) acc += ac_weight(sx, ox, w, ix) * row[ox];
+    dlow[((b * h + iy) * (long)w + ix) * ldl + n] = (T)acc;
+  }
+}
+
+// ---------------------------------------------------------------------------- adaptive average pool (NHWC)
+__device__ __forceinline__ int pool_start(int i, int n, int bins) { return (int)(((long)i * n) / bins); }
+__device__ __forceinline__ int pool_end(int i, int n, int bins) { return (int)((((long)i + 1) * n + bins - 1) / bins); }
+
+template <typename T>
+__global__ __launch_bounds__(NT) void adaptive_pool_fwd_kernel(const T* x, long ldx, T* y, long ldy, int H, int W, int C,
+                                                               int bins, int CV, int NPL) {
+  __shared__ float red[NT * 8];
+  const int cell = blockIdx.x % (bins * bins);
+  const long b = blockIdx.x / (bins * bins);
+  const int bi = cell / bins, bj = cell % bins;
+  const int y0 = pool_start(bi, H, bins), y1 = pool_end(bi, H, bins);
+  const int x0 = pool_start(bj, W, bins), x1 = pool_end(bj, W, bins);
+  const int tid = threadIdx.x, cg = tid % CV, pl = tid / CV;
+  const bool active = pl < NPL;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  if (active) {
+    for (int k = pl; k < n; k += NPL) {
+      const int yy = y0 + k / ww, xx = x0 + k % ww;
+      float v[8];
+      V8<T>::load(x + ((b * H + yy) * (long)W + xx) * ldx + cg * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pl * C + cg * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int q = 0; q < NPL; ++q) s += red[q * C + c];
+    y[(b * bins * bins + cell) * ldy + c] = (T)(s / (float)n);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void adaptive_pool_bwd_kernel(const T* dy, long lddy, T* dx, long lddx, int B, int H,
+                                                               int W, int C, int bins) {
+  const int CV = C / 8;
+  const long total = (long)B * H * W * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const long b = p / H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int bi = 0; bi < bins; ++bi) {
+      const int y0 = pool_start(bi, H, bins), y1 = pool_end(bi, H, bins);
+      if (yy < y0 || yy >= y1) continue;
+      for (int bj = 0; bj < bins; ++bj) {
+        const int x0 = pool_start(bj, W, bins), x1 = pool_end(bj, W, bins);
+        if (xx < x0 || xx >= x1) continue;
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+        float v[8];
+        V8<T>::load(dy + ((b * bins + bi) * (long)bins + bj) * lddy + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j] * inv;
+      }
+    }
+    V8<T>::store(dx + ((b * H + yy) * (long)W + xx) * lddx + cv * 8, acc);
+  }
+}
+
+// copy a [P][C] NHWC tensor into a channel slice of another (concat without torch.cat)
+template <typename T>
+__global__ __launch_bounds__(NT) void copy_nhwc_kernel(const T* x, long ldx, T* y, long ldy, long P, int C) {
+  const int CV = C / 8;
+  const long total = P * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i / CV;
+    const int cv = (int)(i - p * CV);
+    float v[8];
+    V8<T>::load(x + p * ldx + cv * 8, v);
+    V8<T>::store(y + p * ldy + cv * 8, v);
+  }
+}
+
+inline int grid_for(long total) {
+  long g = (total + NT - 1) / NT;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+}  // namespace
+
+#define TSS_DISPATCH(dtype, KERNEL, grid, stream, ...)                                                    \
+  do {                                                                                                    \
+    if ((dtype) == TSS_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL<float>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, __VA_ARGS__);     \
+  } while (0)
+
+extern "C" {
+
+int tss_bilinear_nhwc_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, int Win, int Hout, int Wout,
+                          int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && (ldx % 8) == 0 && (ldy % 8) == 0 && ldx >= C && ldy >= C && Hin > 0 && Win > 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  const long total = (long)B * Hout * Wout * (C / 8);
+  if (total == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_BILINEAR_FWD, (hipStream_t)stream, ((double)B * Hin * Win + (double)B * Hout * Wout) * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(bilinear_nhwc_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, Hin, Win, Hout, Wout, C);
+  else
+    hipLaunchKernelGGL(bilinear_nhwc_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)x, ldx, (float*)y, ldy, B, Hin, Win, Hout, Wout, C);
+  return tss::check_last("bilinear_nhwc_fwd");
+}
+
+int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
+                          int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && (lddy % 8) == 0 && (lddx % 8) == 0 && lddy >= C && lddx >= C, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dy) && tss::aligned16(dx), TSS_ERR_ALIGN);
+  const long total = (long)B * Hin * Win * (C / 8);
+  if (total == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_BILINEAR_BWD, (hipStream_t)stream, ((double)B * Hin * Win + (double)B * Hout * Wout) * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, Hin, Win, Hout, Wout, C);
+  else
+    hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)dy, lddy, (float*)dx, lddx, B, Hin, Win, Hout, Wout, C);
+  return tss::check_last("bilinear_nhwc_bwd");
+}
+
+int tss_bilinear_planar_fwd(const void* x, int x_dtype, void* y, int y_dtype, long planes, int Hin, int Win,
+                            int Hout, int Wout, void* stream) {
+  TSS_REQUIRE((x_dtype == TSS_F32 || x_dtype == TSS_BF16) && (y_dtype == TSS_F32 || y_dtype == TSS_BF16), TSS_ERR_DTYPE);
+  TSS_REQUIRE(Hin > 0 && Win > 0, TSS_ERR_SHAPE);
+  const long total = planes * Hout * Wout;
+  if (total == 0) return TSS_OK;
+  const int grid = grid_for(total);
+  tss::ProfScope prof(TSS_K_BILINEAR_PLANAR_FWD, (hipStream_t)stream,
+                      (double)planes * ((double)Hin * Win * esz(x_dtype) + (double)Hout * Wout * esz(y_dtype)), 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (x_dtype == TSS_F32 && y_dtype == TSS_F32)
+    hipLaunchKernelGGL((bilinear_planar_fwd_kernel<float, float>), dim3(grid), dim3(NT), 0, s, (const float*)x, (float*)y, planes, Hin, Win, Hout, Wout);
+  else if (x_dtype == TSS_F32)
+    hipLaunchKernelGGL((bilinear_planar_fwd_kernel<float, bf16_t>), dim3(grid), dim3(NT), 0, s, (const float*)x, (bf16_t*)y, planes, Hin, Win, Hout, Wout);
+  else if (y_dtype == TSS_F32)
+    hipLaunchKernelGGL((bilinear_planar_fwd_kernel<bf16_t, float>), dim3(grid), dim3(NT), 0, s, (const bf16_t*)x, (float*)y, planes, Hin, Win, Hout, Wout);
+  else
+    hipLaunchKernelGGL((bilinear_planar_fwd_kernel<bf16_t, bf16_t>), dim3(grid), dim3(NT), 0, s, (const bf16_t*)x, (bf16_t*)y, planes, Hin, Win, Hout, Wout);
+  return tss::check_last("bilinear_planar_fwd");
+}
+
+int tss_upsample_head_fwd(const void* low, long ldl, void* y, int B, int N, int h, int w, int H, int W,
+                          int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(N > 0 && ldl >= N && (W % 8) == 0 && h > 0 && w > 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(y), TSS_ERR_ALIGN);
+  const long total = (long)B * N * H * (W / 8);
+  if (total == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_UPSAMPLE_HEAD_FWD, (hipStream_t)stream, ((double)B * N * h * w + (double)B * N * H * W) * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(upsample_head_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
+  else
+    hipLaunchKernelGGL(upsample_head_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+  return tss::check_last("upsample_head_fwd");
+}
+
+int tss_upsample_head_bwd(const void* dy, const float* gscale, float* tmp /*[B*N*h*W] f32 workspace*/,
+                          void* dlow, long ldl, int B, int N, int h, int w, int H, int W, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(N > 0 && ldl >= N && (W % 8) == 0 && h > 0 && w > 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dy) && tss::aligned16(tmp), TSS_ERR_ALIGN);
+  const long planes = (long)B * N;
+  const long t1 = planes * h * (W / 8), t2 = planes * h * w;
+  if (t1 == 0) return TSS_OK;
+  {
+    tss::ProfScope prof(TSS_K_UPSAMPLE_HEAD_BWD_ROWS, (hipStream_t)stream, (double)planes * H * W * esz(dtype) + (double)planes * h * W * 4, 0);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(upsample_head_bwd_rows_kernel<bf16_t>, dim3(grid_for(t1)), dim3(NT), 0, (hipStream_t)stream,
+                         (const bf16_t*)dy, tmp, gscale, planes, h, H, W);
+    else
+      hipLaunchKernelGGL(upsample_head_bwd_rows_kernel<float>, dim3(grid_for(t1)), dim3(NT), 0, (hipStream_t)stream,
+                         (const float*)dy, tmp, gscale, planes, h, H, W);
+  }
+  {
+    tss::ProfScope prof(TSS_K_UPSAMPLE_HEAD_BWD_COLS, (hipStream_t)stream, (double)planes * h * W * 4 + (double)planes * h * w * esz(dtype), 0);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(upsample_head_bwd_cols_kernel<bf16_t>, dim3(grid_for(t2)), dim3(NT), 0, (hipStream_t)stream,
+                         tmp, (bf16_t*)dlow, ldl, B, N, h, w, W);
+    else
+      hipLaunchKernelGGL(upsample_head_bwd_cols_kernel<float>, dim3(grid_for(t2)), dim3(NT), 0, (hipStream_t)stream,
+                         tmp, (float*)dlow, ldl, B, N, h, w, W);
+  }
+  return tss::check_last("upsample_head_bwd");
+}
+
+int tss_adaptive_pool_fwd(const void* x, long ldx, void* y, long ldy, int B, int H, int W, int C, int bins,
+                          int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && C <= NT * 8 && (ldx % 8) == 0 && ldx >= C && ldy >= C && bins >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x), TSS_ERR_ALIGN);
+  if (B == 0) return TSS_OK;
+  const int CV = C / 8, NPL = NT / CV;
+  const int threads = (CV * NPL + 63) / 64 * 64;
+  const int grid = B * bins * bins;
+  tss::ProfScope prof(TSS_K_POOL_FWD, (hipStream_t)stream, (double)B * H * W * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(adaptive_pool_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, ldx, (bf16_t*)y, ldy, H, W, C, bins, CV, NPL);
+  else
+    hipLaunchKernelGGL(adaptive_pool_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream,
+                       (const float*)x, ldx, (float*)y, ldy, H, W, C, bins, CV, NPL);
+  return tss::check_last("adaptive_pool_fwd");
+}
+
+int tss_adaptive_pool_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int H, int W, int C, int bins,
+                          int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && (lddy % 8) == 0 && lddy >= C && (lddx % 8) == 0 && lddx >= C && bins >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dy) && tss::aligned16(dx), TSS_ERR_ALIGN);
+  const long total = (long)B * H * W * (C / 8);
+  if (total == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_POOL_BWD, (hipStream_t)stream, (double)B * H * W * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, H, W, C, bins);
+  else
+    hipLaunchKernelGGL(adaptive_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)dy, lddy, (float*)dx, lddx, B, H, W, C, bins);
+  return tss::check_last("adaptive_pool_bwd");
+}
+
+int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && (ldx % 8) == 0 && (ldy % 8) == 0 && ldx >= C && ldy >= C, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  const long total = P * (C / 8);
+  if (total == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_COPY, (hipStream_t)stream, 2.0 * P * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(copy_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, P, C);
+  else
+    hipLaunchKernelGGL(copy_nhwc_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, P, C);
+  return tss::check_last("copy_nhwc");
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// Weight-gradient contraction for the dense (non-depthwise) convolutions:
+//
+//   dW[n][k] += sum_p G(p, n) * A(p, k)
+//     G(p, n) = ga[n]*e[p][n] + gb[n]*y[p][n] + gd[n]        (deferred BN-backward of this conv's output)
+//     A(p, k) = relu?(x[q(p)][k]*scale[k] + shift[k])        (deferred BN of the producer; q = p for 1x1,
+//                                                             the tap-shifted pixel for 3x3, the NCHW gather
+//                                                             for the 3-channel stem)
+//
+// The contraction index is the pixel, so both operands are needed channel-major.  Tiles are read
+// NHWC-coalesced (16 B per lane) and transposed while they are written to LDS ([channel][pixel]
+// rows of 128 B + 16 B pad, 16-byte chunks XOR-swizzled by channel group so that neither the 2/4-byte
+// transposing stores nor the 16-byte MFMA operand reads pile up on one bank).  Each of the 4 waves
+// owns a 64x64 block of the 128x128 dW tile (16 MFMA accumulators); blocks split the pixel range and
+// add their partial tile to dW with f32 atomics (dW must be zero-initialised or hold a value to
+// accumulate onto, exactly like autograd's .grad).
+#include "common.h"
+
+namespace {
+
+constexpr int TN = 128, TK = 128, NT = 256;
+enum { A_PW = 0, A_TAPS = 1, A_STEM = 2 };
+
+template <typename T> struct WMma;
+template <> struct WMma<bf16_t> {
+  static constexpr int PT = 64, KSTEP = 32;
+  typedef bf16x8 Frag;
+  static __device__ __forceinline__ Frag ld(const unsigned char* row, int swz, int ks, int q) {
+    return *reinterpret_cast<const bf16x8*>(row + (((ks * 4 + q) ^ swz) << 4));
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct WMma<float> {
+  static constexpr int PT = 32, KSTEP = 4;
+  typedef float Frag;
+  static __device__ __forceinline__ Frag ld(const unsigned char* row, int swz, int ks, int q) {
+    return *reinterpret_cast<const float*>(row + ((ks ^ swz) << 4) + q * 4);
+  }
+  static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+constexpr int ROWB = 144;  // bytes per LDS row: 128 B of pixels + 16 B pad (both dtypes)
+
+struct WgradArgs {
+  long P;
+  int ND, KD, ntaps, mode;
+  const void* e; long lde; const void* yraw; long ldyr;
+  const float* ga; const float* gb; const float* gd;
+  const void* x; long ldx; const float* xs; const float* xb; int x_relu, x_f32;
+  int Hin, Win, Hout, Wout, stride, dil, Cin;
+  float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
+  int nsplit;
+};
+
+// transposing store of 8 channel values of one pixel: rows ch0..ch0+7, column px
+template <typename T>
+__device__ __forceinline__ void put8(unsigned char* tile, int ch0, int px, const float v[8]) {
+  const int boff = px * (int)sizeof(T);
+  const int chunk = boff >> 4, within = boff & 15;
+  const int swz = (ch0 >> 3) & 7;
+  unsigned char* base = tile + ch0 * ROWB + ((chunk ^ swz) << 4) + within;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) *reinterpret_cast<T*>(base + j * ROWB) = (T)v[j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
+  typedef WMma<T> M;
+  constexpr int PT = M::PT;
+  __shared__ __align__(16) unsigned char Gt[TN * ROWB];
+  __shared__ __align__(16) unsigned char At[TK * ROWB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wn = wave >> 1, wk = wave & 1;
+
+  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
+  int bid = blockIdx.x;
+  const int split = bid % g.nsplit; bid /= g.nsplit;
+  const int nc = bid % nchn; bid /= nchn;
+  const int kc = bid % nchk; bid /= nchk;
+  const int tap = bid;
+
+  const int n0 = nc * TN, k0 = kc * TK;
+  const int ncw = (g.ND - n0 < TN) ? (g.ND - n0) : TN;
+  const int kcw = (g.KD - k0 < TK) ? (g.KD - k0) : TK;
+  const int nvn = (ncw + 7) >> 3, nvk = (kcw + 7) >> 3;
+
+  const long nstage = (g.P + PT - 1) / PT;
+  const long per = (nstage + g.nsplit - 1) / g.nsplit;
+  const long s_begin = split * per;
+  long s_end = s_begin + per;
+  if (s_end > nstage) s_end = nstage;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // zero both tiles once: rows / chunks that are never staged must read as 0
+  for (int i = tid; i < TN * ROWB / 16; i += NT) {
+    reinterpret_cast<uint4*>(Gt)[i] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+  }
+
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const T* x = reinterpret_cast<const T*>(g.x);
+  const long HWo = (long)g.Hout * g.Wout;
+  const int ky = tap / 3, kx = tap - ky * 3;
+
+  for (long s = s_begin; s < s_end; ++s) {
+    const long p0 = s * PT;
+    __syncthreads();
+    // ---- G tile
+    for (int idx = tid; idx < PT * nvn; idx += NT) {
+      const int px = idx / nvn, cv = idx - px * nvn;
+      const long p = p0 + px;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      if (p < g.P) {
+        const int ch = n0 + cv * 8;
+        float ev[8];
+        V8<T>::load(e + p * g.lde + ch, ev);
+        if (yr) {
+          float yv[8];
+          V8<T>::load(yr + p * g.ldyr + ch, yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (ch + j < g.ND) v[j] = g.ga[ch + j] * ev[j] + g.gb[ch + j] * yv[j] + g.gd[ch + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (ch + j < g.ND) v[j] = g.ga ? g.ga[ch + j] * ev[j] : ev[j];
+        }
+      }
+      put8<T>(Gt, cv * 8, px, v);
+    }
+    // ---- A tile
+    if (g.mode == A_STEM) {
+      const float* src32 = reinterpret_cast<const float*>(g.x);
+      for (int idx = tid; idx < PT * kcw; idx += NT) {
+        const int px = idx % PT, j = idx / PT;
+        const long p = p0 + px;
+        float v = 0.f;
+        if (p < g.P) {
+          const int c = j / 9, t9 = j - c * 9, sy = t9 / 3, sx = t9 - sy * 3;
+          const long b = p / HWo; const long rem = p - b * HWo;
+          const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+          const int iy = oy * g.stride + (sy - 1) * g.dil, ix = ox * g.stride + (sx - 1) * g.dil;
+          if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
+            const long off = ((b * g.Cin + c) * g.Hin + iy) * (long)g.Win + ix;
+            v = g.x_f32 ? src32[off] : (float)x[off];
+          }
+        }
+        const int boff = px * (int)sizeof(T);
+        *reinterpret_cast<T*>(At + j * ROWB + (((boff >> 4) ^ ((j >> 3) & 7)) << 4) + (boff & 15)) = (T)v;
+      }
+    } else {
+      for (int idx = tid; idx < PT * nvk; idx += NT) {
+        const int px = idx / nvk, cv = idx - px * nvk;
+        const long p = p0 + px;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        long q = -1;
+        if (p < g.P) {
+          if (g.mode == A_PW) {
+            q = p;
+          } else {
+            const long b = p / HWo; const long rem = p - b * HWo;
+            const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+            const int iy = oy * g.stride + (ky - 1) * g.dil, ix = ox * g.stride + (kx - 1) * g.dil;
+            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+          }
+        }
+        if (q >= 0) {
+          const int ch = k0 + cv * 8;
+          float xv[8];
+          V8<T>::load(x + q * g.ldx + ch, xv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (ch + j < g.KD) {
+              float a = g.xs ? (xv[j] * g.xs[ch + j] + g.xb[ch + j]) : xv[j];
+              if (g.x_relu) a = a > 0.f ? a : 0.f;
+              v[j] = a;
+            }
+          }
+        }
+        put8<T>(At, cv * 8, px, v);
+      }
+    }
+    __syncthreads();
+    // ---- MFMA over the PT pixels of this stage
+    const unsigned char* grow = Gt + (wn * 64 + fr) * ROWB;
+    const unsigned char* arow = At + (wk * 64 + fr) * ROWB;
+#pragma unroll
+    for (int ks = 0; ks < PT / M::KSTEP; ++ks) {
+      typename M::Frag gf[4], af[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // swizzle key = (row >> 3) & 7 with row = w*64 + i*16 + fr
+        gf[i] = M::ld(grow + i * 16 * ROWB, ((wn * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
+        af[i] = M::ld(arow + i * 16 * ROWB, ((wk * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = M::mma(gf[i], af[j], acc[i][j]);
+    }
+  }
+
+  // ---- add the partial tile: D[row = n][col = k]
+  float* dwt = g.dw + tap * g.dts;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
+        if (n < g.ND && k < g.KD && s_begin < s_end) atomicAdd(dwt + (long)n * g.drs + (long)k * g.dcs, acc[i][j][r]);
+      }
+    }
+}
+
+int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
+  if (g.P <= 0) return TSS_OK;
+  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
+  const int tiles = nchn * nchk * g.ntaps;
+  const int PT = dtype == TSS_BF16 ? WMma<bf16_t>::PT : WMma<float>::PT;
+  const long nstage = (g.P + PT - 1) / PT;
+  long ns = 1024 / tiles;
+  if (ns < 1) ns = 1;
+  if (ns > nstage) ns = nstage;
+  g.nsplit = (int)ns;
+  const int grid = tiles * (int)ns;
+  tss::ProfScope prof(kernel_id, stream, alg_bytes, 2.0 * (double)g.P * g.ND * g.KD * g.ntaps);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(NT), 0, stream, g);
+  else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(NT), 0, stream, g);
+  return tss::check_last("wgrad");
+}
+
+inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+}  // namespace
+
+extern "C" {
+
+int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                          const float* ga, const float* gb, const float* gd,
+                          const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                          float* dw, long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldx % 8) == 0 && ldx >= K, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
+  WgradArgs g = {};
+  g.P = P; g.ND = N; g.KD = K; g.ntaps = 1; g.mode = A_PW;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
+  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.Hout = 1; g.Wout = 1;
+  g.dw = dw; g.drs = K; g.dcs = 1; g.dts = 0;
+  return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream,
+                (double)P * (N * (yraw ? 2 : 1) + K) * esz(dtype));
+}
+
+int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd,
+                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           float* dw, int B, int Hin, int Win, int Cin, int N, int stride, int dil,
+                           int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gd), TSS_ERR_SHAPE);
+  WgradArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.Cin = Cin;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  g.P = (long)B * g.Hout * g.Wout; g.ND = N; g.KD = Cin; g.ntaps = 9; g.mode = A_TAPS;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
+  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 9; g.dts = 1;  // torch layout [N][Cin][3][3]
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
+                ((double)g.P * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin) * esz(dtype));
+}
+
+int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gd,
+                           const void* x_nchw, int x_is_f32, float* dw,
+                           int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin >= 1 && Cin * 9 <= TK && N > 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gd), TSS_ERR_SHAPE);
+  WgradArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = 1; g.Cin = Cin;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  g.P = (long)B * g.Hout * g.Wout; g.ND = N; g.KD = Cin * 9; g.ntaps = 1; g.mode = A_STEM;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
+  g.x = x_nchw; g.x_f32 = x_is_f32;
+  g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 1; g.dts = 0;
+  return launch(g, dtype, TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream,
+                (double)g.P * N * (yraw ? 2 : 1) * esz(dtype) + (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype)));
+}
+
+}  // extern "C"

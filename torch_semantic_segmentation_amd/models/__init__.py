@@ -1,0 +1,3 @@
+from .fastscnn import *      # noqa: F401,F403
+from .contextnet import *    # noqa: F401,F403
+from ._fused import FusedSequential, set_compute_dtype  # noqa: F401

@@ -1,0 +1,129 @@
+"""ContextNet (12/14/18) on the MI355X HIP path: public surface, module tree and state_dict keys (314) of
+TSS/models/contextnet.py; arithmetic in the HIP kernels behind include/tss_hip.h.
+"""
+from torch import nn
+
+from .. import ops
+from ._fused import FusedSequential, run
+
+__all__ = ['ContextNet', 'contextnet12', 'contextnet14', 'contextnet18']
+
+
+def contextnet12(in_channels, out_channels):
+    return ContextNet(in_channels, out_channels, scale_factor=2)
+
+
+def contextnet14(in_channels, out_channels):
+    return ContextNet(in_channels, out_channels, scale_factor=4)
+
+
+def contextnet18(in_channels, out_channels):
+    return ContextNet(in_channels, out_channels, scale_factor=8)
+
+
+def ConvBlock(in_channels, out_channels, kernel_size, padding=0, stride=1, use_relu=True):
+    """conv -> BN -> [ReLU]  (TSS/models/contextnet.py:168-177)"""
+    layers = [nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, stride=stride, bias=False),
+              nn.BatchNorm2d(out_channels)]
+    if use_relu:
+        layers.append(nn.ReLU(inplace=True))
+    return FusedSequential(*layers)
+
+
+def DWConvBlock(in_channels, out_channels, kernel_size, padding=0, stride=1, dilation=1, use_relu=True):
+    """depthwise conv -> BN -> [ReLU]; same ValueError as the reference (TSS/models/contextnet.py:150-165)"""
+    if in_channels != out_channels:
+        raise ValueError("input and output channels must be the same in depthwise convolution")
+    layers = [nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, stride=stride,
+                        dilation=dilation, groups=in_channels, bias=False),
+              nn.BatchNorm2d(out_channels)]
+    if use_relu:
+        layers.append(nn.ReLU(inplace=True))
+    return FusedSequential(*layers)
+
+
+class BottleneckBlock(nn.Module):
+    """(TSS/models/contextnet.py:129-147)"""
+
+    def __init__(self, in_channels, out_channels, stride=1, expansion=6):
+        super().__init__()
+        mid = in_channels * expansion
+        self.conv1 = ConvBlock(in_channels, mid, 1)
+        self.conv2 = DWConvBlock(mid, mid, 3, padding=1, stride=stride)
+        self.conv3 = ConvBlock(mid, out_channels, 1, use_relu=False)
+
+    def forward(self, input):
+        x = ops.to_nhwc(ops.materialize(input))
+        d = run(self.conv3, run(self.conv2, run(self.conv1, x)))
+        same = tuple(d.shape) == tuple(x.shape)
+        return ops.join(d, x if same else None, relu=True)
+
+
+def LinearBottleneck(in_channels, out_channels, num_blocks, expansion=6, stride=1):
+    layers = [BottleneckBlock(in_channels, out_channels, stride=stride, expansion=expansion)]
+    layers += [BottleneckBlock(out_channels, out_channels, expansion=expansion) for _ in range(1, num_blocks)]
+    return FusedSequential(*layers)
+
+
+class FeatureFusionModule(nn.Module):
+    """(TSS/models/contextnet.py:104-126)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        lowres_channels, highres_channels = in_channels
+        self.lowres = FusedSequential(
+            DWConvBlock(lowres_channels, lowres_channels, kernel_size=3, padding=4, dilation=4),
+            ConvBlock(lowres_channels, out_channels, 1, use_relu=False))
+        self.highres = ConvBlock(highres_channels, out_channels, 1, use_relu=False)
+
+    def forward(self, lowres, highres):
+        lowres = ops.bilinear(lowres, size=tuple(highres.shape[2:]))
+        return ops.join(run(self.lowres, lowres), run(self.highres, highres), relu=True)
+
+
+def Classifier(in_channels, out_channels):
+    """(TSS/models/contextnet.py:79-87)"""
+    return FusedSequential(
+        DWConvBlock(in_channels, in_channels, 3, padding=1),
+        ConvBlock(in_channels, in_channels, 1),
+        DWConvBlock(in_channels, in_channels, 3, padding=1),
+        ConvBlock(in_channels, in_channels, 1),
+        nn.Dropout(p=0.1),
+        nn.Conv2d(in_channels, out_channels, 1))
+
+
+class ContextNet(nn.Module):
+    """(TSS/models/contextnet.py:28-76)"""
+
+    scale_factor: int = 4
+
+    def __init__(self, in_channels, out_channels, scale_factor=4):
+        super().__init__()
+        self.scale_factor = scale_factor
+        self.spatial = FusedSequential(
+            ConvBlock(in_channels, 32, 3, padding=1, stride=2),
+            DWConvBlock(32, 32, kernel_size=3, padding=1, stride=2),
+            ConvBlock(32, 64, 1),
+            DWConvBlock(64, 64, kernel_size=3, padding=1, stride=2),
+            ConvBlock(64, 128, 1),
+            DWConvBlock(128, 128, kernel_size=3, padding=1, stride=1),
+            ConvBlock(128, 128, 1))
+        self.context = FusedSequential(
+            ConvBlock(in_channels, 32, 3, padding=1, stride=2),
+            BottleneckBlock(32, 32, expansion=1),
+            BottleneckBlock(32, 32, expansion=6),
+            LinearBottleneck(32, 48, 3, stride=2),
+            LinearBottleneck(48, 64, 3, stride=2),
+            LinearBottleneck(64, 96, 2),
+            LinearBottleneck(96, 128, 2),
+            ConvBlock(128, 128, 3, padding=1))
+        self.feature_fusion = FeatureFusionModule((128, 128), 128)
+        self.classifier = Classifier(128, out_channels)
+
+    def forward(self, input):
+        spatial = self.spatial(input)
+        context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
+        context = self.context(context)
+        fusion = self.feature_fusion(context, spatial)
+        classes = self.classifier(fusion)
+        return ops.upsample_logits(classes, scale_factor=8)

@@ -1,0 +1,136 @@
+"""FastSCNN on the MI355X HIP path: the same public surface as TSS/models/fastscnn.py
+(`FastSCNN`, `fastscnn`, and the block builders the training script imports, scripts/train_fastscnn.py:28),
+the same module tree / state_dict keys (266), every container hookable; the arithmetic runs in the HIP
+kernels behind include/tss_hip.h (ops.py), never in ATen.
+"""
+from torch import nn
+
+from .. import ops
+from ._fused import FusedSequential, run
+
+__all__ = ['FastSCNN', 'fastscnn']
+
+
+def fastscnn(in_channels, out_channels):
+    return FastSCNN(in_channels, out_channels)
+
+
+def _conv_bn(cin, cout, kernel_size, stride, padding, dilation, groups, use_activation):
+    mods = [nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                      groups=groups, bias=False),
+            nn.BatchNorm2d(cout)]
+    if use_activation:
+        mods.append(nn.ReLU(inplace=True))
+    return mods
+
+
+def Conv2dBlock(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, use_activation=True):
+    """conv -> BN -> [ReLU]  (TSS/models/fastscnn.py:164-173)"""
+    return FusedSequential(*_conv_bn(in_channels, out_channels, kernel_size, stride, padding, dilation, 1,
+                                     use_activation))
+
+
+def DWConv2dBlock(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, use_activation=True):
+    """depthwise conv -> BN -> [ReLU]  (TSS/models/fastscnn.py:176-185)"""
+    return FusedSequential(*_conv_bn(in_channels, out_channels, kernel_size, stride, padding, dilation,
+                                     in_channels, use_activation))
+
+
+def DSConv2dBlock(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, use_activation=True):
+    """depthwise -> BN -> pointwise -> BN -> [ReLU], no non-linearity in between (TSS/models/fastscnn.py:188-199)"""
+    return FusedSequential(
+        *_conv_bn(in_channels, in_channels, kernel_size, stride, padding, dilation, in_channels, False),
+        *_conv_bn(in_channels, out_channels, 1, 1, 0, 1, 1, use_activation))
+
+
+class BottleneckBlock(nn.Module):
+    """1x1 expand -> dw 3x3 -> 1x1 project, shape-equal skip, ReLU after the sum (TSS/models/fastscnn.py:138-161).
+    The two expanded tensors stay raw in HBM; only the block output is normalised and written."""
+
+    def __init__(self, in_channels, out_channels, stride=1, expansion=6):
+        super().__init__()
+        mid = expansion * in_channels
+        self.conv1 = Conv2dBlock(in_channels, mid, kernel_size=1)
+        self.conv2 = DWConv2dBlock(mid, mid, kernel_size=3, padding=1, stride=stride)
+        self.conv3 = Conv2dBlock(mid, out_channels, kernel_size=1, use_activation=False)
+
+    def forward(self, input):
+        x = ops.to_nhwc(ops.materialize(input))
+        d = run(self.conv3, run(self.conv2, run(self.conv1, x)))
+        same = tuple(d.shape) == tuple(x.shape)
+        return ops.join(d, x if same else None, relu=True)
+
+
+def BottleneckModule(in_channels, out_channels, expansion, repeats=1, stride=1):
+    blocks = [BottleneckBlock(in_channels, out_channels, expansion=expansion, stride=stride)]
+    blocks += [BottleneckBlock(out_channels, out_channels, expansion=expansion) for _ in range(1, repeats)]
+    return FusedSequential(*blocks)
+
+
+class PyramidPoolingModule(nn.Module):
+    """(TSS/models/fastscnn.py:101-123) pooled branches are written straight into the concat buffer."""
+
+    def __init__(self, in_channels, out_channels, pyramids=(1, 2, 3, 6)):
+        super().__init__()
+        self.pyramids = nn.ModuleList([
+            FusedSequential(nn.AdaptiveAvgPool2d(bins),
+                            Conv2dBlock(in_channels, in_channels // len(pyramids), kernel_size=1))
+            for bins in pyramids])
+        self.conv = Conv2dBlock(in_channels * 2, out_channels, kernel_size=1)
+
+    def forward(self, input):
+        x = ops.to_nhwc(ops.materialize(input))
+        pools = [pool(x) for pool in self.pyramids.children()]
+        return self.conv(ops.concat_upsampled(x, pools))
+
+
+class FeatureFusionModule(nn.Module):
+    """(TSS/models/fastscnn.py:67-89) relu(lowres + highres) with both BatchNorms applied inside the join."""
+
+    def __init__(self, in_channels, out_channels, scale_factor):
+        super().__init__()
+        lowres_channels, highres_channels = in_channels
+        self.lowres = FusedSequential(
+            nn.UpsamplingBilinear2d(scale_factor=scale_factor),
+            DWConv2dBlock(lowres_channels, lowres_channels, kernel_size=3, padding=scale_factor,
+                          dilation=scale_factor),
+            Conv2dBlock(lowres_channels, out_channels, kernel_size=1, use_activation=False))
+        self.highres = FusedSequential(
+            Conv2dBlock(highres_channels, out_channels, kernel_size=1, use_activation=False))
+
+    def forward(self, lowres, highres):
+        return ops.join(run(self.lowres, lowres), run(self.highres, highres), relu=True)
+
+
+def Classifier(in_channels, out_channels):
+    """(TSS/models/fastscnn.py:92-98) also used for the deep-supervision heads of the training script."""
+    return FusedSequential(
+        DSConv2dBlock(in_channels, in_channels, kernel_size=3, padding=1),
+        DSConv2dBlock(in_channels, in_channels, kernel_size=3, padding=1),
+        nn.Dropout(0.1),
+        nn.Conv2d(in_channels, out_channels, kernel_size=1))
+
+
+class FastSCNN(nn.Module):
+    """(TSS/models/fastscnn.py:15-64)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.downsample = FusedSequential(
+            Conv2dBlock(in_channels, 32, kernel_size=3, padding=1, stride=2),
+            DSConv2dBlock(32, 48, kernel_size=3, padding=1, stride=2),
+            DSConv2dBlock(48, 64, kernel_size=3, padding=1, stride=2))
+        self.features = FusedSequential(
+            BottleneckModule(64, 64, expansion=6, repeats=3, stride=2),
+            BottleneckModule(64, 96, expansion=6, repeats=3, stride=2),
+            BottleneckModule(96, 128, expansion=6, repeats=3, stride=1),
+            PyramidPoolingModule(128, 128))
+        self.fusion = FeatureFusionModule((128, 64), 128, scale_factor=4)
+        self.classifier = Classifier(128, out_channels)
+
+    def forward(self, input):
+        downsample = self.downsample(input)
+        features = self.features(downsample)
+        fusion = self.fusion(features, downsample)
+        classes = self.classifier(fusion)
+        return ops.upsample_logits(classes, scale_factor=8)

@@ -1,0 +1,644 @@
+"""Autograd operators of the HIP path: thin Python glue over include/tss_hip.h.
+
+Design: a convolution stores its output RAW.  The BatchNorm(+ReLU) that follows it in the
+reference's blocks (TSS/models/fastscnn.py:164-199, TSS/models/contextnet.py:150-177) is carried as a
+`Deferred` (raw tensor + per-channel affine + relu flag) and applied by the consumer while it loads its
+input; a normalised activation is only written where the reference needs a real tensor (block outputs,
+residual sums) by `join`.  Backward mirrors it: between two of these operators the tensor handed back
+through autograd for a raw conv output is e = d(loss)/d(BN output), already ReLU-masked, and the
+BatchNorm backward (which needs two per-channel sums over e) is applied on load by the producer's
+backward kernels from coefficients finalised out of `BNLink.bstats`.  Tensors that leave a block are
+ordinary tensors with ordinary gradients.
+
+There is no torch/ATen fallback here: every operator calls the C ABI and raises if it is unavailable.
+"""
+import torch
+from torch.autograd import Function
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import _native as N
+
+call, ptr, stream = N.call, N.ptr, N.stream
+
+
+# ----------------------------------------------------------------------------- layout helpers
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def new_nhwc(b, c, h, w, dtype, device, ld=None):
+    """Logical (B,C,H,W) tensor stored NHWC with row pitch `ld` (>= C, multiple of 8)."""
+    ld = round_up(c, 8) if ld is None else ld
+    base = torch.empty((b, h, w, ld), dtype=dtype, device=device)
+    t = base.permute(0, 3, 1, 2)
+    return t if ld == c else t[:, :c]
+
+
+def is_nhwc(t):
+    if t.dim() != 4 or not t.is_cuda:
+        return False
+    b, c, h, w = t.shape
+    ld = t.stride(3)
+    return (t.stride() == (h * w * ld, 1, w * ld, ld) and ld % 8 == 0 and ld >= c
+            and t.data_ptr() % 16 == 0)
+
+
+def to_nhwc(t):
+    """Canonical NHWC-strided view/copy of a logical NCHW tensor (the copy is boundary plumbing)."""
+    if is_nhwc(t):
+        return t
+    _check_device(t)
+    out = new_nhwc(*t.shape, t.dtype, t.device)
+    out.copy_(t)
+    return out
+
+
+def _check_device(t):
+    if not t.is_cuda:
+        raise RuntimeError('torch_semantic_segmentation_amd runs on the MI355X HIP path only: got a %s tensor. '
+                           'There is no CPU fallback (the CPU oracle lives in oracle/, for tests).' % t.device)
+    N.lib()
+
+
+def ld(t):
+    return t.stride(3)
+
+
+def npix(t):
+    return t.shape[0] * t.shape[2] * t.shape[3]
+
+
+# ----------------------------------------------------------------------------- deferred BatchNorm
+
+class BNLink:
+    """State shared by the producer and the consumer of one deferred BatchNorm."""
+    __slots__ = ('C', 'count', 'training', 'gamma', 'vec', 'scale', 'shift', 'mean', 'invstd',
+                 'ga', 'gb', 'gd', 'stats', 'bstats', 'consumed')
+
+    def __init__(self, C, count, training, gamma, device):
+        self.C, self.count, self.training, self.gamma = C, count, training, gamma
+        self.vec = torch.empty((7, C), dtype=torch.float32, device=device)
+        self.scale, self.shift, self.mean, self.invstd, self.ga, self.gb, self.gd = self.vec.unbind(0)
+        both = torch.zeros((2, 2 * C), dtype=torch.float64, device=device)
+        self.stats, self.bstats = both[0], both[1]
+        self.consumed = False
+
+
+class Deferred:
+    """A raw conv output plus the BatchNorm(+ReLU) that its consumer still has to apply."""
+    __slots__ = ('raw', 'link', 'relu')
+
+    def __init__(self, raw, link=None, relu=False):
+        self.raw, self.link, self.relu = raw, link, relu
+
+    @property
+    def shape(self):
+        return self.raw.shape
+
+    def affine(self):
+        if self.link is None:
+            return None, None
+        return self.link.scale, self.link.shift
+
+    def take(self):
+        """Mark the single allowed consumption of a BN-pending tensor (its backward sums are single-use)."""
+        if self.link is not None:
+            if self.link.consumed:
+                raise RuntimeError('a deferred BatchNorm output may feed exactly one consumer; materialize it first')
+            self.link.consumed = True
+        return self
+
+
+def as_deferred(x):
+    if isinstance(x, Deferred):
+        return x
+    _check_device(x)
+    N.dtype_code(x.dtype)
+    return Deferred(to_nhwc(x))
+
+
+def materialize(d, relu_override=None):
+    """Deferred -> ordinary tensor (applies the pending BatchNorm/ReLU with one `join` pass)."""
+    if not isinstance(d, Deferred):
+        return d
+    if d.link is None and not d.relu:
+        return d.raw
+    return join(d, None, d.relu)
+
+
+# ----------------------------------------------------------------------------- convolution unit
+
+class UnitCfg:
+    __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
+                 'image_f32', 'cin', 'cout')
+
+
+def _classify(conv, x_is_image):
+    k = conv.kernel_size
+    if conv.padding_mode != 'zeros' or k[0] != k[1] or conv.stride[0] != conv.stride[1] \
+            or conv.dilation[0] != conv.dilation[1] or conv.padding[0] != conv.padding[1]:
+        raise NotImplementedError('HIP path: square kernels/strides/dilations with zero padding only: %r' % conv)
+    k, s, d, p = k[0], conv.stride[0], conv.dilation[0], conv.padding[0]
+    if k == 1:
+        if conv.groups != 1 or s != 1 or p != 0:
+            raise NotImplementedError('HIP path: 1x1 convolutions must be dense, stride 1, padding 0: %r' % conv)
+        return 'pw', 1, 1
+    if k != 3 or p != d:
+        raise NotImplementedError('HIP path: 3x3 convolutions need padding == dilation: %r' % conv)
+    if conv.groups == conv.in_channels == conv.out_channels and conv.groups > 1:
+        return 'dw', s, d
+    if conv.groups != 1:
+        raise NotImplementedError('HIP path: grouped convolutions other than depthwise are not on the hot path: %r' % conv)
+    if x_is_image:
+        if d != 1 or conv.in_channels * 9 > 64:
+            raise NotImplementedError('HIP path: image stem needs dilation 1 and in_channels*9 <= 64: %r' % conv)
+        return 'stem', s, 1
+    return 'dense', s, d
+
+
+def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
+    """conv -> [BatchNorm] -> [ReLU] as ONE deferred unit.  `x` is a Deferred, an NHWC/NCHW activation tensor
+    or (for the stem) the contiguous NCHW image.  Returns a Deferred."""
+    is_image = (not isinstance(x, Deferred)) and x.dim() == 4 and x.shape[1] % 8 != 0
+    kind, stride, dil = _classify(conv, is_image)
+    cfg = UnitCfg()
+    cfg.kind, cfg.stride, cfg.dil = kind, stride, dil
+    cfg.cin, cfg.cout = conv.in_channels, conv.out_channels
+    if kind == 'stem':
+        _check_device(x)
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError('image must be float32 or bfloat16')
+        x_raw = x.contiguous()
+        cfg.in_link, cfg.in_relu = None, False
+        cfg.image_f32 = x_raw.dtype == torch.float32
+        cfg.out_dtype = out_dtype or x_raw.dtype
+    else:
+        d = as_deferred(x).take()
+        x_raw = d.raw
+        cfg.in_link, cfg.in_relu = d.link, d.relu
+        cfg.image_f32 = False
+        cfg.out_dtype = x_raw.dtype
+    if x_raw.shape[1] != conv.in_channels:
+        raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
+    if conv.weight.dtype != torch.float32:
+        raise TypeError('HIP path keeps parameters in float32 (activations may be bfloat16); got %s' % conv.weight.dtype)
+    cfg.bn = bn
+    cfg.training = False
+    gamma = beta = None
+    if bn is not None:
+        if not isinstance(bn, _BatchNorm):
+            raise TypeError('expected a BatchNorm module, got %r' % bn)
+        cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
+        if cfg.training and bn.momentum is None:
+            raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
+        gamma, beta = bn.weight, bn.bias
+    y = ConvUnitFn.apply(x_raw, conv.weight, gamma, beta, conv.bias, cfg)
+    return Deferred(y, cfg.out_link, relu)
+
+
+class ConvUnitFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, bias, cfg):
+        dev = x.device
+        B = x.shape[0]
+        dt = N.dtype_code(cfg.out_dtype)
+        s, d = cfg.stride, cfg.dil
+        Hin, Win = x.shape[2], x.shape[3]
+        Ho, Wo = (Hin - 1) // s + 1, (Win - 1) // s + 1
+        Cout = cfg.cout
+        y = new_nhwc(B, Cout, Ho, Wo, cfg.out_dtype, dev)
+        P = B * Ho * Wo
+        link = None
+        if cfg.bn is not None:
+            if cfg.training and P <= 1:
+                raise ValueError('Expected more than 1 value per channel when training, got input size %s'
+                                 % (tuple(y.shape),))
+            link = BNLink(Cout, P, cfg.training, gamma, dev)
+        stats = ptr(link.stats) if (link is not None and cfg.training) else None
+        isc, ish = (cfg.in_link.scale, cfg.in_link.shift) if cfg.in_link is not None else (None, None)
+        st = stream()
+        if cfg.kind == 'pw':
+            call('tss_pwconv_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(weight), ptr(bias),
+                 ptr(y), ld(y), stats, P, cfg.cin, Cout, dt, st)
+        elif cfg.kind == 'dw':
+            if bias is not None:
+                raise NotImplementedError('HIP path: depthwise convolution with bias')
+            call('tss_dwconv3x3_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(weight),
+                 ptr(y), ld(y), stats, B, Hin, Win, Cout, s, d, dt, st)
+        elif cfg.kind == 'dense':
+            if bias is not None:
+                raise NotImplementedError('HIP path: dense 3x3 convolution with bias')
+            w_tnc = torch.empty((9, Cout, cfg.cin), dtype=torch.float32, device=dev)
+            call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
+            call('tss_conv3x3_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(w_tnc),
+                 ptr(y), ld(y), stats, B, Hin, Win, cfg.cin, Cout, s, d, dt, st)
+        else:  # stem
+            if bias is not None:
+                raise NotImplementedError('HIP path: stem convolution with bias')
+            call('tss_stem3x3_fwd', ptr(x), int(cfg.image_f32), ptr(weight), ptr(y), ld(y), stats,
+                 B, cfg.cin, Hin, Win, Cout, s, dt, st)
+        if link is not None:
+            bn = cfg.bn
+            if cfg.training:
+                track = bn.track_running_stats and bn.running_mean is not None
+                call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), ptr(beta), float(bn.eps),
+                     float(bn.momentum), ptr(bn.running_mean) if track else None,
+                     ptr(bn.running_var) if track else None,
+                     ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
+                     ptr(link.mean), ptr(link.invstd), ptr(link.scale), ptr(link.shift), Cout, st)
+            else:
+                call('tss_bn_eval_affine', ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
+                     float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), ptr(link.shift), Cout, st)
+        cfg.out_link = link
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, weight, y if link is not None else None)
+        ctx.has_bias = bias is not None
+        ctx.has_affine = gamma is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, e):
+        cfg = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        dev = x.device
+        e = to_nhwc(e)
+        dt = N.dtype_code(e.dtype)
+        st = stream()
+        link = cfg.out_link
+        B, Hin, Win = x.shape[0], x.shape[2], x.shape[3]
+        s, d = cfg.stride, cfg.dil
+        Cout, Cin = cfg.cout, cfg.cin
+        P = npix(e)
+        dgamma = dbeta = None
+        if link is not None:
+            if ctx.has_affine:
+                dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                dgamma, dbeta = dgb[0], dgb[1]
+            call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.mean), ptr(link.invstd),
+                 ptr(link.gamma), int(link.training), 0, ptr(dgamma), ptr(dbeta),
+                 ptr(link.ga), ptr(link.gb), ptr(link.gd), Cout, st)
+            ga, gb, gd = link.ga, link.gb, link.gd
+            if not link.training:
+                y, gb, gd = None, None, None
+        else:
+            ga = gb = gd = None
+            y = None
+        gargs = (ptr(e), ld(e), ptr(y), ld(y) if y is not None else 0, ptr(ga), ptr(gb), ptr(gd))
+        il = cfg.in_link
+        isc, ish = (il.scale, il.shift) if il is not None else (None, None)
+
+        dw = torch.zeros_like(weight)
+        need_dx = ctx.needs_input_grad[0]
+        e_in = None
+        if cfg.kind == 'stem':
+            call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw),
+                 B, Cin, Hin, Win, Cout, s, dt, st)
+            if need_dx:
+                raise NotImplementedError('HIP path: gradient with respect to the input image is not implemented')
+        else:
+            xargs = (ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu))
+            deferred_in = il is not None or cfg.in_relu
+            if cfg.kind == 'pw':
+                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, st)
+            elif cfg.kind == 'dw':
+                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cout, s, d, dt, st)
+            else:
+                call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, st)
+            if need_dx:
+                e_in = new_nhwc(B, Cin, Hin, Win, e.dtype, dev)
+                margs = xargs if deferred_in else (None, 0, None, None, 0)
+                bst = ptr(il.bstats) if il is not None else None
+                if cfg.kind == 'pw':
+                    call('tss_pwconv_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
+                         P, Cin, Cout, dt, st)
+                elif cfg.kind == 'dw':
+                    call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
+                         B, Hin, Win, Cout, s, d, dt, st)
+                else:
+                    if s != 1:
+                        raise NotImplementedError('HIP path: input gradient of a strided dense 3x3 convolution')
+                    w_tcn = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
+                    call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
+                    call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
+                         B, Hin, Win, Cin, Cout, d, dt, st)
+        dbias = None
+        if ctx.has_bias:
+            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
+            call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
+        return e_in, dw, dgamma, dbeta, dbias, None
+
+
+# ----------------------------------------------------------------------------- join (materialise / add / relu)
+
+class JoinCfg:
+    __slots__ = ('a_link', 'b_link', 'relu')
+
+
+def join(a, b=None, relu=False):
+    """relu?(bn_a(a) + bn_b(b)) -> ordinary NHWC tensor.  a, b: Deferred (without pending ReLU) or tensors."""
+    a = as_deferred(a).take()
+    cfg = JoinCfg()
+    cfg.relu = bool(relu)
+    if a.relu and (b is not None or not relu):
+        raise RuntimeError('join: a pending ReLU can only be folded into a single-input relu join')
+    cfg.a_link = a.link
+    braw = None
+    cfg.b_link = None
+    if b is not None:
+        b = as_deferred(b).take()
+        if b.relu:
+            raise RuntimeError('join: operand b carries a pending ReLU; materialize it first')
+        if b.raw.shape != a.raw.shape or b.raw.dtype != a.raw.dtype:
+            raise RuntimeError('join: operands differ in shape/dtype: %s vs %s' % (a.raw.shape, b.raw.shape))
+        braw, cfg.b_link = b.raw, b.link
+    return JoinFn.apply(a.raw, braw, cfg)
+
+
+class JoinFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, cfg):
+        out = new_nhwc(*a.shape, a.dtype, a.device)
+        al, bl = cfg.a_link, cfg.b_link
+        call('tss_join_fwd', ptr(a), ld(a), ptr(al.scale) if al else None, ptr(al.shift) if al else None,
+             ptr(b), ld(b) if b is not None else 0, ptr(bl.scale) if bl else None, ptr(bl.shift) if bl else None,
+             ptr(out), ld(out), int(cfg.relu), npix(a), a.shape[1], N.dtype_code(a.dtype), stream())
+        ctx.cfg = cfg
+        ctx.has_b = b is not None
+        ctx.save_for_backward(a if al is not None else None, b if bl is not None else None,
+                              out if cfg.relu else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        a, b, out = ctx.saved_tensors
+        dout = to_nhwc(dout)
+        al, bl = cfg.a_link, cfg.b_link
+        e = new_nhwc(*dout.shape, dout.dtype, dout.device) if cfg.relu else None
+        if cfg.relu or al is not None or bl is not None:
+            call('tss_join_bwd', ptr(dout), ld(dout), ptr(out), ld(out) if out is not None else 0, int(cfg.relu),
+                 ptr(a), ld(a) if a is not None else 0, ptr(al.bstats) if al else None,
+                 ptr(b), ld(b) if b is not None else 0, ptr(bl.bstats) if bl else None,
+                 ptr(e), ld(e) if e is not None else 0, npix(dout), dout.shape[1],
+                 N.dtype_code(dout.dtype), stream())
+        g = e if e is not None else dout
+        return g, (g if ctx.has_b else None), None
+
+
+# ----------------------------------------------------------------------------- dropout
+
+_dropout_counters = {}
+
+
+def _dropout_counter(device):
+    key = (device.type, device.index)
+    if key not in _dropout_counters:
+        seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        _dropout_counters[key] = torch.tensor([seed], dtype=torch.int64, device=device)
+    return _dropout_counters[key]
+
+
+def dropout(x, p, training):
+    """nn.Dropout on a materialised NHWC tensor (Philox mask, regenerated in backward)."""
+    if not training or p == 0.0:
+        return x
+    if p >= 1.0:
+        raise NotImplementedError('HIP path: dropout with p >= 1')
+    return DropoutFn.apply(to_nhwc(x), float(p))
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        slot = torch.empty(1, dtype=torch.int64, device=x.device)
+        call('tss_dropout_tick', ptr(_dropout_counter(x.device)), ptr(slot), stream())
+        y = new_nhwc(*x.shape, x.dtype, x.device)
+        call('tss_dropout', ptr(x), ld(x), ptr(y), ld(y), npix(x), x.shape[1], p, ptr(slot),
+             N.dtype_code(x.dtype), stream())
+        ctx.p = p
+        ctx.save_for_backward(slot)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (slot,) = ctx.saved_tensors
+        dy = to_nhwc(dy)
+        dx = new_nhwc(*dy.shape, dy.dtype, dy.device)
+        call('tss_dropout', ptr(dy), ld(dy), ptr(dx), ld(dx), npix(dy), dy.shape[1], ctx.p, ptr(slot),
+             N.dtype_code(dy.dtype), stream())
+        return dx, None
+
+
+# ----------------------------------------------------------------------------- resampling
+
+def _out_size(x, size, scale_factor):
+    if size is not None:
+        return (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+    sf = (scale_factor, scale_factor) if not isinstance(scale_factor, (tuple, list)) else scale_factor
+    # torch: output = floor(input * scale_factor)
+    import math
+    return int(math.floor(x.shape[2] * sf[0])), int(math.floor(x.shape[3] * sf[1]))
+
+
+def bilinear(x, size=None, scale_factor=None, out=None):
+    """F.interpolate(mode='bilinear', align_corners=True) on an NHWC activation tensor."""
+    x = to_nhwc(materialize(x))
+    ho, wo = _out_size(x, size, scale_factor)
+    return BilinearFn.apply(x, ho, wo)
+
+
+class BilinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, ho, wo):
+        B, C, H, W = x.shape
+        y = new_nhwc(B, C, ho, wo, x.dtype, x.device)
+        call('tss_bilinear_nhwc_fwd', ptr(x), ld(x), ptr(y), ld(y), B, H, W, ho, wo, C,
+             N.dtype_code(x.dtype), stream())
+        ctx.geom = (B, C, H, W, ho, wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, ho, wo = ctx.geom
+        dy = to_nhwc(dy)
+        dx = new_nhwc(B, C, H, W, dy.dtype, dy.device)
+        call('tss_bilinear_nhwc_bwd', ptr(dy), ld(dy), ptr(dx), ld(dx), B, H, W, ho, wo, C,
+             N.dtype_code(dy.dtype), stream())
+        return dx, None, None
+
+
+def resize_image(x, size=None, scale_factor=None, out_dtype=None):
+    """Bilinear (align_corners=True) resize of the NCHW image itself (ContextNet's context branch input,
+    TSS/models/contextnet.py:65-67).  No gradient flows to the image."""
+    _check_device(x)
+    x = x.contiguous()
+    ho, wo = _out_size(x, size, scale_factor)
+    B, C, H, W = x.shape
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty((B, C, ho, wo), dtype=out_dtype, device=x.device)
+    call('tss_bilinear_planar_fwd', ptr(x), N.dtype_code(x.dtype), ptr(y), N.dtype_code(out_dtype),
+         B * C, H, W, ho, wo, stream())
+    return y
+
+
+def upsample_logits(low, scale_factor=None, size=None):
+    """The decoder head's final F.interpolate: NHWC low-res logits -> NCHW-contiguous full-res logits."""
+    low = to_nhwc(materialize(low))
+    ho, wo = _out_size(low, size, scale_factor)
+    if wo % 8:
+        raise NotImplementedError('HIP path: logits width must be a multiple of 8, got %d' % wo)
+    return UpsampleHeadFn.apply(low, ho, wo)
+
+
+class UpsampleHeadFn(Function):
+    @staticmethod
+    def forward(ctx, low, ho, wo):
+        B, C, h, w = low.shape
+        y = torch.empty((B, C, ho, wo), dtype=low.dtype, device=low.device)
+        call('tss_upsample_head_fwd', ptr(low), ld(low), ptr(y), B, C, h, w, ho, wo,
+             N.dtype_code(low.dtype), stream())
+        ctx.geom = (B, C, h, w, ho, wo, ld(low))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, h, w, ho, wo, ldl = ctx.geom
+        dy = dy.contiguous()
+        tmp = torch.empty((B * C * h * wo,), dtype=torch.float32, device=dy.device)
+        # padded channels of dlow must be finite zeros: they are read (and discarded) by 8-wide loaders
+        base = torch.zeros((B, h, w, ldl), dtype=dy.dtype, device=dy.device)
+        dlow = base.permute(0, 3, 1, 2)[:, :C]
+        call('tss_upsample_head_bwd', ptr(dy), None, ptr(tmp), ptr(dlow), ldl, B, C, h, w, ho, wo,
+             N.dtype_code(dy.dtype), stream())
+        return dlow, None, None
+
+
+def adaptive_avg_pool(x, bins):
+    x = to_nhwc(materialize(x))
+    return AdaptivePoolFn.apply(x, int(bins))
+
+
+class AdaptivePoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, bins):
+        B, C, H, W = x.shape
+        y = new_nhwc(B, C, bins, bins, x.dtype, x.device)
+        call('tss_adaptive_pool_fwd', ptr(x), ld(x), ptr(y), ld(y), B, H, W, C, bins,
+             N.dtype_code(x.dtype), stream())
+        ctx.geom = (B, C, H, W, bins)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W, bins = ctx.geom
+        dy = to_nhwc(dy)
+        dx = new_nhwc(B, C, H, W, dy.dtype, dy.device)
+        call('tss_adaptive_pool_bwd', ptr(dy), ld(dy), ptr(dx), ld(dx), B, H, W, C, bins,
+             N.dtype_code(dy.dtype), stream())
+        return dx, None
+
+
+def concat_upsampled(x, branches):
+    """torch.cat([x, *[bilinear(b, size=x.shape[2:]) for b in branches]], dim=1) written in place into one
+    NHWC buffer (TSS/models/fastscnn.py:118-122)."""
+    x = to_nhwc(materialize(x))
+    branches = [to_nhwc(materialize(b)) for b in branches]
+    return ConcatUpFn.apply(x, *branches)
+
+
+class ConcatUpFn(Function):
+    @staticmethod
+    def forward(ctx, x, *branches):
+        B, C, H, W = x.shape
+        ctot = C + sum(b.shape[1] for b in branches)
+        out = new_nhwc(B, ctot, H, W, x.dtype, x.device)
+        dt, st = N.dtype_code(x.dtype), stream()
+        call('tss_copy_nhwc', ptr(x), ld(x), ptr(out), ld(out), npix(x), C, dt, st)
+        off = C
+        geoms = []
+        for b in branches:
+            cb, hb, wb = b.shape[1], b.shape[2], b.shape[3]
+            sl = out[:, off:off + cb]
+            call('tss_bilinear_nhwc_fwd', ptr(b), ld(b), ptr(sl), ld(out), B, hb, wb, H, W, cb, dt, st)
+            geoms.append((off, cb, hb, wb))
+            off += cb
+        ctx.geom = (B, C, H, W, geoms)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, C, H, W, geoms = ctx.geom
+        dout = to_nhwc(dout)
+        dt, st = N.dtype_code(dout.dtype), stream()
+        grads = [dout[:, :C]]
+        for off, cb, hb, wb in geoms:
+            db = new_nhwc(B, cb, hb, wb, dout.dtype, dout.device)
+            sl = dout[:, off:off + cb]
+            call('tss_bilinear_nhwc_bwd', ptr(sl), ld(dout), ptr(db), ld(db), B, hb, wb, H, W, cb, dt, st)
+            grads.append(db)
+        return tuple(grads)
+
+
+# ----------------------------------------------------------------------------- loss / metrics (caller side)
+
+class CrossEntropyFn(Function):
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        _check_device(logits)
+        logits = logits.contiguous()
+        B, C, H, W = logits.shape
+        if (H * W) % 8:
+            raise NotImplementedError('HIP path: H*W must be a multiple of 8')
+        if target.dtype != torch.int64 or target.shape != (B, H, W):
+            raise RuntimeError('target must be int64 of shape (B,H,W)')
+        target = target.contiguous()
+        dev = logits.device
+        lse = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        call('tss_cross_entropy_fwd', ptr(logits), ptr(target), ptr(lse), ptr(acc), ptr(scal[0:1]), ptr(scal[1:2]),
+             B, C, H * W, int(ignore_index), N.dtype_code(logits.dtype), stream())
+        ctx.ignore_index = int(ignore_index)
+        ctx.save_for_backward(logits, target, lse, scal)
+        return scal[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, lse, scal = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        gout = gout.to(torch.float32).contiguous()
+        d = torch.empty_like(logits)
+        call('tss_cross_entropy_bwd', ptr(logits), ptr(target), ptr(lse), ptr(scal[1:2]), ptr(gout), ptr(d),
+             B, C, H * W, ctx.ignore_index, N.dtype_code(logits.dtype), stream())
+        return d, None, None
+
+
+def cross_entropy(logits, target, ignore_index=-100):
+    """F.cross_entropy(logits, target, ignore_index=..., reduction='mean') for (B,C,H,W) logits."""
+    return CrossEntropyFn.apply(logits, target, ignore_index)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for nn.CrossEntropyLoss(ignore_index=...) as scripts/train_fastscnn.py:132 builds it."""
+
+    def __init__(self, ignore_index=-100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, input, target):
+        return cross_entropy(input, target, self.ignore_index)
+
+
+def argmax_confusion(logits, target=None, num_classes=None, ignore_index=255, confusion=None, want_pred=True):
+    """argmax over dim 1 (lowest index wins ties) and, with a target, the confusion-matrix update
+    (rows = truth, cols = prediction) that create_segmentation_evaluator's metrics need (TSS/engine.py:65-72)."""
+    _check_device(logits)
+    logits = logits.contiguous()
+    B, C, H, W = logits.shape
+    pred = torch.empty((B, H, W), dtype=torch.uint8, device=logits.device) if want_pred else None
+    if target is not None and confusion is None:
+        confusion = torch.zeros((C, C), dtype=torch.int64, device=logits.device)
+    call('tss_argmax_confusion', ptr(logits), ptr(target.contiguous()) if target is not None else None, ptr(pred),
+         ptr(confusion), B, C, H * W, int(ignore_index), N.dtype_code(logits.dtype), stream())
+    return pred, confusion
