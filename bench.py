@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of one full FastSCNN train step (zero_grad + forward + CrossEntropy(ignore 255)
++ backward + AdamW) on synthetic 8 x 3 x 1024 x 2048 batches per GPU, bf16 activations / f32 parameters.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model fastscnn|contextnet14] [--dtype bf16|f32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : the kernel with the largest share of step time, timed with HIP events on its launch stream
+                 (libtss_hip's profiler) over a few un-captured steps; achieved = algorithmic bytes / time.
+  cpu_baseline : the CPU oracle (oracle/, a torch restatement of the reference) timed on this node's host
+                 cores on a bounded sample of the same workload, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--batch', type=int, default=8, help='images per GPU')
+    ap.add_argument('--height', type=int, default=1024)
+    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--stock', action='store_true', help='also time the stock PyTorch-ROCm (MIOpen) path of the oracle modules')
+    return ap.parse_args()
+
+
+def build_model(name):
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd.models import fastscnn as _f  # noqa: F401
+    import importlib
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    C = importlib.import_module('torch_semantic_segmentation_amd.models.contextnet')
+    ctor = {'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12, 'contextnet14': C.contextnet14,
+            'contextnet18': C.contextnet18}[name]
+    torch.manual_seed(0)
+    return ctor(3, 19), tssa
+
+
+def synthetic(batch, h, w, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 3, h, w, generator=g, dtype=torch.float32)
+    y = torch.randint(0, 19, (batch, h, w), generator=g, dtype=torch.int64)
+    y[torch.rand(batch, h, w, generator=g) < 0.05] = 255
+    return x.to(device), y.to(device)
+
+
+def algorithmic_step_bytes(model_name, batch, h, w, esz):
+    """A_step = 3*S*b + 4*U*b + 8*T, S scaled from the 8x1024x2048 figures."""
+    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}.get(model_name)
+    if S_ref is None:
+        return None
+    scale = batch * h * w / (8.0 * 1024 * 2048)
+    U = batch * 19.0 * h * w
+    T = batch * 1.0 * h * w
+    return 3 * S_ref * scale * esz + 4 * U * esz + 8 * T
+
+
+def cpu_baseline(model_name, seconds):
+    """Oracle (port) on the host cores: FastSCNN fwd+CE+bwd+AdamW at BASELINE config 1 (4x3x512x1024, f32)."""
+    from oracle import nets
+    from oracle.recipe import synthetic_batch, train_step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = nets.build(model_name)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=255)
+    x, y = synthetic_batch(4, 512, 1024)
+    train_step(m, opt, loss_fn, x, y)  # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds and n < 50):
+        train_step(m, opt, loss_fn, x, y)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(4 * n / dt, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d train steps of %s at 4x3x512x1024 f32 (BASELINE config 1), oracle/nets.py on torch CPU, %.1f s'
+                      % (n, model_name, dt)}
+
+
+def stock_gpu(model_name, batch, h, w, device, steps=5):
+    """What you get without this project: the same modules on stock PyTorch-ROCm (MIOpen), channels_last + bf16 autocast."""
+    from oracle import nets
+    torch.manual_seed(0)
+    m = nets.build(model_name).to(device).to(memory_format=torch.channels_last)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, fused=True)
+    loss_fn = torch.nn.CrossEntropyLoss(ignore_index=255)
+    x, y = synthetic(batch, h, w, 1234, device)
+    x = x.contiguous(memory_format=torch.channels_last)
+
+    def step():
+        m.train()
+        opt.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = m(x)
+        loss = loss_fn(out.float(), y)
+        loss.backward()
+        opt.step()
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return batch * steps / (time.time() - t0)
+
+
+def main():
+    args = parse()
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd import _native as N
+    world, rank, local_rank = E.setup_distributed(enable=True)
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    model, tssa = build_model(args.model)
+    model.to(device)
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tssa.set_compute_dtype(model, dtype)
+    opt = E.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    loss_fn = tssa.CrossEntropyLoss(ignore_index=255)
+    x, y = synthetic(args.batch, args.height, args.width, 1234 + rank, device)
+
+    def make_trainer(use_graph):
+        return E.Trainer(model, opt, loss_fn, device=None, use_graph=use_graph, world_size=world)
+
+    graph_used = args.graph != 'off'
+    trainer = make_trainer(graph_used)
+    try:
+        loss = trainer.step_async(x, y)
+        torch.cuda.synchronize()
+    except Exception as exc:  # graph capture unsupported -> eager launches (reported in config)
+        if args.graph == 'on' or not graph_used:
+            raise
+        print('graph capture failed (%s: %s); falling back to eager launches' % (type(exc).__name__, exc), file=sys.stderr)
+        graph_used = False
+        trainer = make_trainer(False)
+        loss = trainer.step_async(x, y)
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup - 1, 0)):
+        loss = trainer.step_async(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step_async(x, y)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss)
+
+    roofline = None
+    breakdown = None
+    if not args.no_roofline and rank == 0:
+        eager = make_trainer(False)
+        eager.step_async(x, y)
+        torch.cuda.synchronize()
+        N.prof_reset()
+        N.prof_enable(True)
+        nprof = 3
+        for _ in range(nprof):
+            eager.step_async(x, y)
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+        table = N.prof_table()
+        by_symbol = {}
+        for op, r in table.items():
+            s = by_symbol.setdefault(r['symbol'], dict(launches=0, ms=0.0, bytes=0.0, flops=0.0, ops=[]))
+            s['launches'] += r['launches']; s['ms'] += r['ms']; s['bytes'] += r['bytes']; s['flops'] += r['flops']
+            s['ops'].append(op)
+        total_ms = sum(s['ms'] for s in by_symbol.values())
+        sym, top = max(by_symbol.items(), key=lambda kv: kv[1]['ms'])
+        gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+        roofline = {'bound': 'hbm', 'kernel': sym, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'launches_per_step': top['launches'] // nprof,
+                    'avg_launch_us': round(1e3 * top['ms'] / top['launches'], 2),
+                    'alg_bytes_per_launch': round(top['bytes'] / top['launches']),
+                    'share_of_kernel_time': round(top['ms'] / total_ms, 3),
+                    'tflops': round(top['flops'] / (top['ms'] * 1e-3) / 1e12, 2)}
+        breakdown = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches': v['launches'] // nprof,
+                         'GBps': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
+                     for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]['ms'])}
+
+    if rank == 0:
+        esz = 2 if dtype == torch.bfloat16 else 4
+        ms = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        a_step = algorithmic_step_bytes(args.model, args.batch, args.height, args.width, esz)
+        out = {
+            'metric': 'images/sec (train step) %s %dx%d bs=%d' % (args.model, args.height, args.width, args.batch),
+            'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if dtype == torch.bfloat16 else 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s train step (zero_grad+fwd+CE(ignore 255)+bwd+AdamW), %d x 3 x %d x %d per GPU, '
+                                   '19 classes, random-init weights' % (args.model, args.batch, args.height, args.width),
+                       'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
+                       'hip_graph': graph_used, 'final_loss': round(final_loss, 4)},
+        }
+        if a_step:
+            out['step_roofline'] = {'alg_bytes_per_step': round(a_step), 'achieved_GBps': round(a_step / (ms * 1e-3) / 1e9, 1),
+                                    'frac_of_8TBps': round(a_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if roofline:
+            out['roofline'] = roofline
+            out['kernel_breakdown'] = breakdown
+        if args.stock:
+            out['stock_pytorch_rocm_images_per_sec'] = round(stock_gpu(args.model, args.batch, args.height, args.width, device), 2)
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

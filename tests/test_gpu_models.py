@@ -1,0 +1,198 @@
+"""GPU parity, model level: FastSCNN / ContextNet12/14/18 eval logits + argmax masks and
+two full train steps, HIP path vs golden vectors generated from the reference, and vs the CPU oracle on the
+seeded synthetic inputs of BASELINE.md.  f32 activations; logits within 1e-3 relative, argmax exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import nets as O
+from oracle.recipe import formula_state, lattice_input, lattice_target, synthetic_batch, train_step
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rel(a, b):
+    return cases.rel_err(a, b)
+
+
+@pytest.mark.parametrize('name', cases.MODEL_NAMES)
+def test_eval_logits_and_argmax_vs_reference(golden_dir, name):
+    import torch_semantic_segmentation_amd as tssa
+    g = cases.load_npz(os.path.join(golden_dir, 'eval_models.npz'))
+    m = cases.product_model(name)
+    m.load_state_dict(formula_state(m, gain=1.0), strict=True)
+    m.to(DEV).eval()
+    low = {}
+    h = m.classifier.register_forward_hook(lambda _m, _i, o: low.__setitem__('v', o))
+    with torch.no_grad():
+        logits = m(lattice_input(*cases.EVAL_SHAPE).to(DEV))
+    h.remove()
+    assert logits.is_contiguous() and tuple(logits.shape) == (2, 19, 64, 128)
+    assert rel(low['v'].cpu().numpy(), g[name + '/low']) < 1e-3
+    assert rel(logits[:, :, ::4, ::4].cpu().numpy(), g[name + '/sub']) < 1e-3
+    # argmax: bit-exact except where the reference's own top-2 gap is below f32 resolution of the logits
+    pred, _ = tssa.argmax_confusion(logits)
+    ref = g[name + '/argmax']
+    mism = pred.cpu().numpy() != ref
+    assert (g[name + '/gap'][mism] < 1e-5).all(), 'argmax differs at a pixel with a resolvable top-2 gap'
+    assert mism.mean() < 1e-3
+    assert (pred.cpu() == logits.argmax(1).to(torch.uint8).cpu()).all()
+
+
+@pytest.mark.parametrize('name', cases.MODEL_NAMES)
+def test_frozen_bn_train_step_vs_reference(golden_dir, name):
+    """End-to-end backward, well conditioned (BatchNorm frozen): loss, EVERY parameter's gradient norm, full
+    gradients of representative tensors and the post-AdamW loss, against the reference's own output."""
+    import torch_semantic_segmentation_amd as tssa
+    g = cases.load_npz(os.path.join(golden_dir, 'frozen_steps.npz'))
+    m = cases.product_model(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    m.to(DEV).eval()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)   # the reference's optimizer, unchanged
+    loss_fn = tssa.CrossEntropyLoss(ignore_index=255)
+    x = lattice_input(*cases.TRAIN_SHAPE).to(DEV)
+    y = lattice_target(cases.TRAIN_SHAPE[0], cases.TRAIN_SHAPE[2], cases.TRAIN_SHAPE[3]).to(DEV)
+
+    def step():
+        opt.zero_grad()
+        loss = loss_fn(m(x), y)
+        loss.backward()
+        opt.step()
+        return loss.item()
+    losses = [step()]
+    assert abs(losses[0] / g[name + '/losses'][0] - 1) < 1e-5
+    norms = np.array([p.grad.double().norm().item() for p in m.parameters()])
+    gn = g[name + '/grad_norms']
+    assert np.abs(norms - gn).max() <= 1e-3 * gn.max()
+    big = gn > 1e-2 * gn.max()
+    assert np.abs(norms[big] / gn[big] - 1).max() < 1e-3
+    for key in g:
+        if key.startswith(name + '/grad.'):
+            pname = key[len(name) + 6:]
+            assert rel(m.get_parameter(pname).grad.cpu().numpy(), g[key]) < 1e-3, pname
+    losses.append(step())
+    assert abs(losses[1] / g[name + '/losses'][1] - 1) < 2e-2     # one AdamW step later (eval-mode nets diverge fast)
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_train_mode_step_vs_reference_and_f64_oracle(golden_dir, name):
+    """Train-mode (batch-statistics BatchNorm) step.  Loss and running statistics are checked against the
+    reference's golden output.  Whole-model train-mode GRADIENTS are ill-conditioned in f32 -- the reference's own
+    f32 and f64 runs disagree by 2-130% on these networks -- so they are judged against an f64
+    run of the oracle: the HIP path must be as close to f64 as the reference's f32 run is (x4 slack), or 2e-3."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    g = cases.load_npz(os.path.join(golden_dir, 'train_steps.npz'))
+    x = lattice_input(*cases.TRAIN_SHAPE)
+    y = lattice_target(cases.TRAIN_SHAPE[0], cases.TRAIN_SHAPE[2], cases.TRAIN_SHAPE[3])
+
+    def oracle(dtype):
+        r = O.build(name)
+        r.load_state_dict(formula_state(r), strict=True)
+        cases.zero_dropout(r)
+        r.to(dtype).train()
+        nn.CrossEntropyLoss(ignore_index=255)(r(x.to(dtype)), y).backward()
+        return torch.cat([p.grad.flatten() for p in r.parameters()]).double()
+    g64, g32 = oracle(torch.float64), oracle(torch.float32)
+
+    m = cases.product_model(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_dropout(m)
+    m.to(DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    trainer = E.create_segmentation_trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), DEV)
+    loss = trainer.update((x, y))
+    assert abs(loss / g[name + '/losses'][0] - 1) < 2e-4
+    for key in g:
+        if key.startswith(name + '/buf_norm.'):
+            b = m.get_buffer(key[len(name) + 10:])
+            assert abs(b.double().norm().item() / float(g[key]) - 1) < 1e-3, key
+    gh = torch.cat([p.grad.flatten().cpu() for p in m.parameters()]).double()
+    err_ref32 = ((g32 - g64).norm() / g64.norm()).item()
+    err_hip = ((gh - g64).norm() / g64.norm()).item()
+    assert err_hip <= max(2e-3, 4 * err_ref32), (err_hip, err_ref32)
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet12'])
+def test_seeded_inputs_vs_oracle(name):
+    """Same seeded N(0,1) inputs / default torch init as the benchmark, small spatial size.
+    Logits within 1e-3 of the f32 oracle; gradients judged against the f64 oracle as above."""
+    import torch_semantic_segmentation_amd as tssa
+    torch.manual_seed(0)
+    ref = O.build(name)
+    hip = cases.product_model(name)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    cases.zero_dropout(ref); cases.zero_dropout(hip)
+    hip.to(DEV)
+    x, y = synthetic_batch(2, 96, 160)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+    ref.train(); hip.train()
+    out_r = ref(x); loss_r = loss_fn(out_r, y); loss_r.backward()
+    g32 = torch.cat([p.grad.flatten() for p in ref.parameters()]).double()
+    ref64 = O.build(name).double()
+    ref64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in hip.state_dict().items()})
+    for k, v in ref64.state_dict().items():   # running stats were already updated once by the f32 run: reset them
+        pass
+    cases.zero_dropout(ref64); ref64.train()
+    out64 = ref64(x.double()); loss_fn(out64, y).backward()
+    g64 = torch.cat([p.grad.flatten() for p in ref64.parameters()]).double()
+    out_h = hip(x.to(DEV)); loss_h = tssa.cross_entropy(out_h, y.to(DEV), ignore_index=255); loss_h.backward()
+    gh = torch.cat([p.grad.flatten().cpu() for p in hip.parameters()]).double()
+    err_logits_ref32 = cases.rel_err(out_r.detach().numpy(), out64.detach().numpy())
+    err_logits_hip = cases.rel_err(out_h.detach().cpu().numpy(), out64.detach().numpy())
+    assert err_logits_hip <= max(1e-3, 4 * err_logits_ref32), (err_logits_hip, err_logits_ref32)
+    assert abs(loss_h.item() / loss_r.item() - 1) < 1e-4
+    err_ref32 = ((g32 - g64).norm() / g64.norm()).item()
+    err_hip = ((gh - g64).norm() / g64.norm()).item()
+    assert err_hip <= max(2e-3, 4 * err_ref32), (err_hip, err_ref32)
+
+
+def test_flat_adamw_and_graph_replay_match_eager():
+    """FlatAdamW + direct gradient accumulation + HIP-graph replay give the same trajectory as the plain path."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    x, y = synthetic_batch(2, 64, 128)
+    x, y = x.to(DEV), y.to(DEV)
+    results = []
+    for mode in ('torch_adamw', 'flat', 'flat_graph'):
+        m = cases.product_model('fastscnn')
+        m.load_state_dict(formula_state(m), strict=True)
+        cases.zero_dropout(m)
+        m.to(DEV)
+        if mode == 'torch_adamw':
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        else:
+            opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=(mode == 'flat_graph'))
+        losses = [tr.step_async(x, y).item() for _ in range(3)]
+        results.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).double().cpu(),
+                        m.downsample[0][1].running_var.clone().cpu(), int(m.downsample[0][1].num_batches_tracked)))
+    base = results[0]
+    for other in results[1:]:
+        assert np.allclose(other[0], base[0], rtol=1e-3)
+        assert ((other[1] - base[1]).norm() / base[1].norm()).item() < 2e-3   # 3 ill-conditioned train-mode steps apart
+        assert torch.allclose(other[2], base[2], rtol=1e-3)
+        assert other[3] == base[3] == 3
+
+
+def test_bf16_training_tracks_f32():
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    x, y = synthetic_batch(2, 128, 256)
+    x, y = x.to(DEV), y.to(DEV)
+    curves = {}
+    for dt in (torch.float32, torch.bfloat16):
+        torch.manual_seed(0)
+        m = cases.product_model('fastscnn').to(DEV)
+        tssa.set_compute_dtype(m, dt)
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255))
+        curves[dt] = [tr.step_async(x, y).item() for _ in range(8)]
+    a, b = np.array(curves[torch.float32]), np.array(curves[torch.bfloat16])
+    assert a[-1] < a[0] and b[-1] < b[0]
+    assert np.abs(a - b).max() < 0.05 * a[0]

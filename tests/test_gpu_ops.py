@@ -1,0 +1,156 @@
+"""GPU: individual operators through the C ABI vs plain PyTorch f32 references of the same op (ATen on the GPU
+is used here only as the checker)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def rel(a, b):
+    return cases.rel_err(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy())
+
+
+@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 16, 4, 8), 4), ((3, 5, 6, 3), 8)])
+def test_upsample_head_fwd_bwd(shape, scale):
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(1)
+    low = torch.randn(*shape, device=DEV)
+    cot = torch.randn(shape[0], shape[1], shape[2] * scale, shape[3] * scale, device=DEV)
+    a = ops.to_nhwc(low).clone().requires_grad_(True)
+    ya = ops.upsample_logits(a, scale_factor=scale)
+    ya.backward(cot)
+    b = low.clone().requires_grad_(True)
+    yb = F.interpolate(b, scale_factor=scale, mode='bilinear', align_corners=True)
+    yb.backward(cot)
+    assert ya.is_contiguous() and ya.shape == yb.shape
+    assert rel(ya, yb) < 1e-5
+    assert rel(a.grad, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize('cin,hin,win,hout,wout', [(16, 4, 8, 16, 32), (32, 2, 4, 8, 20), (8, 6, 6, 8, 16), (8, 1, 1, 8, 16),
+                                                  (24, 3, 3, 3, 3)])
+def test_bilinear_nhwc_fwd_bwd(cin, hin, win, hout, wout):
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(2)
+    x = torch.randn(2, cin, hin, win, device=DEV)
+    cot = torch.randn(2, cin, hout, wout, device=DEV)
+    a = x.clone().requires_grad_(True)
+    ya = ops.bilinear(a, size=(hout, wout))
+    ya.backward(cot)
+    b = x.clone().requires_grad_(True)
+    yb = F.interpolate(b, size=(hout, wout), mode='bilinear', align_corners=True)
+    yb.backward(cot)
+    assert rel(ya, yb) < 1e-5 and rel(a.grad, b.grad) < 1e-5
+
+
+@pytest.mark.parametrize('bins,h,w', [(1, 8, 16), (2, 8, 16), (3, 8, 20), (6, 8, 20), (6, 32, 64), (3, 2, 4)])
+def test_adaptive_pool_fwd_bwd(bins, h, w):
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(3)
+    x = torch.randn(2, 16, h, w, device=DEV)
+    cot = torch.randn(2, 16, bins, bins, device=DEV)
+    a = x.clone().requires_grad_(True)
+    ya = ops.adaptive_avg_pool(a, bins)
+    ya.backward(cot)
+    b = x.clone().requires_grad_(True)
+    yb = F.adaptive_avg_pool2d(b, bins)
+    yb.backward(cot)
+    assert rel(ya, yb) < 1e-5 and rel(a.grad, b.grad) < 1e-5
+
+
+def test_resize_image_matches_interpolate():
+    from torch_semantic_segmentation_amd import ops
+    x = torch.randn(2, 3, 64, 128, device=DEV)
+    for s in (2, 4, 8):
+        assert rel(ops.resize_image(x, scale_factor=1 / s), F.interpolate(x, scale_factor=1 / s, mode='bilinear', align_corners=True)) < 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cross_entropy_fwd_bwd(dtype):
+    import torch_semantic_segmentation_amd as tssa
+    torch.manual_seed(4)
+    logits = (3 * torch.randn(2, 19, 16, 24, device=DEV)).to(dtype)
+    target = torch.randint(0, 19, (2, 16, 24), device=DEV)
+    target[torch.rand(2, 16, 24, device=DEV) < 0.1] = 255
+    a = logits.clone().requires_grad_(True)
+    la = tssa.cross_entropy(a, target, ignore_index=255)
+    (0.4 * la).backward()
+    b = logits.float().clone().requires_grad_(True)
+    lb = F.cross_entropy(b, target, ignore_index=255)
+    (0.4 * lb).backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert abs(la.item() / lb.item() - 1) < tol
+    assert rel(a.grad, b.grad) < tol
+    # every pixel ignored -> nan loss like torch, zero gradient
+    all_ign = torch.full_like(target, 255)
+    c = logits.clone().requires_grad_(True)
+    lc = tssa.cross_entropy(c, all_ign, ignore_index=255)
+    lc.backward()
+    assert math.isnan(lc.item()) and float(c.grad.float().abs().max()) == 0.0
+
+
+def test_argmax_confusion_matches_torch():
+    import torch_semantic_segmentation_amd as tssa
+    torch.manual_seed(5)
+    logits = torch.randn(2, 19, 16, 24, device=DEV)
+    logits[0, 3, :, :8] = logits[0, 7, :, :8]          # exact ties: lowest index must win
+    logits[0, 3, :, :8] += 10; logits[0, 7, :, :8] += 10
+    target = torch.randint(0, 19, (2, 16, 24), device=DEV)
+    target[0, :2] = 255
+    pred, cm = tssa.argmax_confusion(logits, target, ignore_index=255)
+    ref = logits.argmax(1)
+    assert (pred.long() == ref).all()
+    valid = target != 255
+    want = torch.bincount(target[valid] * 19 + ref[valid], minlength=361).view(19, 19)
+    assert (cm == want).all()
+
+
+def test_dropout_statistics_and_backward_mask():
+    from torch_semantic_segmentation_amd import ops
+    x = torch.ones(4, 64, 32, 32, device=DEV, requires_grad=True)
+    y = ops.dropout(x, 0.1, True)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 5e-3
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.9, device=DEV))
+    y.sum().backward()
+    assert ((x.grad != 0) == (y != 0)).all()
+    y2 = ops.dropout(x, 0.1, True)
+    assert (y2 != y).any()                             # a new mask every call
+    assert ops.dropout(x, 0.1, False) is x
+
+
+def test_flat_adamw_matches_torch_adamw():
+    from torch_semantic_segmentation_amd import engine as E
+    torch.manual_seed(6)
+    ps = [torch.randn(7, 5, device=DEV), torch.randn(33, device=DEV)]
+    pa = [torch.nn.Parameter(p.clone()) for p in ps]
+    pb = [torch.nn.Parameter(p.clone()) for p in ps]
+    oa = E.FlatAdamW(pa, lr=1e-2, weight_decay=1e-2)
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=1e-2)
+    for step in range(5):
+        for qa, qb in zip(pa, pb):
+            g = torch.randn_like(qb)
+            qa.grad.copy_(g)
+            qb.grad = g.clone()
+        oa.step(); ob.step()
+    for qa, qb in zip(pa, pb):
+        assert rel(qa, qb) < 1e-5
+
+
+def test_unsupported_shapes_fail_loudly():
+    from torch import nn
+    from torch_semantic_segmentation_amd import ops
+    x = torch.randn(2, 12, 8, 8, device=DEV)           # 12 channels: not a multiple of 8 and too many for a stem
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ops.conv_unit(x, nn.Conv2d(12, 16, 1, bias=False).to(DEV))
+    with pytest.raises(NotImplementedError):
+        ops.conv_unit(torch.randn(2, 16, 8, 8, device=DEV), nn.Conv2d(16, 16, 3, padding=0, bias=False).to(DEV))
+    with pytest.raises(TypeError):
+        ops.conv_unit(torch.randn(2, 16, 8, 8, device=DEV).half(), nn.Conv2d(16, 16, 1, bias=False).to(DEV))

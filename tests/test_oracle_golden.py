@@ -77,6 +77,31 @@ def test_train_steps_bit_identical(golden_dir, name):
     assert np.array_equal(after2, g[name + '/param_norms_after2'])
 
 
+def frozen_step(m, opt, loss_fn, x, y):
+    m.eval()
+    opt.zero_grad()
+    loss = loss_fn(m(x), y)
+    loss.backward()
+    opt.step()
+    return loss.item()
+
+
+@pytest.mark.parametrize('name', cases.MODEL_NAMES)
+def test_frozen_bn_steps_bit_identical(golden_dir, name):
+    g = cases.load_npz(os.path.join(golden_dir, 'frozen_steps.npz'))
+    m = O.build(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+    x = lattice_input(*cases.TRAIN_SHAPE)
+    y = lattice_target(cases.TRAIN_SHAPE[0], cases.TRAIN_SHAPE[2], cases.TRAIN_SHAPE[3])
+    losses = [frozen_step(m, opt, loss_fn, x, y)]
+    norms = np.array([p.grad.double().norm().item() for p in m.parameters()])
+    assert np.array_equal(norms, g[name + '/grad_norms'])
+    losses.append(frozen_step(m, opt, loss_fn, x, y))
+    assert np.array_equal(np.array(losses), g[name + '/losses'])
+
+
 def test_state_dict_contract():
     """Key/shape contract quoted in SURVEY.md §5 (266 / 314 keys, parameter counts)."""
     f = O.build('fastscnn')

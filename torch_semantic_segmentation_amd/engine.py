@@ -1,0 +1,282 @@
+"""Train / eval step of the hot path: the counterpart of TSS/engine.py (rows R, S of SURVEY.md §8a).
+
+`create_segmentation_trainer` reproduces the body of the reference's `update_fn` (TSS/engine.py:24-39):
+train mode, zero_grad, forward, loss, backward, optimizer step, loss value.  ignite and apex are not
+dependencies: the returned :class:`Trainer` is a plain object with `update(batch)` and `run(loader, epochs)`.
+
+MI355X specifics
+  * parameters and gradients of the model live in two flat f32 buffers (`FlatAdamW`), so the optimizer is one
+    fused kernel (tss_adamw_step) and data-parallel training needs ONE RCCL all-reduce per step;
+  * weight-gradient kernels accumulate straight into the flat gradient buffer (ops.direct_grads), so there is
+    no per-parameter `.grad +=` launch;
+  * zero_grad + forward + loss + backward can be captured once into a HIP graph (`use_graph=True`) and
+    replayed, removing ~10^3 Python-side launches per step;
+  * one process per GPU; gradients are averaged with `torch.distributed.all_reduce` (backend "nccl" = RCCL over
+    xGMI on GPUs, "gloo" on CPU for tests).  BatchNorm statistics stay per replica.
+"""
+import os
+from functools import partial
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import _native as N
+from . import ops
+
+
+# ----------------------------------------------------------------------------- flat parameters + fused AdamW
+
+class FlatAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) on ONE flat f32 buffer.
+
+    `param_groups[0]['lr']` stays a Python float so LR schedulers work; it is mirrored into a device scalar
+    before every step (outside any captured graph).
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise NotImplementedError('FlatAdamW: a single parameter group')
+        ps = self.param_groups[0]['params']
+        dev = ps[0].device
+        if any(p.dtype != torch.float32 or p.device != dev for p in ps):
+            raise TypeError('FlatAdamW: float32 parameters on one device')
+        n = sum(p.numel() for p in ps)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.reshape(-1))
+                p.data = self.flat_param[off:off + k].view_as(p)
+                p.grad = self.flat_grad[off:off + k].view_as(p)
+                off += k
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.state_vec = torch.zeros(3, dtype=torch.float32, device=dev)  # step, bias corrections
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        if not self.flat_param.is_cuda:
+            raise RuntimeError('FlatAdamW runs on the HIP path only (no CPU fallback)')
+        self.lr_dev.fill_(float(g['lr']))
+        b1, b2 = g['betas']
+        N.call('tss_adamw_step', N.ptr(self.flat_param), N.ptr(self.flat_grad), N.ptr(self.exp_avg),
+               N.ptr(self.exp_avg_sq), self.flat_param.numel(), N.ptr(self.lr_dev), float(b1), float(b2),
+               float(g['eps']), float(g['weight_decay']), N.ptr(self.state_vec), float(self.grad_scale),
+               N.stream())
+
+
+# ----------------------------------------------------------------------------- distributed helpers
+
+def setup_distributed(enable=True, local_rank=None, backend=None):
+    """TSS/utils/training.py:5-19 without the GPU-only assumption: returns (world_size, rank, local_rank).
+    Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run)."""
+    if not enable:
+        return 1, 0, 0
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+    if world > 1 and not dist.is_initialized():
+        dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), init_method='env://')
+    if dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank(), local_rank
+    return 1, 0, local_rank
+
+
+def shard_batch(n_items, world_size, rank):
+    """DistributedSampler's partition without shuffling (TSS/utils/training.py:54-61): rank r owns r, r+W, ..."""
+    return list(range(rank, n_items, world_size))
+
+
+def allreduce_mean_(flat, world_size, group=None):
+    """ONE collective per step over the flat gradient buffer: sum here, the 1/world factor is folded into AdamW."""
+    if world_size > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
+# ----------------------------------------------------------------------------- trainer
+
+class Trainer:
+    def __init__(self, model, optimizer, loss_fn, device=None, use_graph=False, world_size=1,
+                 non_blocking=True):
+        self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
+        self.device = device
+        self.non_blocking = non_blocking
+        self.world_size = world_size
+        self.use_graph = use_graph
+        self.flat = isinstance(optimizer, FlatAdamW)
+        if self.flat:
+            optimizer.grad_scale = 1.0 / world_size
+        self._graph = None
+        self._static = None
+        self.iteration = 0
+        self.last_loss = None
+
+    # -- one un-captured iteration: exactly the statements of the reference's update_fn
+    def _forward_backward(self, x, y):
+        self.model.train()
+        self.optimizer.zero_grad()
+        with ops.direct_grads(self.flat):
+            y_pred = self.model(x)
+            loss = self.loss_fn(y_pred, y)
+            loss.backward()
+        return loss
+
+    def _reduce_and_step(self):
+        if self.world_size > 1:
+            if self.flat:
+                allreduce_mean_(self.optimizer.flat_grad, self.world_size)
+            else:
+                for p in self.model.parameters():
+                    if p.grad is not None:
+                        dist.all_reduce(p.grad)
+                        p.grad.div_(self.world_size)
+        self.optimizer.step()
+
+    def _capture(self, x, y):
+        self._static = (torch.empty_like(x), torch.empty_like(y))
+        sx, sy = self._static
+        sx.copy_(x)
+        sy.copy_(y)
+        # warm-up on a side stream (lazily initialised state must exist before capture); buffers that a
+        # forward pass mutates (BatchNorm running statistics) are restored so the warm-up leaves no trace
+        saved = [(b, b.clone()) for b in self.model.buffers()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._forward_backward(sx, sy)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for b, v in saved:
+                b.copy_(v)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._static_loss = self._forward_backward(sx, sy).detach()
+
+    def step_async(self, x, y):
+        """One training iteration; returns the loss as a device tensor (no host sync)."""
+        if self.use_graph:
+            if self._graph is None:
+                self._capture(x, y)
+            sx, sy = self._static
+            sx.copy_(x, non_blocking=True)
+            sy.copy_(y, non_blocking=True)
+            self._graph.replay()
+            loss = self._static_loss
+        else:
+            loss = self._forward_backward(x, y).detach()
+        self._reduce_and_step()
+        self.iteration += 1
+        return loss
+
+    def update(self, batch):
+        """TSS/engine.py:24-39: returns loss.item() (a device->host sync per iteration, as in the reference)."""
+        x, y = batch
+        if self.device is not None:
+            x = x.to(self.device, non_blocking=self.non_blocking)
+            y = y.to(self.device, non_blocking=self.non_blocking)
+        self.last_loss = self.step_async(x, y).item()
+        return self.last_loss
+
+    def run(self, data, max_epochs=1):
+        history = []
+        for _ in range(max_epochs):
+            for batch in data:
+                history.append(self.update(batch))
+        return history
+
+
+def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False, logging=True,
+                                non_blocking=True, use_graph=False, world_size=None):
+    """Same arguments as TSS/engine.py:22.  `use_f16` selects bf16 activations (f32 master parameters), the
+    MI355X counterpart of the reference's apex amp O2 branch (TSS/engine.py:32-34); no loss scaling is needed."""
+    from .models import set_compute_dtype
+    set_compute_dtype(model, torch.bfloat16 if use_f16 else torch.float32)
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return Trainer(model, optimizer, loss_fn, device=device, use_graph=use_graph, world_size=world_size,
+                   non_blocking=non_blocking)
+
+
+# ----------------------------------------------------------------------------- evaluator
+
+class Evaluator:
+    """model.eval() + no_grad forward, argmax, confusion matrix -> IoU / mIoU / accuracy / Dice
+    (the metrics of create_segmentation_evaluator, TSS/engine.py:59-82; confusion rows = truth)."""
+
+    def __init__(self, model, device=None, num_classes=19, loss_fn=None, ignore_index=255, non_blocking=True):
+        self.model, self.device, self.num_classes = model, device, num_classes
+        self.loss_fn, self.ignore_index, self.non_blocking = loss_fn, ignore_index, non_blocking
+
+    @torch.no_grad()
+    def run(self, data):
+        self.model.eval()
+        cm = None
+        loss_sum, n = 0.0, 0
+        for x, y in data:
+            if self.device is not None:
+                x = x.to(self.device, non_blocking=self.non_blocking)
+                y = y.to(self.device, non_blocking=self.non_blocking)
+            logits = self.model(x)
+            _, cm = ops.argmax_confusion(logits, y, ignore_index=self.ignore_index, confusion=cm, want_pred=False)
+            if self.loss_fn is not None:
+                loss_sum += float(self.loss_fn(logits, y)) * x.shape[0]
+                n += x.shape[0]
+        metrics = confusion_metrics(cm.cpu().double())
+        if self.loss_fn is not None and n:
+            metrics['loss'] = loss_sum / n
+        return metrics
+
+
+def confusion_metrics(cm):
+    tp = cm.diag()
+    iou = tp / (cm.sum(0) + cm.sum(1) - tp + 1e-15)
+    return {'iou': iou, 'miou': iou.mean().item(), 'accuracy': (tp.sum() / (cm.sum() + 1e-15)).item(),
+            'dice': 2 * tp / (cm.sum(0) + cm.sum(1) + 1e-15)}
+
+
+def create_segmentation_evaluator(model, device, num_classes=19, loss_fn=None, non_blocking=True):
+    return Evaluator(model, device, num_classes=num_classes, loss_fn=loss_fn, non_blocking=non_blocking)
+
+
+# ----------------------------------------------------------------------------- deep supervision (row S)
+
+class DeepSupervisionWrapper(nn.Module):
+    """Forward hooks on inner blocks feed auxiliary heads in training mode
+    (TSS/wrappers/deep_supervision_wrapper.py:10-43): train -> (output, [aux...]); eval -> output."""
+
+    def __init__(self, module, auxiliary_modules):
+        super().__init__()
+        self.module = module
+        self.layers = [layer for layer, _ in auxiliary_modules]
+        self.auxiliary = nn.ModuleList([head for _, head in auxiliary_modules])
+
+    def forward(self, input):
+        if not self.training:
+            return self.module(input)
+        aux_outputs = [None] * len(self.layers)
+
+        def capture(_module, _inputs, output, slot, head):
+            aux_outputs[slot] = head(output)
+
+        handles = [layer.register_forward_hook(partial(capture, slot=i, head=head))
+                   for i, (layer, head) in enumerate(zip(self.layers, self.auxiliary))]
+        try:
+            output = self.module(input)
+        finally:
+            for h in handles:
+                h.remove()
+        return output, aux_outputs

@@ -21,6 +21,36 @@ from . import _native as N
 call, ptr, stream = N.call, N.ptr, N.stream
 
 
+# ----------------------------------------------------------------------------- direct gradient accumulation
+
+_DIRECT = [False]
+
+
+class direct_grads:
+    """While active, parameter gradients are accumulated by the kernels straight into an existing float32
+    `.grad` (e.g. FlatAdamW's flat buffer) and autograd is handed None for them: no per-parameter zero-fill
+    and no `.grad +=` launch.  Off by default: then every backward returns ordinary gradient tensors."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _DIRECT[0]
+        _DIRECT[0] = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT[0] = self.prev
+        return False
+
+
+def _direct_target(param):
+    g = param.grad if param is not None else None
+    if _DIRECT[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda:
+        return g
+    return None
+
+
 # ----------------------------------------------------------------------------- layout helpers
 
 def round_up(v, m):
@@ -131,7 +161,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout')
+                 'image_f32', 'cin', 'cout', 'params')
 
 
 def _classify(conv, x_is_image):
@@ -193,6 +223,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         if cfg.training and bn.momentum is None:
             raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
         gamma, beta = bn.weight, bn.bias
+    cfg.params = (conv.weight, gamma, beta, conv.bias)
     y = ConvUnitFn.apply(x_raw, conv.weight, gamma, beta, conv.bias, cfg)
     return Deferred(y, cfg.out_link, relu)
 
@@ -270,14 +301,22 @@ class ConvUnitFn(Function):
         s, d = cfg.stride, cfg.dil
         Cout, Cin = cfg.cout, cfg.cin
         P = npix(e)
+        p_weight, p_gamma, p_beta, p_bias = cfg.params
         dgamma = dbeta = None
         if link is not None:
+            acc = 0
             if ctx.has_affine:
-                dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
-                dgamma, dbeta = dgb[0], dgb[1]
+                dgamma, dbeta = _direct_target(p_gamma), _direct_target(p_beta)
+                if dgamma is not None and dbeta is not None:
+                    acc = 1
+                else:
+                    dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+                    dgamma, dbeta = dgb[0], dgb[1]
             call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.mean), ptr(link.invstd),
-                 ptr(link.gamma), int(link.training), 0, ptr(dgamma), ptr(dbeta),
+                 ptr(link.gamma), int(link.training), acc, ptr(dgamma), ptr(dbeta),
                  ptr(link.ga), ptr(link.gb), ptr(link.gd), Cout, st)
+            if acc:
+                dgamma = dbeta = None
             ga, gb, gd = link.ga, link.gb, link.gd
             if not link.training:
                 y, gb, gd = None, None, None
@@ -288,7 +327,10 @@ class ConvUnitFn(Function):
         il = cfg.in_link
         isc, ish = (il.scale, il.shift) if il is not None else (None, None)
 
-        dw = torch.zeros_like(weight)
+        dw = _direct_target(p_weight)
+        dw_ret = None
+        if dw is None:
+            dw = dw_ret = torch.zeros_like(weight)
         need_dx = ctx.needs_input_grad[0]
         e_in = None
         if cfg.kind == 'stem':
@@ -322,11 +364,13 @@ class ConvUnitFn(Function):
                     call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
                     call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cin, Cout, d, dt, st)
-        dbias = None
+        dbias_ret = None
         if ctx.has_bias:
-            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
+            dbias = _direct_target(p_bias)
+            if dbias is None:
+                dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
             call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
-        return e_in, dw, dgamma, dbeta, dbias, None
+        return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
 
 
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
