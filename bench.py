@@ -77,11 +77,22 @@ def algorithmic_step_bytes(model_name, batch, h, w, esz):
     return 3 * S_ref * scale * esz + 4 * U * esz + 8 * T
 
 
+def host_cores():
+    """Threads the CPU baseline uses: the cores this process may run on (cgroup/affinity aware), at most 16 --
+    a gpurun box exposes 256 logical CPUs but grants a 16-core share per GPU, and torch oversubscribed on 256
+    threads is ~100x slower than on 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(model_name, seconds):
     """Oracle (port) on the host cores: FastSCNN fwd+CE+bwd+AdamW at BASELINE config 1 (4x3x512x1024, f32)."""
     from oracle import nets
     from oracle.recipe import synthetic_batch, train_step
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = nets.build(model_name)
@@ -217,6 +228,11 @@ def main():
         breakdown = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches': v['launches'] // nprof,
                          'GBps': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
                      for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]['ms'])}
+        if os.environ.get('TSS_BENCH_OPS'):
+            for op, r in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
+                print('%-24s %-28s launches/step %3d  ms/step %7.3f  GB/s %7.1f  TFLOP/s %6.2f' % (
+                    op, r['symbol'], r['launches'] // nprof, r['ms'] / nprof, r['bytes'] / max(r['ms'], 1e-9) / 1e6,
+                    r['flops'] / max(r['ms'], 1e-9) / 1e9), file=sys.stderr)
 
     if rank == 0:
         esz = 2 if dtype == torch.bfloat16 else 4

@@ -13,9 +13,12 @@
  *   - dtype: TSS_F32 (parity path, exact-f32 MFMA) or TSS_BF16 (performance path, f32 accumulate).
  *     Parameters, statistics and gradients of parameters are always f32 (statistics: f64 sums).
  *   - deferred BatchNorm: a conv output is stored RAW; the BatchNorm(+ReLU) that follows it is applied by
- *     the CONSUMER on load through per-channel (in_scale, in_shift, in_relu).  In backward, the tensor `e`
- *     is d(loss)/d(BN output) (already ReLU-masked) and the BN backward g = ga*e + gb*y_raw + gd is applied
- *     on load from per-channel coefficients produced by tss_bn_bwd_finalize.
+ *     the CONSUMER on load: a = relu?((x - in_mean) * in_scale + in_bias) with in_scale = gamma/sqrt(var+eps),
+ *     in_bias = beta (in_scale NULL: identity; in_mean / in_bias NULL: 0).  In backward, the tensor `e` is
+ *     d(loss)/d(BN output) (already ReLU-masked) and the BN backward g = ga*(e - gce) + gb*(y_raw - gmu) is
+ *     applied on load from per-channel coefficients produced by tss_bn_bwd_finalize (gmu = batch mean;
+ *     yraw NULL: g = ga*e, frozen statistics; ga NULL too: g = e).  Both forms subtract the mean BEFORE
+ *     scaling, as torch does, so channels with |mean| >> std lose no precision.
  *   - every function returns TSS_OK or a negative TSS_ERR_* code; launches are asynchronous on `stream`,
  *     there is no internal synchronisation and no global mutable state besides the optional profiler.
  */
@@ -68,20 +71,20 @@ const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launc
  *           Conv2dBlock TSS/models/fastscnn.py:164-173, DSConv2dBlock :194, ConvBlock TSS/models/contextnet.py:168-177
  *           and the biased classifier conv TSS/models/fastscnn.py:97, TSS/models/contextnet.py:86.
  * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional, [2N] f64, caller-zeroed) += sum(y), sum(y^2). */
-int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream);
-/* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*e + gb*yraw + gd  (gb,gd,yraw NULL: g = ga*e or e);
- * bstats (optional, [2K] f64) += sum(e_in), sum(e_in * xraw).  xraw/in_* NULL: plain dX, no mask. */
+/* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
+ * bstats (optional, [2K] f64) += sum(e_in), sum(e_in * (xraw - in_mean)).  xraw/in_* NULL: plain dX, no mask. */
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                        const float* ga, const float* gb, const float* gd, const float* w,
-                        const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                        const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats,
                         long P, int K, int N, int dtype, void* stream);
 /* dw[n][k] += sum_p g[p][n] * act(x[p][k])   (f32 atomics onto the caller's buffer) */
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                          const float* ga, const float* gb, const float* gd,
-                          const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                          const float* ga, const float* gb, const float* gce, const float* gmu,
+                          const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                           float* dw, long P, int K, int N, int dtype, void* stream);
 
 /* ---- dense 3x3 convolution, padding = dilation ------------------------------------------------------
@@ -89,17 +92,17 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
  * fwd takes the weight re-laid out as [9][N][Cin], bwd_data as [9][Cin][N] (tss_permute_w3x3); bwd_weight
  * accumulates straight into the torch layout [N][Cin][3][3]. */
 int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, void* stream);
-int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w_tnc, void* y, long ldy, double* stats,
                     int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream);
 int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                         const float* ga, const float* gb, const float* gd, const float* w_tcn,
-                         const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats,
                          int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream);  /* stride 1 */
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd,
-                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int Hin, int Win, int Cin, int N, int stride, int dil,
                            int dtype, void* stream);
 
@@ -108,47 +111,49 @@ int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
 int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
                     int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream);
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* x_nchw, int x_is_f32, float* dw,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream);
 
 /* ---- depthwise 3x3 convolution, padding = dilation, weight [C][3][3] --------------------------------
  * replaces: nn.Conv2d(groups=in_channels) of DWConv2dBlock TSS/models/fastscnn.py:176-185, DSConv2dBlock :191-192,
  *           DWConvBlock TSS/models/contextnet.py:150-165. */
-int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                       const float* w, void* y, long ldy, double* stats,
                       int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
 int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd, const float* w,
-                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            void* e_in, long ldei, double* bstats,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                             const float* ga, const float* gb, const float* gd,
-                             const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                             const float* ga, const float* gb, const float* gce, const float* gmu,
+                             const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                              float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
 
 /* ---- BatchNorm2d bookkeeping (eps, momentum, running stats exactly as torch.nn.BatchNorm2d) ----------
  * replaces: nn.BatchNorm2d in every block above (training: batch statistics + running update; eval: running stats). */
-int tss_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+int tss_bn_finalize(const double* sums, double count, const float* gamma, float eps,
                     float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                    float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream);
-int tss_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                       float eps, float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream);
-int tss_bn_bwd_finalize(const double* bstats, double count, const float* mean, const float* invstd,
+                    float* mean_out, float* invstd_out, float* scale, int C, void* stream);
+int tss_bn_eval_affine(const float* gamma, const float* running_mean, const float* running_var,
+                       float eps, float* mean_out, float* invstd_out, float* scale, int C, void* stream);
+/* bstats = [sum(e), sum(e*(y-mean))]; writes d(gamma), d(beta) (+= when accumulate) and ga, gb, gce */
+int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,
-                        float* ga, float* gb, float* gd, int C, void* stream);
+                        float* ga, float* gb, float* gce, int C, void* stream);
 
 /* ---- join: out = relu?(affA(a) + affB(b)) ------------------------------------------------------------
  * replaces: the trailing BatchNorm2d(+ReLU) of a block, `x + input` / F.relu of BottleneckBlock
  *           TSS/models/fastscnn.py:158-161, TSS/models/contextnet.py:145-147 and F.relu(lowres + highres)
  *           TSS/models/fastscnn.py:89, TSS/models/contextnet.py:126. */
-int tss_join_fwd(const void* a, long lda, const float* sa, const float* ba,
-                 const void* b, long ldb, const float* sb, const float* bb,
+int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, const float* ba,
+                 const void* b, long ldb, const float* mb, const float* sb, const float* bb,
                  void* out, long ldo, int relu, long P, int C, int dtype, void* stream);
-/* e = dout * relu'(out) (written if e != NULL); stats_x (optional, [2C] f64) += sum(e), sum(e * x_raw) */
+/* e = dout * relu'(out) (written if e != NULL); stats_x (optional, [2C] f64) += sum(e), sum(e * (x_raw - mean_x)) */
 int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
-                 const void* a_raw, long lda, double* stats_a, const void* b_raw, long ldb, double* stats_b,
+                 const void* a_raw, long lda, const float* mean_a, double* stats_a,
+                 const void* b_raw, long ldb, const float* mean_b, double* stats_b,
                  void* e, long lde, long P, int C, int dtype, void* stream);
 
 /* ---- dropout / bias gradient / optimizer ------------------------------------------------------------

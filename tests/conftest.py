@@ -8,6 +8,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+try:  # the CPU oracle: a GPU box reports 256 logical CPUs but grants ~16; oversubscribed torch is very slow
+    import torch
+    torch.set_num_threads(_threads())
+except ImportError:  # pragma: no cover
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

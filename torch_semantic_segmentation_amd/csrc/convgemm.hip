@@ -2,8 +2,8 @@
 //
 //   out[p][n] = sum_k A(p, k) * Wt(n, k)            p = output pixel (NHWC row), n = output channel
 //
-//   * pointwise 1x1 forward        A = relu?(x*scale+shift)                (deferred BN of the producer)
-//   * pointwise 1x1 backward-data  A = ga*e + gb*y + gd                    (deferred BN-backward of this conv)
+//   * pointwise 1x1 forward        A = relu?((x-mean)*scale+bias)          (deferred BN of the producer)
+//   * pointwise 1x1 backward-data  A = ga*(e-ce) + gb*(y-mu)               (deferred BN-backward of this conv)
 //   * dense 3x3 forward/backward   the same two prologues, gathered over 9 taps (im2col-free)
 //   * 3-channel stem 3x3 stride 2  A gathered from the NCHW image, K = Cin*9 zero-padded to the MFMA step
 //
@@ -49,7 +49,9 @@ struct GemmArgs {
   // A operand
   const void* a0; long lda0;
   const void* a1; long lda1;
-  const float* c0; const float* c1; const float* c2;
+  // one source : A = (a0 - c1) * c0 + c2            (c0 scale, c1 mean, c2 bias; NULL -> 1, 0, 0)
+  // two sources: A = c0 * (a0 - c2) + c1 * (a1 - c3)   (c0 ga, c2 ce, c1 gb, c3 mu)
+  const float* c0; const float* c1; const float* c2; const float* c3;
   int a_relu, a0_f32;
   int Hin, Win, Hout, Wout, stride, dil, tap_sign, Cin;
   // weights: element (n, k, tap) at w[n*wrs + k*wcs + tap*wts]
@@ -58,7 +60,7 @@ struct GemmArgs {
   // output + forward statistics
   void* y; long ldy; double* stats;
   // backward epilogue: mask / second moment source
-  const void* xm; long ldxm; const float* ms; const float* mb; int m_relu;
+  const void* xm; long ldxm; const float* mm; const float* ms; const float* mb; int m_relu;
   int gslots;             // tile slots per XCD per channel chunk
 };
 
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);
   T* Ws = Xs + BM * RS;
-  float* Cs = reinterpret_cast<float*>(Ws + NCH * RS);  // [3][KC]
+  float* Cs = reinterpret_cast<float*>(Ws + NCH * RS);  // [4][KC]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -121,6 +123,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
           Cs[j] = g.c0 ? g.c0[k0 + j] : 1.f;
           Cs[KC + j] = g.c1 ? g.c1[k0 + j] : 0.f;
           Cs[2 * KC + j] = g.c2 ? g.c2[k0 + j] : 0.f;
+          Cs[3 * KC + j] = g.c3 ? g.c3[k0 + j] : 0.f;
         }
       }
       if (!w_resident || !w_loaded) {
@@ -206,10 +209,11 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
               float x1[8];
               V8<T>::load(a1 + q * g.lda1 + k0 + cv * 8, x1);
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = cc[j] * x0[j] + cc[KC + j] * x1[j] + cc[2 * KC + j];
+              for (int j = 0; j < 8; ++j)
+                v[j] = cc[j] * (x0[j] - cc[2 * KC + j]) + cc[KC + j] * (x1[j] - cc[3 * KC + j]);
             } else {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = cc[j] * x0[j] + cc[2 * KC + j];
+              for (int j = 0; j < 8; ++j) v[j] = (x0[j] - cc[KC + j]) * cc[j] + cc[2 * KC + j];
             }
             if (g.a_relu) {
 #pragma unroll
@@ -265,13 +269,14 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
               V4<T>::load(xm + p * g.ldxm + n, xr);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
+                const float xc = xr[r] - (g.mm ? g.mm[n + r] : 0.f);
                 if (g.m_relu) {
-                  const float a = g.ms ? (xr[r] * g.ms[n + r] + g.mb[n + r]) : xr[r];
+                  const float a = g.ms ? (xc * g.ms[n + r] + (g.mb ? g.mb[n + r] : 0.f)) : xc;
                   if (!(a > 0.f)) v[r] = 0.f;
                 }
                 v[r] = V8<T>::round(v[r]);
                 st1[i][r] += v[r];
-                st2[i][r] += v[r] * xr[r];
+                st2[i][r] += v[r] * xc;
               }
             } else {
 #pragma unroll
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 }
 
 template <typename T> size_t smem_bytes() {
-  return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 3 * Mma<T>::KC * sizeof(float);
+  return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 4 * Mma<T>::KC * sizeof(float);
 }
 
 int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
@@ -357,7 +362,7 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
@@ -366,7 +371,7 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* 
   TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y) && tss::aligned16(w), TSS_ERR_ALIGN);
   GemmArgs g = {};
   g.P = P; g.KD = K; g.ND = N; g.ntaps = 1; g.mode = A_PW;
-  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c2 = in_shift; g.a_relu = in_relu;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.Hout = 1; g.Wout = 1;
   g.w = w; g.wrs = K; g.wcs = 1; g.wts = 0; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
@@ -374,8 +379,8 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_scale, const float* 
 }
 
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                        const float* ga, const float* gb, const float* gd, const float* w,
-                        const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                        const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats,
                         long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
@@ -387,16 +392,17 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(w), TSS_ERR_ALIGN);
   GemmArgs g = {};
   g.P = P; g.KD = N; g.ND = K; g.ntaps = 1; g.mode = A_PW;
-  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gd;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr;
+  if (yraw) { g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu; } else { g.c0 = ga; }
   g.Hout = 1; g.Wout = 1;
   g.w = w; g.wrs = 1; g.wcs = K; g.wts = 0;  // Wt(k_out, n) = w[n*K + k_out]
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
-  g.xm = xraw; g.ldxm = ldx; g.ms = in_scale; g.mb = in_shift; g.m_relu = in_relu;
+  g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   const double bytes = (double)P * (N * (yraw ? 2 : 1) + K * (xraw ? 2 : 1)) * esz(dtype);
   return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
 }
 
-int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w_tnc, void* y, long ldy, double* stats,
                     int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
@@ -407,7 +413,7 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float*
   g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.tap_sign = 1; g.Cin = Cin;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;  // pad = dil, k = 3
   g.P = (long)B * g.Hout * g.Wout; g.KD = Cin; g.ND = N; g.ntaps = 9; g.mode = A_TAPS;
-  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c2 = in_shift; g.a_relu = in_relu;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin;  // [tap][n][c]
   g.y = y; g.ldy = ldy; g.stats = stats;
   const double bytes = ((double)B * Hin * Win * Cin + (double)g.P * N) * esz(dtype);
@@ -415,8 +421,8 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_scale, const float*
 }
 
 int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                         const float* ga, const float* gb, const float* gd, const float* w_tcn,
-                         const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats,
                          int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream) {
   // stride-1 dense 3x3 only (the hot path has no strided dense conv with Cin > 3)
@@ -428,10 +434,11 @@ int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   GemmArgs g = {};
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = -1; g.Cin = N;
   g.P = (long)B * H * W; g.KD = N; g.ND = Cin; g.ntaps = 9; g.mode = A_TAPS;
-  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gd;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr;
+  if (yraw) { g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu; } else { g.c0 = ga; }
   g.w = w_tcn; g.wrs = N; g.wcs = 1; g.wts = (long)Cin * N;  // [tap][ci][co]
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
-  g.xm = xraw; g.ldxm = ldx; g.ms = in_scale; g.mb = in_shift; g.m_relu = in_relu;
+  g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   const double bytes = (double)g.P * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * esz(dtype);
   return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes);
 }

@@ -4,8 +4,8 @@
 // consecutive channel vectors, so every load/store instruction of a wave covers whole contiguous
 // NHWC rows.  Blocks are persistent and sweep the image in XCD bands (common.h: xcd_tiles) so the
 // three input rows a tile shares with its vertical neighbours are served by the same L2.
-//   forward        y = dw(relu?(x*scale+shift))          + per-channel sum / sum-of-squares of y
-//   backward-data  e_in = relu'(.) * dw^T(ga*e+gb*y+gd)  + per-channel sum(e_in), sum(e_in*x)
+//   forward        y = dw(relu?((x-mean)*scale+bias))              + per-channel sum / sum-of-squares of y
+//   backward-data  e_in = relu'(.) * dw^T(ga*(e-ce)+gb*(y-mu))      + per-channel sum(e_in), sum(e_in*(x-mean))
 //   backward-weight dW[c][tap] += sum_p g(p,c) * a(p+tap, c)
 // The producer's BatchNorm(+ReLU) is applied on load and this conv's BatchNorm backward is applied on
 // load of (e, y): neither normalised activations nor input gradients of BN ever touch HBM.
@@ -16,10 +16,10 @@ namespace {
 constexpr int NT_MAX = 256;
 
 struct DwArgs {
-  const void* x; long ldx; const float* xs; const float* xb; int x_relu;
+  const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu;
   const float* w;  // [C][9]
   void* y; long ldy; double* stats;
-  const void* e; long lde; const void* yraw; long ldyr; const float* ga; const float* gb; const float* gd;
+  const void* e; long lde; const void* yraw; long ldyr; const float* ga; const float* gb; const float* gce; const float* gmu;
   float* dw;
   int B, Hin, Win, C, stride, dil, Hout, Wout;
   int CV, NPL;
@@ -61,16 +61,16 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
   const T* x = reinterpret_cast<const T*>(g.x);
   T* y = reinterpret_cast<T*>(g.y);
 
-  float wt[9][8], sc[8], sh[8];
+  float wt[9][8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; sc[j] = 1.f; sh[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
   if (active) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
-      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+      if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
   const long P = (long)g.B * g.Hout * g.Wout;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
         V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float a = v[j] * sc[j] + sh[j];
+          float a = (v[j] - mu[j]) * sc[j] + sh[j];
           if (g.x_relu) a = a > 0.f ? a : 0.f;
           acc[j] += a * wt[ky * 3 + kx][j];
         }
@@ -128,18 +128,21 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
   const T* x = reinterpret_cast<const T*>(g.x);
   T* out = reinterpret_cast<T*>(g.y);
 
-  float wt[9][8], ca[8], cb[8], cd[8], sc[8], sh[8];
+  float wt[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; ca[j] = 1.f; cb[j] = 0.f; cd[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0; s2[j] = 0; ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
+  }
   if (active) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
       if (g.ga) ca[j] = g.ga[c0 + j];
-      if (g.yraw) { cb[j] = g.gb[c0 + j]; cd[j] = g.gd[c0 + j]; }
-      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
+      if (g.xm) mu[j] = g.xm[c0 + j];
+      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
   const long P = (long)g.B * g.Hin * g.Win;  // one item per INPUT pixel
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
           float yv[8];
           V8<T>::load(yr + q * g.ldyr + c0, yv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (ca[j] * ev[j] + cb[j] * yv[j] + cd[j]) * wt[ky * 3 + kx][j];
+          for (int j = 0; j < 8; ++j)
+            acc[j] += (ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j])) * wt[ky * 3 + kx][j];
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] += (ca[j] * ev[j]) * wt[ky * 3 + kx][j];
@@ -186,10 +190,11 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
       V8<T>::load(x + p * g.ldx + c0, xv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (g.x_relu && !(xv[j] * sc[j] + sh[j] > 0.f)) acc[j] = 0.f;
+        const float xc = xv[j] - mu[j];
+        if (g.x_relu && !(xc * sc[j] + sh[j] > 0.f)) acc[j] = 0.f;
         acc[j] = V8<T>::round(acc[j]);
         s1[j] += (A)acc[j];
-        s2[j] += (A)acc[j] * (A)xv[j];
+        s2[j] += (A)acc[j] * (A)xc;
       }
     }
     V8<T>::store(out + p * g.ldy + c0, acc);
@@ -209,10 +214,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
   const T* x = reinterpret_cast<const T*>(g.x);
 
   for (int i = tid; i < g.C * 9; i += blockDim.x) sdw[i] = 0.f;
-  float acc[9][8], ca[8], cb[8], cd[8], sc[8], sh[8];
+  float acc[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    ca[j] = 1.f; cb[j] = 0.f; cd[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
+    ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t][j] = 0.f;
   }
@@ -220,8 +225,8 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (g.ga) ca[j] = g.ga[c0 + j];
-      if (g.yraw) { cb[j] = g.gb[c0 + j]; cd[j] = g.gd[c0 + j]; }
-      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb[c0 + j]; }
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
+      if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
   const long P = (long)g.B * g.Hout * g.Wout;
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
       float yv[8];
       V8<T>::load(yr + p * g.ldyr + c0, yv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = ca[j] * gv[j] + cb[j] * yv[j] + cd[j];
+      for (int j = 0; j < 8; ++j) gv[j] = ca[j] * (gv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) gv[j] = ca[j] * gv[j];
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
         V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float a = v[j] * sc[j] + sh[j];
+          float a = (v[j] - mu[j]) * sc[j] + sh[j];
           if (g.x_relu) a = a > 0.f ? a : 0.f;
           acc[ky * 3 + kx][j] += gv[j] * a;
         }
@@ -290,14 +295,14 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                       const float* w, void* y, long ldy, double* stats,
                       int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((ldx % 8) == 0 && (ldy % 8) == 0 && ldx >= C && ldy >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
   DwArgs g = {};
-  g.x = x; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu; g.w = w;
+  g.x = x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.w = w;
   g.y = y; g.ldy = ldy; g.stats = stats;
   g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
@@ -315,19 +320,19 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_scale, const floa
 }
 
 int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd, const float* w,
-                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            void* e_in, long ldei, double* bstats,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldei % 8) == 0 && ldei >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(!xraw || ((ldx % 8) == 0 && ldx >= C), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in), TSS_ERR_ALIGN);
   DwArgs g = {};
-  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd; g.w = w;
-  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu; g.w = w;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
   g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
@@ -346,16 +351,16 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 }
 
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                             const float* ga, const float* gb, const float* gd,
-                             const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                             const float* ga, const float* gb, const float* gce, const float* gmu,
+                             const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                              float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldx % 8) == 0 && ldx >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
   DwArgs g = {};
-  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
-  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu; g.dw = dw;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.dw = dw;
   g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
   int threads;

@@ -11,10 +11,10 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------ BN
-__global__ void bn_finalize_kernel(const double* sums, double count, const float* gamma, const float* beta,
+__global__ void bn_finalize_kernel(const double* sums, double count, const float* gamma,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    long long* num_batches, float* mean_out, float* invstd_out,
-                                   float* scale, float* shift, int C) {
+                                   float* scale, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && num_batches) *num_batches += 1;
   if (c >= C) return;
@@ -22,12 +22,11 @@ __global__ void bn_finalize_kernel(const double* sums, double count, const float
   double var = sums[C + c] / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float g = gamma ? gamma[c] : 1.f;
   const float m = (float)mean;
   mean_out[c] = m;
   invstd_out[c] = invstd;
   scale[c] = g * invstd;
-  shift[c] = b - m * (g * invstd);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
   if (running_var) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
@@ -35,30 +34,29 @@ __global__ void bn_finalize_kernel(const double* sums, double count, const float
   }
 }
 
-__global__ void bn_eval_affine_kernel(const float* gamma, const float* beta, const float* running_mean,
+__global__ void bn_eval_affine_kernel(const float* gamma, const float* running_mean,
                                       const float* running_var, float eps, float* mean_out, float* invstd_out,
-                                      float* scale, float* shift, int C) {
+                                      float* scale, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float invstd = 1.f / sqrtf(running_var[c] + eps);
-  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   mean_out[c] = running_mean[c];
   invstd_out[c] = invstd;
-  scale[c] = g * invstd;
-  shift[c] = b - running_mean[c] * (g * invstd);
+  scale[c] = (gamma ? gamma[c] : 1.f) * invstd;
 }
 
-// bstats = [sum(e), sum(e*y)] over the N = count elements of each channel.
-// training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N  =>  g = ga*e + gb*y + gd
+// bstats = [sum(e), sum(e*(y-mean))] over the N = count elements of each channel (centred: no cancellation).
+// training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
+//           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
 // frozen  : g = k*e
-__global__ void bn_bwd_finalize_kernel(const double* bstats, double count, const float* mean, const float* invstd,
+__global__ void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
                                        const float* gamma, int training, int accumulate,
-                                       float* dgamma, float* dbeta, float* ga, float* gb, float* gd, int C) {
+                                       float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double se = bstats[c], sey = bstats[C + c];
-  const double mu = mean[c], r = invstd[c];
-  const double dg = r * (sey - mu * se);
+  const double r = invstd[c];
+  const double dg = r * sey;
   const double db = se;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
@@ -67,16 +65,16 @@ __global__ void bn_bwd_finalize_kernel(const double* bstats, double count, const
     const double c1 = db / count, c2 = dg / count;
     ga[c] = (float)k;
     gb[c] = (float)(-k * c2 * r);
-    gd[c] = (float)(-k * c1 + k * c2 * r * mu);
+    gce[c] = (float)c1;
   } else {
-    ga[c] = (float)k; gb[c] = 0.f; gd[c] = 0.f;
+    ga[c] = (float)k; gb[c] = 0.f; gce[c] = 0.f;
   }
 }
 
 // ------------------------------------------------------------------------------------------ join
 struct JoinArgs {
-  const void* a; long lda; const float* sa; const float* ba;
-  const void* b; long ldb; const float* sb; const float* bb;
+  const void* a; long lda; const float* ma; const float* sa; const float* ba;
+  const void* b; long ldb; const float* mb; const float* sb; const float* bb;
   void* out; long ldo; int relu;
   // backward
   const void* dout; long lddo; void* e; long lde; double* stats_a; double* stats_b;
@@ -92,23 +90,23 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
   const T* a = reinterpret_cast<const T*>(g.a);
   const T* b = reinterpret_cast<const T*>(g.b);
   T* out = reinterpret_cast<T*>(g.out);
-  float sa[8], ba[8], sb[8], bb[8];
+  float ma[8], sa[8], ba[8], mb[8], sb[8], bb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    sa[j] = g.sa ? g.sa[c0 + j] : 1.f; ba[j] = g.sa ? g.ba[c0 + j] : 0.f;
-    sb[j] = g.sb ? g.sb[c0 + j] : 1.f; bb[j] = g.sb ? g.bb[c0 + j] : 0.f;
+    sa[j] = g.sa ? g.sa[c0 + j] : 1.f; ma[j] = (g.sa && g.ma) ? g.ma[c0 + j] : 0.f; ba[j] = (g.sa && g.ba) ? g.ba[c0 + j] : 0.f;
+    sb[j] = g.sb ? g.sb[c0 + j] : 1.f; mb[j] = (g.sb && g.mb) ? g.mb[c0 + j] : 0.f; bb[j] = (g.sb && g.bb) ? g.bb[c0 + j] : 0.f;
   }
   const long stride = (long)gridDim.x * g.NPL;
   for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
     float v[8];
     V8<T>::load(a + p * g.lda + c0, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = v[j] * sa[j] + ba[j];
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - ma[j]) * sa[j] + ba[j];
     if (b) {
       float u[8];
       V8<T>::load(b + p * g.ldb + c0, u);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += u[j] * sb[j] + bb[j];
+      for (int j = 0; j < 8; ++j) v[j] += (u[j] - mb[j]) * sb[j] + bb[j];
     }
     if (g.relu) {
 #pragma unroll
@@ -135,8 +133,13 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
   const T* b = reinterpret_cast<const T*>(g.b);
   T* e = reinterpret_cast<T*>(g.e);
   A s0[8], sA[8], sB[8];
+  float ma[8], mb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s0[j] = 0; sA[j] = 0; sB[j] = 0; }
+  for (int j = 0; j < 8; ++j) {
+    s0[j] = 0; sA[j] = 0; sB[j] = 0;
+    ma[j] = (active && g.ma) ? g.ma[c0 + j] : 0.f;
+    mb[j] = (active && g.mb) ? g.mb[c0 + j] : 0.f;
+  }
   const long stride = (long)gridDim.x * g.NPL;
   if (active) {
     for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
@@ -155,13 +158,13 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
         float u[8];
         V8<T>::load(a + p * g.lda + c0, u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sA[j] += (A)v[j] * (A)u[j];
+        for (int j = 0; j < 8; ++j) sA[j] += (A)v[j] * (A)(u[j] - ma[j]);
       }
       if (g.stats_b) {
         float u[8];
         V8<T>::load(b + p * g.ldb + c0, u);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sB[j] += (A)v[j] * (A)u[j];
+        for (int j = 0; j < 8; ++j) sB[j] += (A)v[j] * (A)(u[j] - mb[j]);
       }
     }
   }
@@ -315,44 +318,44 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 extern "C" {
 
-int tss_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float eps,
+int tss_bn_finalize(const double* sums, double count, const float* gamma, float eps,
                     float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
-                    float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream) {
+                    float* mean_out, float* invstd_out, float* scale, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 40.0 * C, 0);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
-                     gamma, beta, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
-                     scale, shift, C);
+                     gamma, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
+                     scale, C);
   return tss::check_last("bn_finalize");
 }
 
-int tss_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                       float eps, float* mean_out, float* invstd_out, float* scale, float* shift, int C, void* stream) {
+int tss_bn_eval_affine(const float* gamma, const float* running_mean, const float* running_var,
+                       float eps, float* mean_out, float* invstd_out, float* scale, int C, void* stream) {
   TSS_REQUIRE(C > 0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 32.0 * C, 0);
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta,
-                     running_mean, running_var, eps, mean_out, invstd_out, scale, shift, C);
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma,
+                     running_mean, running_var, eps, mean_out, invstd_out, scale, C);
   return tss::check_last("bn_eval_affine");
 }
 
-int tss_bn_bwd_finalize(const double* bstats, double count, const float* mean, const float* invstd,
+int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,
-                        float* ga, float* gb, float* gd, int C, void* stream) {
+                        float* ga, float* gb, float* gce, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, bstats, count,
-                     mean, invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gd, C);
+                     invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C);
   return tss::check_last("bn_bwd_finalize");
 }
 
-int tss_join_fwd(const void* a, long lda, const float* sa, const float* ba,
-                 const void* b, long ldb, const float* sb, const float* bb,
+int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, const float* ba,
+                 const void* b, long ldb, const float* mb, const float* sb, const float* bb,
                  void* out, long ldo, int relu, long P, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lda % 8) == 0 && lda >= C && (ldo % 8) == 0 && ldo >= C && (!b || ((ldb % 8) == 0 && ldb >= C)), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(a) && tss::aligned16(out) && tss::aligned16(b), TSS_ERR_ALIGN);
   JoinArgs g = {};
-  g.a = a; g.lda = lda; g.sa = sa; g.ba = ba; g.b = b; g.ldb = ldb; g.sb = sb; g.bb = bb;
+  g.a = a; g.lda = lda; g.ma = ma; g.sa = sa; g.ba = ba; g.b = b; g.ldb = ldb; g.mb = mb; g.sb = sb; g.bb = bb;
   g.out = out; g.ldo = ldo; g.relu = relu; g.P = P; g.C = C;
   int threads, grid;
   const int rc = join_geometry(g, &threads, &grid);
@@ -365,7 +368,8 @@ int tss_join_fwd(const void* a, long lda, const float* sa, const float* ba,
 }
 
 int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
-                 const void* a_raw, long lda, double* stats_a, const void* b_raw, long ldb, double* stats_b,
+                 const void* a_raw, long lda, const float* mean_a, double* stats_a,
+                 const void* b_raw, long ldb, const float* mean_b, double* stats_b,
                  void* e, long lde, long P, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lddo % 8) == 0 && lddo >= C && (!relu || (out && (ldo % 8) == 0 && ldo >= C)), TSS_ERR_SHAPE);
@@ -374,7 +378,7 @@ int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int rel
   TSS_REQUIRE(tss::aligned16(dout) && tss::aligned16(e), TSS_ERR_ALIGN);
   JoinArgs g = {};
   g.dout = dout; g.lddo = lddo; g.out = const_cast<void*>(out); g.ldo = ldo; g.relu = relu;
-  g.a = a_raw; g.lda = lda; g.stats_a = stats_a; g.b = b_raw; g.ldb = ldb; g.stats_b = stats_b;
+  g.a = a_raw; g.lda = lda; g.ma = mean_a; g.stats_a = stats_a; g.b = b_raw; g.ldb = ldb; g.mb = mean_b; g.stats_b = stats_b;
   g.e = e; g.lde = lde; g.P = P; g.C = C;
   int threads, grid;
   const int rc = join_geometry(g, &threads, &grid);

@@ -1,8 +1,8 @@
 // Weight-gradient contraction for the dense (non-depthwise) convolutions:
 //
 //   dW[n][k] += sum_p G(p, n) * A(p, k)
-//     G(p, n) = ga[n]*e[p][n] + gb[n]*y[p][n] + gd[n]        (deferred BN-backward of this conv's output)
-//     A(p, k) = relu?(x[q(p)][k]*scale[k] + shift[k])        (deferred BN of the producer; q = p for 1x1,
+//     G(p, n) = ga[n]*(e[p][n]-ce[n]) + gb[n]*(y[p][n]-mu[n]) (deferred BN-backward of this conv's output)
+//     A(p, k) = relu?((x[q(p)][k]-mean[k])*scale[k]+bias[k]) (deferred BN of the producer; q = p for 1x1,
 //                                                             the tap-shifted pixel for 3x3, the NCHW gather
 //                                                             for the 3-channel stem)
 //
@@ -47,8 +47,8 @@ struct WgradArgs {
   long P;
   int ND, KD, ntaps, mode;
   const void* e; long lde; const void* yraw; long ldyr;
-  const float* ga; const float* gb; const float* gd;
-  const void* x; long ldx; const float* xs; const float* xb; int x_relu, x_f32;
+  const float* ga; const float* gb; const float* gce; const float* gmu;
+  const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_f32;
   int Hin, Win, Hout, Wout, stride, dil, Cin;
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
           V8<T>::load(yr + p * g.ldyr + ch, yv);
 #pragma unroll
           for (int j = 0; j < 8; ++j)
-            if (ch + j < g.ND) v[j] = g.ga[ch + j] * ev[j] + g.gb[ch + j] * yv[j] + g.gd[ch + j];
+            if (ch + j < g.ND)
+              v[j] = g.ga[ch + j] * (ev[j] - g.gce[ch + j]) + g.gb[ch + j] * (yv[j] - g.gmu[ch + j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             if (ch + j < g.KD) {
-              float a = g.xs ? (xv[j] * g.xs[ch + j] + g.xb[ch + j]) : xv[j];
+              float a = g.xs ? ((xv[j] - (g.xm ? g.xm[ch + j] : 0.f)) * g.xs[ch + j] + (g.xb ? g.xb[ch + j] : 0.f)) : xv[j];
               if (g.x_relu) a = a > 0.f ? a : 0.f;
               v[j] = a;
             }
@@ -253,17 +254,17 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 extern "C" {
 
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                          const float* ga, const float* gb, const float* gd,
-                          const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                          const float* ga, const float* gb, const float* gce, const float* gmu,
+                          const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                           float* dw, long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldx % 8) == 0 && ldx >= K, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
   WgradArgs g = {};
   g.P = P; g.ND = N; g.KD = K; g.ntaps = 1; g.mode = A_PW;
-  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
-  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.Hout = 1; g.Wout = 1;
   g.dw = dw; g.drs = K; g.dcs = 1; g.dts = 0;
   return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream,
@@ -271,37 +272,37 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
 }
 
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd,
-                           const void* xraw, long ldx, const float* in_scale, const float* in_shift, int in_relu,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int Hin, int Win, int Cin, int N, int stride, int dil,
                            int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin,
               TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   WgradArgs g = {};
   g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.Cin = Cin;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
   g.P = (long)B * g.Hout * g.Wout; g.ND = N; g.KD = Cin; g.ntaps = 9; g.mode = A_TAPS;
-  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
-  g.x = xraw; g.ldx = ldx; g.xs = in_scale; g.xb = in_shift; g.x_relu = in_relu;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 9; g.dts = 1;  // torch layout [N][Cin][3][3]
   return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
                 ((double)g.P * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin) * esz(dtype));
 }
 
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
-                           const float* ga, const float* gb, const float* gd,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* x_nchw, int x_is_f32, float* dw,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(Cin >= 1 && Cin * 9 <= TK && N > 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gd), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   WgradArgs g = {};
   g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = 1; g.Cin = Cin;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
   g.P = (long)B * g.Hout * g.Wout; g.ND = N; g.KD = Cin * 9; g.ntaps = 1; g.mode = A_STEM;
-  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gd = gd;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
   g.x = x_nchw; g.x_f32 = x_is_f32;
   g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 1; g.dts = 0;
   return launch(g, dtype, TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream,

@@ -44,6 +44,13 @@ class direct_grads:
         return False
 
 
+def _aff(link):
+    """(mean, scale, bias) device pointers of a pending BatchNorm: a = (x - mean) * scale + bias."""
+    if link is None:
+        return None, None, None
+    return ptr(link.mean), ptr(link.scale), ptr(link.beta)
+
+
 def _direct_target(param):
     g = param.grad if param is not None else None
     if _DIRECT[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda:
@@ -103,13 +110,13 @@ def npix(t):
 
 class BNLink:
     """State shared by the producer and the consumer of one deferred BatchNorm."""
-    __slots__ = ('C', 'count', 'training', 'gamma', 'vec', 'scale', 'shift', 'mean', 'invstd',
-                 'ga', 'gb', 'gd', 'stats', 'bstats', 'consumed')
+    __slots__ = ('C', 'count', 'training', 'gamma', 'beta', 'vec', 'scale', 'mean', 'invstd',
+                 'ga', 'gb', 'gce', 'stats', 'bstats', 'consumed')
 
-    def __init__(self, C, count, training, gamma, device):
-        self.C, self.count, self.training, self.gamma = C, count, training, gamma
-        self.vec = torch.empty((7, C), dtype=torch.float32, device=device)
-        self.scale, self.shift, self.mean, self.invstd, self.ga, self.gb, self.gd = self.vec.unbind(0)
+    def __init__(self, C, count, training, gamma, beta, device):
+        self.C, self.count, self.training, self.gamma, self.beta = C, count, training, gamma, beta
+        self.vec = torch.empty((6, C), dtype=torch.float32, device=device)
+        self.mean, self.invstd, self.scale, self.ga, self.gb, self.gce = self.vec.unbind(0)
         both = torch.zeros((2, 2 * C), dtype=torch.float64, device=device)
         self.stats, self.bstats = both[0], both[1]
         self.consumed = False
@@ -126,10 +133,6 @@ class Deferred:
     def shape(self):
         return self.raw.shape
 
-    def affine(self):
-        if self.link is None:
-            return None, None
-        return self.link.scale, self.link.shift
 
     def take(self):
         """Mark the single allowed consumption of a BN-pending tensor (its backward sums are single-use)."""
@@ -245,24 +248,24 @@ class ConvUnitFn(Function):
             if cfg.training and P <= 1:
                 raise ValueError('Expected more than 1 value per channel when training, got input size %s'
                                  % (tuple(y.shape),))
-            link = BNLink(Cout, P, cfg.training, gamma, dev)
+            link = BNLink(Cout, P, cfg.training, gamma, beta, dev)
         stats = ptr(link.stats) if (link is not None and cfg.training) else None
-        isc, ish = (cfg.in_link.scale, cfg.in_link.shift) if cfg.in_link is not None else (None, None)
+        aff = _aff(cfg.in_link)
         st = stream()
         if cfg.kind == 'pw':
-            call('tss_pwconv_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(weight), ptr(bias),
+            call('tss_pwconv_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), ptr(bias),
                  ptr(y), ld(y), stats, P, cfg.cin, Cout, dt, st)
         elif cfg.kind == 'dw':
             if bias is not None:
                 raise NotImplementedError('HIP path: depthwise convolution with bias')
-            call('tss_dwconv3x3_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(weight),
+            call('tss_dwconv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight),
                  ptr(y), ld(y), stats, B, Hin, Win, Cout, s, d, dt, st)
         elif cfg.kind == 'dense':
             if bias is not None:
                 raise NotImplementedError('HIP path: dense 3x3 convolution with bias')
             w_tnc = torch.empty((9, Cout, cfg.cin), dtype=torch.float32, device=dev)
             call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
-            call('tss_conv3x3_fwd', ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu), ptr(w_tnc),
+            call('tss_conv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc),
                  ptr(y), ld(y), stats, B, Hin, Win, cfg.cin, Cout, s, d, dt, st)
         else:  # stem
             if bias is not None:
@@ -273,14 +276,14 @@ class ConvUnitFn(Function):
             bn = cfg.bn
             if cfg.training:
                 track = bn.track_running_stats and bn.running_mean is not None
-                call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), ptr(beta), float(bn.eps),
+                call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
                      float(bn.momentum), ptr(bn.running_mean) if track else None,
                      ptr(bn.running_var) if track else None,
                      ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
-                     ptr(link.mean), ptr(link.invstd), ptr(link.scale), ptr(link.shift), Cout, st)
+                     ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
             else:
-                call('tss_bn_eval_affine', ptr(gamma), ptr(beta), ptr(bn.running_mean), ptr(bn.running_var),
-                     float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), ptr(link.shift), Cout, st)
+                call('tss_bn_eval_affine', ptr(gamma), ptr(bn.running_mean), ptr(bn.running_var),
+                     float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
         cfg.out_link = link
         ctx.cfg = cfg
         ctx.save_for_backward(x, weight, y if link is not None else None)
@@ -312,20 +315,19 @@ class ConvUnitFn(Function):
                 else:
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
-            call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.mean), ptr(link.invstd),
+            call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd),
                  ptr(link.gamma), int(link.training), acc, ptr(dgamma), ptr(dbeta),
-                 ptr(link.ga), ptr(link.gb), ptr(link.gd), Cout, st)
+                 ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
             if acc:
                 dgamma = dbeta = None
-            ga, gb, gd = link.ga, link.gb, link.gd
+            ga, gb, gce, gmu = link.ga, link.gb, link.gce, link.mean
             if not link.training:
-                y, gb, gd = None, None, None
+                y, gb, gce, gmu = None, None, None, None
         else:
-            ga = gb = gd = None
+            ga = gb = gce = gmu = None
             y = None
-        gargs = (ptr(e), ld(e), ptr(y), ld(y) if y is not None else 0, ptr(ga), ptr(gb), ptr(gd))
+        gargs = (ptr(e), ld(e), ptr(y), ld(y) if y is not None else 0, ptr(ga), ptr(gb), ptr(gce), ptr(gmu))
         il = cfg.in_link
-        isc, ish = (il.scale, il.shift) if il is not None else (None, None)
 
         dw = _direct_target(p_weight)
         dw_ret = None
@@ -339,7 +341,7 @@ class ConvUnitFn(Function):
             if need_dx:
                 raise NotImplementedError('HIP path: gradient with respect to the input image is not implemented')
         else:
-            xargs = (ptr(x), ld(x), ptr(isc), ptr(ish), int(cfg.in_relu))
+            xargs = (ptr(x), ld(x), *_aff(il), int(cfg.in_relu))
             deferred_in = il is not None or cfg.in_relu
             if cfg.kind == 'pw':
                 call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, st)
@@ -349,7 +351,7 @@ class ConvUnitFn(Function):
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, st)
             if need_dx:
                 e_in = new_nhwc(B, Cin, Hin, Win, e.dtype, dev)
-                margs = xargs if deferred_in else (None, 0, None, None, 0)
+                margs = xargs if deferred_in else (None, 0, None, None, None, 0)
                 bst = ptr(il.bstats) if il is not None else None
                 if cfg.kind == 'pw':
                     call('tss_pwconv_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
@@ -404,8 +406,7 @@ class JoinFn(Function):
     def forward(ctx, a, b, cfg):
         out = new_nhwc(*a.shape, a.dtype, a.device)
         al, bl = cfg.a_link, cfg.b_link
-        call('tss_join_fwd', ptr(a), ld(a), ptr(al.scale) if al else None, ptr(al.shift) if al else None,
-             ptr(b), ld(b) if b is not None else 0, ptr(bl.scale) if bl else None, ptr(bl.shift) if bl else None,
+        call('tss_join_fwd', ptr(a), ld(a), *_aff(al), ptr(b), ld(b) if b is not None else 0, *_aff(bl),
              ptr(out), ld(out), int(cfg.relu), npix(a), a.shape[1], N.dtype_code(a.dtype), stream())
         ctx.cfg = cfg
         ctx.has_b = b is not None
@@ -422,8 +423,8 @@ class JoinFn(Function):
         e = new_nhwc(*dout.shape, dout.dtype, dout.device) if cfg.relu else None
         if cfg.relu or al is not None or bl is not None:
             call('tss_join_bwd', ptr(dout), ld(dout), ptr(out), ld(out) if out is not None else 0, int(cfg.relu),
-                 ptr(a), ld(a) if a is not None else 0, ptr(al.bstats) if al else None,
-                 ptr(b), ld(b) if b is not None else 0, ptr(bl.bstats) if bl else None,
+                 ptr(a), ld(a) if a is not None else 0, ptr(al.mean) if al else None, ptr(al.bstats) if al else None,
+                 ptr(b), ld(b) if b is not None else 0, ptr(bl.mean) if bl else None, ptr(bl.bstats) if bl else None,
                  ptr(e), ld(e) if e is not None else 0, npix(dout), dout.shape[1],
                  N.dtype_code(dout.dtype), stream())
         g = e if e is not None else dout
