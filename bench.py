@@ -228,6 +228,12 @@ def main():
         breakdown = {k: {'ms_per_step': round(v['ms'] / nprof, 3), 'launches': v['launches'] // nprof,
                          'GBps': round(v['bytes'] / max(v['ms'], 1e-9) / 1e6, 1)}
                      for k, v in sorted(by_symbol.items(), key=lambda kv: -kv[1]['ms'])}
+        if os.environ.get('TSS_BENCH_LAUNCHES'):
+            recs = N.prof_records()
+            per_step = len(recs) // nprof
+            for i, (op, ms_i, by) in enumerate(recs[:per_step]):
+                print('%4d %-24s %9.1f us %9.1f MB %8.1f GB/s' % (i, op, ms_i * 1e3, by / 1e6, by / max(ms_i, 1e-9) / 1e6),
+                      file=sys.stderr)
         if os.environ.get('TSS_BENCH_OPS'):
             for op, r in sorted(table.items(), key=lambda kv: -kv[1]['ms']):
                 print('%-24s %-28s launches/step %3d  ms/step %7.3f  GB/s %7.1f  TFLOP/s %6.2f' % (

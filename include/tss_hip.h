@@ -46,7 +46,7 @@ enum {
   TSS_K_DWCONV_FWD, TSS_K_DWCONV_BWD_DATA, TSS_K_DWCONV_BWD_WEIGHT,
   TSS_K_BN_FINALIZE, TSS_K_BN_BWD_FINALIZE, TSS_K_JOIN_FWD, TSS_K_JOIN_BWD,
   TSS_K_DROPOUT, TSS_K_BIAS_GRAD, TSS_K_ADAMW,
-  TSS_K_BILINEAR_FWD, TSS_K_BILINEAR_BWD, TSS_K_BILINEAR_PLANAR_FWD,
+  TSS_K_BILINEAR_FWD, TSS_K_BILINEAR_BWD, TSS_K_BILINEAR_BWD_COLS, TSS_K_BILINEAR_PLANAR_FWD,
   TSS_K_UPSAMPLE_HEAD_FWD, TSS_K_UPSAMPLE_HEAD_BWD_ROWS, TSS_K_UPSAMPLE_HEAD_BWD_COLS,
   TSS_K_POOL_FWD, TSS_K_POOL_BWD, TSS_K_COPY,
   TSS_K_CE_FWD, TSS_K_CE_BWD, TSS_K_ARGMAX,
@@ -63,6 +63,7 @@ int tss_prof_enable(int on);           /* 1: record events for every launch from
 int tss_prof_reset(void);
 int tss_prof_collect(void);            /* synchronises recorded events and folds them into the per-kernel table */
 int tss_prof_get(int kernel_id, long* launches, double* total_ms, double* alg_bytes, double* flops);
+long tss_prof_records(int* kernel_ids, double* ms, double* alg_bytes, long max_records);  /* per-launch, in launch order */
 const char* tss_prof_name(int kernel_id);    /* operator name, e.g. "pwconv_fwd" */
 const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launches, e.g. "convgemm_kernel" */
 
@@ -70,12 +71,12 @@ const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launc
  * replaces: nn.Conv2d(k=1, bias=False) (+BatchNorm2d, ReLU fused as described above) built by
  *           Conv2dBlock TSS/models/fastscnn.py:164-173, DSConv2dBlock :194, ConvBlock TSS/models/contextnet.py:168-177
  *           and the biased classifier conv TSS/models/fastscnn.py:97, TSS/models/contextnet.py:86.
- * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional, [2N] f64, caller-zeroed) += sum(y), sum(y^2). */
+ * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional) = partial sums of y and y^2. */
 int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
- * bstats (optional, [2K] f64) += sum(e_in), sum(e_in * (xraw - in_mean)).  xraw/in_* NULL: plain dX, no mask. */
+ * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask. */
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
@@ -129,7 +130,13 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu,
                              const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                             float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+                             float* dw, float* ws /* [tss_stat_slabs()][C*9] f32 workspace */,
+                             int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+
+/* Per-channel statistics buffers (`stats`, `bstats`, `stats_a/b` everywhere in this header) are
+ * [tss_stat_slabs()][2*C] f64: every producing kernel writes one partial row per block and zeroes the rest, so
+ * the caller allocates them uninitialised; tss_bn_finalize / tss_bn_bwd_finalize sum the rows. */
+int tss_stat_slabs(void);
 
 /* ---- BatchNorm2d bookkeeping (eps, momentum, running stats exactly as torch.nn.BatchNorm2d) ----------
  * replaces: nn.BatchNorm2d in every block above (training: batch statistics + running update; eval: running stats). */
@@ -150,7 +157,7 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
 int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, const float* ba,
                  const void* b, long ldb, const float* mb, const float* sb, const float* bb,
                  void* out, long ldo, int relu, long P, int C, int dtype, void* stream);
-/* e = dout * relu'(out) (written if e != NULL); stats_x (optional, [2C] f64) += sum(e), sum(e * (x_raw - mean_x)) */
+/* e = dout * relu'(out) (written if e != NULL); stats_x (optional) = partial sums of e and e * (x_raw - mean_x) */
 int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
                  const void* a_raw, long lda, const float* mean_a, double* stats_a,
                  const void* b_raw, long ldb, const float* mean_b, double* stats_b,
@@ -173,8 +180,8 @@ int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp
  *           nn.AdaptiveAvgPool2d TSS/models/fastscnn.py:108; torch.cat :122 (tss_copy_nhwc into a channel slice). */
 int tss_bilinear_nhwc_fwd(const void* x, long ldx, void* y, long ldy, int B, int Hin, int Win, int Hout, int Wout,
                           int C, int dtype, void* stream);
-int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
-                          int C, int dtype, void* stream);
+int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, float* tmp /* [B*Hin*Wout*C] f32 */,
+                          int B, int Hin, int Win, int Hout, int Wout, int C, int dtype, void* stream);
 int tss_bilinear_planar_fwd(const void* x, int x_dtype, void* y, int y_dtype, long planes, int Hin, int Win,
                             int Hout, int Wout, void* stream);
 /* logits head: NHWC low-res logits (pitch ldl) -> NCHW-contiguous full-res logits, and its backward */

@@ -70,6 +70,9 @@ def lib():
         handle.tss_prof_symbol.argtypes = [ctypes.c_int]
         handle.tss_prof_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        handle.tss_prof_records.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
+                                            ctypes.POINTER(ctypes.c_double), ctypes.c_long]
+        handle.tss_prof_records.restype = ctypes.c_long
         _lib = handle
     return _lib
 
@@ -90,6 +93,16 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_slabs = None
+
+
+def stat_slabs():
+    global _slabs
+    if _slabs is None:
+        _slabs = lib().tss_stat_slabs()
+    return _slabs
+
+
 def dtype_code(dtype):
     if dtype == torch.float32:
         return TSS_F32
@@ -100,7 +113,7 @@ def dtype_code(dtype):
 
 # ----------------------------------------------------------------------------- profiler helpers
 
-K_COUNT = 30
+K_COUNT = 31
 
 
 def prof_enable(on=True):
@@ -109,6 +122,16 @@ def prof_enable(on=True):
 
 def prof_reset():
     call('tss_prof_reset')
+
+
+def prof_records(limit=100000):
+    """Per-launch (op_name, ms, algorithmic bytes) in launch order (after prof_table() collected them)."""
+    h = lib()
+    ids = (ctypes.c_int * limit)()
+    ms = (ctypes.c_double * limit)()
+    by = (ctypes.c_double * limit)()
+    n = min(h.tss_prof_records(ids, ms, by, limit), limit)
+    return [(h.tss_prof_name(ids[i]).decode(), ms[i], by[i]) for i in range(n)]
 
 
 def prof_table():

@@ -12,6 +12,10 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 #define TSS_WAVE 64
+// Per-channel statistics leave a kernel as one PARTIAL ROW per block ("slab"), written with plain stores into a
+// [TSS_STAT_SLABS][2C] f64 buffer and summed by the finalize kernels: no atomics (512 blocks adding 2C values to
+// the same addresses cost 50-100 us per launch on MI355X), and the sums are run-to-run deterministic.
+#define TSS_STAT_SLABS 512
 #define TSS_MAX_PERSISTENT_BLOCKS 1024  // 256 CUs x 4: enough waves in flight for HBM-bound loops
 
 // ---------------------------------------------------------------------------------------------
@@ -29,6 +33,13 @@ template <> struct V8<float> {
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
   static __device__ __forceinline__ float round(float x) { return x; }
+  struct Raw { float4 a, b; };
+  static __device__ __forceinline__ Raw load_raw(const float* p) {
+    Raw r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r;
+  }
+  static __device__ __forceinline__ void unpack(const Raw& r, float v[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+  }
 };
 
 template <> struct V8<bf16_t> {
@@ -46,6 +57,14 @@ template <> struct V8<bf16_t> {
     *reinterpret_cast<bf16x8*>(p) = o;
   }
   static __device__ __forceinline__ float round(float x) { return (float)(bf16_t)x; }
+  typedef uint4 Raw;  // issue all loads of a tap window first, convert afterwards
+  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& r, float v[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
 };
 
 // 4-wide access used by the MFMA epilogues (one lane owns 4 consecutive channels of one pixel).

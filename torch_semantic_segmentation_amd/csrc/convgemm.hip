@@ -72,6 +72,8 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
   T* Xs = reinterpret_cast<T*>(smem);
   T* Ws = Xs + BM * RS;
   float* Cs = reinterpret_cast<float*>(Ws + NCH * RS);  // [4][KC]
+  double* Sacc = reinterpret_cast<double*>(Cs + 4 * KC);  // [NCH][2] exact statistics (f32 path)
+  constexpr bool EXACT_STATS = sizeof(T) == 4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -102,6 +104,9 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
 
   const long HWo = (long)g.Hout * g.Wout;
+  if (EXACT_STATS) {
+    for (int i = tid; i < NCH * 2; i += NT) Sacc[i] = 0.0;  // first use is after the tile loop's barriers
+  }
 
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * BM;
@@ -250,12 +255,13 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     T* yo = reinterpret_cast<T*>(g.y);
     const T* xm = reinterpret_cast<const T*>(g.xm);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const long p = p0 + wave * 32 + m * 16 + fr;
+    for (int i = 0; i < 8; ++i) {
+      if (i < nfr) {
+        const int n = n0 + i * 16 + fq * 4;
+        double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};  // f32 parity path only
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i < nfr) {
-          const int n = n0 + i * 16 + fq * 4;
+        for (int m = 0; m < 2; ++m) {
+          const long p = p0 + wave * 32 + m * 16 + fr;
           if (p < g.P && n < g.ND) {
             float v[4];
 #pragma unroll
@@ -275,53 +281,79 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
                   if (!(a > 0.f)) v[r] = 0.f;
                 }
                 v[r] = V8<T>::round(v[r]);
-                st1[i][r] += v[r];
-                st2[i][r] += v[r] * xc;
+                if (EXACT_STATS) { d1[r] += (double)v[r]; d2[r] += (double)v[r] * (double)xc; }
+                else { st1[i][r] += v[r]; st2[i][r] += v[r] * xc; }
               }
             } else {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
                 v[r] = V8<T>::round(v[r]);
-                st1[i][r] += v[r];
-                st2[i][r] += v[r] * v[r];
+                if (EXACT_STATS) { d1[r] += (double)v[r]; d2[r] += (double)v[r] * (double)v[r]; }
+                else { st1[i][r] += v[r]; st2[i][r] += v[r] * v[r]; }
               }
             }
             V4<T>::store(yo + p * g.ldy + n, v);
+          }
+        }
+        if (EXACT_STATS && g.stats) {
+          // f32 parity path: products and sums in f64, so var = E[y^2] - mean^2 does not cancel in f32
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double a = d1[r], b = d2[r];
+#pragma unroll
+            for (int mk = 1; mk <= 8; mk <<= 1) { a += __shfl_xor(a, mk, 64); b += __shfl_xor(b, mk, 64); }
+            if (fr == 0) {
+              atomicAdd(&Sacc[(i * 16 + fq * 4 + r) * 2 + 0], a);
+              atomicAdd(&Sacc[(i * 16 + fq * 4 + r) * 2 + 1], b);
+            }
           }
         }
       }
     }
   }
 
-  // ---- per-channel statistics: 16-lane reduce, 4-wave reduce through LDS, one f64 atomic per channel
+  // ---- per-channel statistics: this block's partial sums go to slab row (xcd + 8*gslot), columns of its chunk;
+  //      rows that no block owns are zeroed here (the caller never clears the buffer)
   if (g.stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [4][2][NCH], aliases Xs
+    const int row = xcd + 8 * gslot, rows_used = 8 * g.gslots;
+    double a = 0.0, b = 0.0;
+    if (EXACT_STATS) {
+      if (tid < ncw) { a = Sacc[tid * 2 + 0]; b = Sacc[tid * 2 + 1]; }
+    } else {
+      // bf16 path: f32 partials per lane, 16-lane reduce, 4-wave reduce through LDS
+      float* red = reinterpret_cast<float*>(smem);  // [4][2][NCH], aliases Xs
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = st1[i][r], b = st2[i][r];
+        for (int r = 0; r < 4; ++r) {
+          float u = st1[i][r], w = st2[i][r];
 #pragma unroll
-        for (int mk = 1; mk <= 8; mk <<= 1) { a += __shfl_xor(a, mk, 64); b += __shfl_xor(b, mk, 64); }
-        if (fr == 0) {
-          red[(wave * 2 + 0) * NCH + i * 16 + fq * 4 + r] = a;
-          red[(wave * 2 + 1) * NCH + i * 16 + fq * 4 + r] = b;
+          for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w += __shfl_xor(w, mk, 64); }
+          if (fr == 0) {
+            red[(wave * 2 + 0) * NCH + i * 16 + fq * 4 + r] = u;
+            red[(wave * 2 + 1) * NCH + i * 16 + fq * 4 + r] = w;
+          }
         }
-      }
-    __syncthreads();
-    if (tid < ncw) {
-      double a = 0.0, b = 0.0;
+      __syncthreads();
+      if (tid < ncw) {
 #pragma unroll
-      for (int wv = 0; wv < 4; ++wv) { a += red[(wv * 2 + 0) * NCH + tid]; b += red[(wv * 2 + 1) * NCH + tid]; }
-      atomicAdd(g.stats + n0 + tid, a);
-      atomicAdd(g.stats + g.ND + n0 + tid, b);
+        for (int wv = 0; wv < 4; ++wv) { a += red[(wv * 2 + 0) * NCH + tid]; b += red[(wv * 2 + 1) * NCH + tid]; }
+      }
+    }
+    if (tid < ncw) {
+      g.stats[(long)row * 2 * g.ND + n0 + tid] = a;
+      g.stats[(long)row * 2 * g.ND + g.ND + n0 + tid] = b;
+      for (int r = row + rows_used; r < TSS_STAT_SLABS; r += rows_used) {
+        g.stats[(long)r * 2 * g.ND + n0 + tid] = 0.0;
+        g.stats[(long)r * 2 * g.ND + g.ND + n0 + tid] = 0.0;
+      }
     }
   }
 }
 
 template <typename T> size_t smem_bytes() {
-  return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 4 * Mma<T>::KC * sizeof(float);
+  return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 4 * Mma<T>::KC * sizeof(float) + NCH * 2 * sizeof(double);
 }
 
 int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {

@@ -20,7 +20,7 @@ struct DwArgs {
   const float* w;  // [C][9]
   void* y; long ldy; double* stats;
   const void* e; long lde; const void* yraw; long ldyr; const float* ga; const float* gb; const float* gce; const float* gmu;
-  float* dw;
+  float* dw; float* ws;
   int B, Hin, Win, C, stride, dil, Hout, Wout;
   int CV, NPL;
 };
@@ -28,7 +28,8 @@ struct DwArgs {
 template <typename T> struct StatAcc { typedef float type; };
 template <> struct StatAcc<float> { typedef double type; };
 
-// Block-level per-channel reduction of two 8-channel partials per thread, then f64 atomics.
+// Block-level per-channel reduction of two 8-channel partials per thread; the block's partial sums go to its own
+// slab row (plain stores), rows no block owns are zeroed here so the caller never has to clear the buffer.
 template <typename A>
 __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double* stats, int C, int CV, int NPL,
                                             int cg, int pl, bool active, unsigned char* smem) {
@@ -46,33 +47,37 @@ __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double
     const int which = i / C, c = i - which * C;
     double a = 0.0;
     for (int q = 0; q < NPL; ++q) a += (double)red[(q * 2 + which) * C + c];
-    atomicAdd(stats + which * C + c, a);
+    stats[(long)blockIdx.x * 2 * C + i] = a;
+    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) stats[(long)r * 2 * C + i] = 0.0;
   }
 }
+
+// Tap geometry of one pixel, branch-free: clamped source coordinates + validity, so that all nine loads of a
+// window can be issued back to back (no divergent skip between them) and invalid taps are zeroed by a select.
+struct Taps { long off[9]; bool ok[9]; };
 
 template <typename T>
 __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) float wl[9 * 768];  // [tap][C]
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
   const bool active = pl < g.NPL;
   const int c0 = cg * 8;
   const T* x = reinterpret_cast<const T*>(g.x);
   T* y = reinterpret_cast<T*>(g.y);
+  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
 
-  float wt[9][8], mu[8], sc[8], sh[8];
+  float mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
-  if (active) {
+  if (active && g.xs) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
-      if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
-    }
+    for (int j = 0; j < 8; ++j) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
   }
+  __syncthreads();
   const long P = (long)g.B * g.Hout * g.Wout;
   const long ntiles = (P + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles);
@@ -83,25 +88,38 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
     const long t2 = p / g.Wout;
     const int oy = (int)(t2 % g.Hout);
     const long b = t2 / g.Hout;
+    typename V8<T>::Raw raw[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * g.stride + (ky - 1) * g.dil;
+      const bool vy = iy >= 0 && iy < g.Hin;
+      const int iyc = vy ? iy : 0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * g.stride + (kx - 1) * g.dil;
+        const bool vx = ix >= 0 && ix < g.Win;
+        const int ixc = vx ? ix : 0;
+        ok[ky * 3 + kx] = vy && vx;
+        raw[ky * 3 + kx] = V8<T>::load_raw(x + ((b * g.Hin + iyc) * (long)g.Win + ixc) * g.ldx + c0);
+      }
+    }
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * g.stride + (ky - 1) * g.dil;
-      if (iy < 0 || iy >= g.Hin) continue;
+    for (int t = 0; t < 9; ++t) {
+      float v[8];
+      V8<T>::unpack(raw[t], v);
+      const float4 w0 = *reinterpret_cast<const float4*>(wl + t * g.C + c0);
+      const float4 w1 = *reinterpret_cast<const float4*>(wl + t * g.C + c0 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * g.stride + (kx - 1) * g.dil;
-        if (ix < 0 || ix >= g.Win) continue;
-        float v[8];
-        V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = (v[j] - mu[j]) * sc[j] + sh[j];
-          if (g.x_relu) a = a > 0.f ? a : 0.f;
-          acc[j] += a * wt[ky * 3 + kx][j];
-        }
+      for (int j = 0; j < 8; ++j) {
+        float a = (v[j] - mu[j]) * sc[j] + sh[j];
+        if (g.x_relu) a = a > 0.f ? a : 0.f;
+        a = ok[t] ? a : 0.f;
+        acc[j] += a * wv[j];
       }
     }
 #pragma unroll
@@ -119,6 +137,7 @@ template <typename T>
 __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) float wl[9 * 768];  // [tap][C]
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
   const bool active = pl < g.NPL;
@@ -127,8 +146,9 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
   T* out = reinterpret_cast<T*>(g.y);
+  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
 
-  float wt[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
+  float ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -137,14 +157,13 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
   if (active) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wt[t][j] = g.w[(c0 + j) * 9 + t];
       if (g.ga) ca[j] = g.ga[c0 + j];
       if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
       if (g.xm) mu[j] = g.xm[c0 + j];
       if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
+  __syncthreads();
   const long P = (long)g.B * g.Hin * g.Win;  // one item per INPUT pixel
   const long ntiles = (P + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles);
@@ -155,39 +174,54 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
     const long t2 = p / g.Win;
     const int iy = (int)(t2 % g.Hin);
     const long b = t2 / g.Hin;
+    typename V8<T>::Raw re[9], ry[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ny = iy - (ky - 1) * g.dil;  // = oy * stride
+      const int oy = ny / g.stride;
+      const bool vy = ny >= 0 && oy * g.stride == ny && oy < g.Hout;
+      const int oyc = vy ? oy : 0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int nx = ix - (kx - 1) * g.dil;
+        const int ox = nx / g.stride;
+        const bool vx = nx >= 0 && ox * g.stride == nx && ox < g.Wout;
+        const int oxc = vx ? ox : 0;
+        ok[ky * 3 + kx] = vy && vx;
+        const long q = (b * g.Hout + oyc) * (long)g.Wout + oxc;
+        re[ky * 3 + kx] = V8<T>::load_raw(e + q * g.lde + c0);
+        if (yr) ry[ky * 3 + kx] = V8<T>::load_raw(yr + q * g.ldyr + c0);
+      }
+    }
+    typename V8<T>::Raw rx;
+    if (g.x) rx = V8<T>::load_raw(x + p * g.ldx + c0);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int ny = iy - (ky - 1) * g.dil;  // = oy * stride
-      if (ny < 0 || (ny % g.stride) != 0) continue;
-      const int oy = ny / g.stride;
-      if (oy >= g.Hout) continue;
+    for (int t = 0; t < 9; ++t) {
+      float ev[8];
+      V8<T>::unpack(re[t], ev);
+      const float4 w0 = *reinterpret_cast<const float4*>(wl + t * g.C + c0);
+      const float4 w1 = *reinterpret_cast<const float4*>(wl + t * g.C + c0 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+      if (yr) {
+        float yv[8];
+        V8<T>::unpack(ry[t], yv);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int nx = ix - (kx - 1) * g.dil;
-        if (nx < 0 || (nx % g.stride) != 0) continue;
-        const int ox = nx / g.stride;
-        if (ox >= g.Wout) continue;
-        const long q = (b * g.Hout + oy) * (long)g.Wout + ox;
-        float ev[8];
-        V8<T>::load(e + q * g.lde + c0, ev);
-        if (yr) {
-          float yv[8];
-          V8<T>::load(yr + q * g.ldyr + c0, yv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            acc[j] += (ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j])) * wt[ky * 3 + kx][j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += (ca[j] * ev[j]) * wt[ky * 3 + kx][j];
+        for (int j = 0; j < 8; ++j) {
+          const float gv = ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
+          acc[j] += (ok[t] ? gv : 0.f) * wv[j];
         }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (ok[t] ? ca[j] * ev[j] : 0.f) * wv[j];
       }
     }
     if (g.x) {
       float xv[8];
-      V8<T>::load(x + p * g.ldx + c0, xv);
+      V8<T>::unpack(rx, xv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xc = xv[j] - mu[j];
@@ -239,6 +273,22 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
     const long t2 = p / g.Wout;
     const int oy = (int)(t2 % g.Hout);
     const long b = t2 / g.Hout;
+    typename V8<T>::Raw raw[9];
+    bool ok[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * g.stride + (ky - 1) * g.dil;
+      const bool vy = iy >= 0 && iy < g.Hin;
+      const int iyc = vy ? iy : 0;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * g.stride + (kx - 1) * g.dil;
+        const bool vx = ix >= 0 && ix < g.Win;
+        const int ixc = vx ? ix : 0;
+        ok[ky * 3 + kx] = vy && vx;
+        raw[ky * 3 + kx] = V8<T>::load_raw(x + ((b * g.Hin + iyc) * (long)g.Win + ixc) * g.ldx + c0);
+      }
+    }
     float gv[8];
     V8<T>::load(e + p * g.lde + c0, gv);
     if (yr) {
@@ -251,21 +301,14 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
       for (int j = 0; j < 8; ++j) gv[j] = ca[j] * gv[j];
     }
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * g.stride + (ky - 1) * g.dil;
-      if (iy < 0 || iy >= g.Hin) continue;
+    for (int t = 0; t < 9; ++t) {
+      float v[8];
+      V8<T>::unpack(raw[t], v);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * g.stride + (kx - 1) * g.dil;
-        if (ix < 0 || ix >= g.Win) continue;
-        float v[8];
-        V8<T>::load(x + ((b * g.Hin + iy) * (long)g.Win + ix) * g.ldx + c0, v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = (v[j] - mu[j]) * sc[j] + sh[j];
-          if (g.x_relu) a = a > 0.f ? a : 0.f;
-          acc[ky * 3 + kx][j] += gv[j] * a;
-        }
+      for (int j = 0; j < 8; ++j) {
+        float a = (v[j] - mu[j]) * sc[j] + sh[j];
+        if (g.x_relu) a = a > 0.f ? a : 0.f;
+        acc[t][j] += gv[j] * (ok[t] ? a : 0.f);
       }
     }
   }
@@ -277,7 +320,22 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
       for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(c0 + j) * 9 + t], acc[t][j]);
   }
   __syncthreads();
-  for (int i = tid; i < g.C * 9; i += blockDim.x) atomicAdd(g.dw + i, sdw[i]);
+  // partial dW of this block -> its workspace row; rows nobody owns are zeroed; dw_reduce_kernel sums the rows
+  for (int i = tid; i < g.C * 9; i += blockDim.x) {
+    g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
+    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.ws[(long)r * g.C * 9 + i] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* dw, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (int r = 0; r < TSS_STAT_SLABS; r += 4) {
+    s0 += ws[(long)r * n + i]; s1 += ws[(long)(r + 1) * n + i];
+    s2 += ws[(long)(r + 2) * n + i]; s3 += ws[(long)(r + 3) * n + i];
+  }
+  dw[i] += (s0 + s1) + (s2 + s3);
 }
 
 int geometry(DwArgs& g, int* threads) {
@@ -311,7 +369,7 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float
   if (rc) return rc;
   const long P = (long)B * g.Hout * g.Wout;
   if (P == 0) return TSS_OK;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 2048);
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   tss::ProfScope prof(TSS_K_DWCONV_FWD, (hipStream_t)stream,
                       ((double)B * Hin * Win + (double)P) * C * esz(dtype), 18.0 * P * C);
   if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
@@ -342,7 +400,7 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   const long P = (long)B * Hin * Win;
   if (P == 0) return TSS_OK;
   const long Po = (long)B * g.Hout * g.Wout;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 2048);
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)Po * (yraw ? 2 : 1) + (double)P * (xraw ? 2 : 1)) * C * esz(dtype), 18.0 * Po * C);
   if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
@@ -353,14 +411,14 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu,
                              const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                             float* dw, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+                             float* dw, float* ws, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldx % 8) == 0 && ldx >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw) && ws, TSS_ERR_ALIGN);
   DwArgs g = {};
   g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
-  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.dw = dw;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.dw = dw; g.ws = ws;
   g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
   int threads;
@@ -368,11 +426,12 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
   if (rc) return rc;
   const long P = (long)B * g.Hout * g.Wout;
   if (P == 0) return TSS_OK;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, 512);
+  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   tss::ProfScope prof(TSS_K_DWCONV_BWD_WEIGHT, (hipStream_t)stream,
                       ((double)P * (yraw ? 2 : 1) + (double)B * Hin * Win) * C * esz(dtype), 18.0 * P * C);
   if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
   return tss::check_last("dwconv_bwd_weight");
 }
 

@@ -11,15 +11,37 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------ BN
-__global__ void bn_finalize_kernel(const double* sums, double count, const float* gamma,
+// sum of one column pair (c, C + c) over the TSS_STAT_SLABS partial rows: one 64-lane wave per channel, all
+// 2 x 8 loads of a lane issued before the first add (one memory round trip per finalize)
+__device__ __forceinline__ void slab_sum(const double* slabs, int C, int c, int lane, double* s0, double* s1) {
+  constexpr int R = TSS_STAT_SLABS / 64;
+  double va[R], vb[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const long off = (long)(lane + 64 * i) * 2 * C;
+    va[i] = c < C ? slabs[off + c] : 0.0;
+    vb[i] = c < C ? slabs[off + C + c] : 0.0;
+  }
+  double a = 0.0, b = 0.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) { a += va[i]; b += vb[i]; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+  *s0 = a; *s1 = b;
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sums, double count, const float* gamma,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    long long* num_batches, float* mean_out, float* invstd_out,
                                    float* scale, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches) *num_batches += 1;
-  if (c >= C) return;
-  const double mean = sums[c] / count;
-  double var = sums[C + c] / count - mean * mean;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  double ssum, ssq;
+  slab_sum(sums, C, c, lane, &ssum, &ssq);
+  if (c >= C || lane != 0) return;
+  const double mean = ssum / count;
+  double var = ssq / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f;
@@ -49,12 +71,14 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* running_m
 // training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
 //           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
 // frozen  : g = k*e
-__global__ void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
                                        const float* gamma, int training, int accumulate,
                                        float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double se = bstats[c], sey = bstats[C + c];
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  double se, sey;
+  slab_sum(bstats, C, c, lane, &se, &sey);
+  if (c >= C || lane != 0) return;
   const double r = invstd[c];
   const double dg = r * sey;
   const double db = se;
@@ -185,13 +209,19 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
     const int which = i / C, c = i - which * C;
     double s = 0.0;
     for (int q = 0; q < g.NPL; ++q) s += (double)red[(q * 3 + which) * C + c];
+    const long row = (long)blockIdx.x * 2 * C;
     if (which == 0) {
-      if (g.stats_a) atomicAdd(g.stats_a + c, s);
-      if (g.stats_b) atomicAdd(g.stats_b + c, s);
+      if (g.stats_a) g.stats_a[row + c] = s;
+      if (g.stats_b) g.stats_b[row + c] = s;
     } else if (which == 1) {
-      if (g.stats_a) atomicAdd(g.stats_a + C + c, s);
+      if (g.stats_a) g.stats_a[row + C + c] = s;
     } else {
-      if (g.stats_b) atomicAdd(g.stats_b + C + c, s);
+      if (g.stats_b) g.stats_b[row + C + c] = s;
+    }
+    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) {  // rows nobody owns
+      const long z = (long)r * 2 * C + (which == 0 ? c : C + c);
+      if (g.stats_a && which != 2) g.stats_a[z] = 0.0;
+      if (g.stats_b && which != 1) g.stats_b[z] = 0.0;
     }
   }
 }
@@ -202,7 +232,7 @@ int join_geometry(JoinArgs& g, int* threads, int* grid) {
   g.NPL = NT / g.CV;
   *threads = (g.CV * g.NPL + 63) / 64 * 64;
   const long tiles = (g.P + g.NPL - 1) / g.NPL;
-  long gsz = tiles < 2048 ? tiles : 2048;
+  long gsz = tiles < TSS_STAT_SLABS ? tiles : TSS_STAT_SLABS;  // one statistics slab row per block
   if (gsz < 1) gsz = 1;
   *grid = (int)gsz;
   return TSS_OK;
@@ -323,7 +353,7 @@ int tss_bn_finalize(const double* sums, double count, const float* gamma, float 
                     float* mean_out, float* invstd_out, float* scale, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 40.0 * C, 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, sums, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, count,
                      gamma, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
                      scale, C);
   return tss::check_last("bn_finalize");
@@ -343,7 +373,7 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         float* ga, float* gb, float* gce, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, bstats, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, bstats, count,
                      invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C);
   return tss::check_last("bn_bwd_finalize");
 }
@@ -390,6 +420,8 @@ int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int rel
   else hipLaunchKernelGGL(join_bwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   return tss::check_last("join_bwd");
 }
+
+int tss_stat_slabs(void) { return TSS_STAT_SLABS; }
 
 int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot, void* stream) {
   hipLaunchKernelGGL(dropout_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, seed_slot);

@@ -17,7 +17,8 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     {"bn_finalize", "bn_finalize_kernel"}, {"bn_bwd_finalize", "bn_bwd_finalize_kernel"},
     {"join_fwd", "join_fwd_kernel"}, {"join_bwd", "join_bwd_kernel"},
     {"dropout", "dropout_kernel"}, {"bias_grad", "colsum_kernel"}, {"adamw", "adamw_kernel"},
-    {"bilinear_nhwc_fwd", "bilinear_nhwc_fwd_kernel"}, {"bilinear_nhwc_bwd", "bilinear_nhwc_bwd_kernel"},
+    {"bilinear_nhwc_fwd", "bilinear_nhwc_fwd_kernel"}, {"bilinear_nhwc_bwd_rows", "bilinear_nhwc_bwd_rows_kernel"},
+    {"bilinear_nhwc_bwd_cols", "bilinear_nhwc_bwd_cols_kernel"},
     {"bilinear_planar_fwd", "bilinear_planar_fwd_kernel"},
     {"upsample_head_fwd", "upsample_head_fwd_kernel"}, {"upsample_head_bwd_rows", "upsample_head_bwd_rows_kernel"},
     {"upsample_head_bwd_cols", "upsample_head_bwd_cols_kernel"},
@@ -28,6 +29,8 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
 
 struct Rec { int kid; hipEvent_t a, b; double bytes, flops; };
 struct Total { long launches; double ms, bytes, flops; };
+struct Done { int kid; double ms, bytes; };
+std::vector<Done> g_done;
 
 std::mutex g_mu;
 bool g_enabled = false;
@@ -90,6 +93,7 @@ int tss_prof_reset(void) {
   for (Rec& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
   g_recs.clear();
   for (int i = 0; i < TSS_K_COUNT; ++i) g_tot[i] = Total{0, 0.0, 0.0, 0.0};
+  g_done.clear();
   return TSS_OK;
 }
 
@@ -101,6 +105,7 @@ int tss_prof_collect(void) {
     if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return TSS_ERR_HIP;
     Total& t = g_tot[r.kid];
     t.launches += 1; t.ms += ms; t.bytes += r.bytes; t.flops += r.flops;
+    g_done.push_back(Done{r.kid, (double)ms, r.bytes});
     g_pool.push_back(r.a); g_pool.push_back(r.b);
   }
   g_recs.clear();
@@ -116,6 +121,13 @@ int tss_prof_get(int kernel_id, long* launches, double* total_ms, double* alg_by
   if (alg_bytes) *alg_bytes = t.bytes;
   if (flops) *flops = t.flops;
   return TSS_OK;
+}
+
+long tss_prof_records(int* kernel_ids, double* ms, double* alg_bytes, long max_records) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  long n = (long)g_done.size() < max_records ? (long)g_done.size() : max_records;
+  for (long i = 0; i < n; ++i) { kernel_ids[i] = g_done[i].kid; ms[i] = g_done[i].ms; alg_bytes[i] = g_done[i].bytes; }
+  return (long)g_done.size();
 }
 
 const char* tss_prof_name(int kernel_id) {

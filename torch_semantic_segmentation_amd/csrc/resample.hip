@@ -68,35 +68,64 @@ __global__ __launch_bounds__(NT) void bilinear_nhwc_fwd_kernel(const T* x, long 
   }
 }
 
+// Backward is separable and done as two gathers through an f32 workspace [B][Hin][Wout][C]:
+//   rows : tmp[b][iy][ox][:] = sum_oy wy(oy, iy) * dy[b][oy][ox][:]      (coalesced 16-byte loads down a column)
+//   cols : dx [b][iy][ix][:] = sum_ox wx(ox, ix) * tmp[b][iy][ox][:]
+// A direct 2-D gather would give a source pixel of a 1x1 pooled map (pyramid pooling) a serial loop over every
+// output pixel; the two passes keep every loop at O(scale) or O(output extent) with ~Wout x more threads.
 template <typename T>
-__global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_kernel(const T* dy, long lddy, T* dx, long lddx, int B, int Hin,
-                                                               int Win, int Hout, int Wout, int C) {
+__global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_rows_kernel(const T* dy, long lddy, float* tmp, int B, int Hin,
+                                                                    int Hout, int Wout, int C) {
+  const int CV = C / 8;
+  const long total = (long)B * Hin * Wout * CV;
+  const float sy = ac_scale(Hin, Hout);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % Wout); p /= Wout;
+    const int iy = (int)(p % Hin);
+    const long b = p / Hin;
+    int lo, hi;
+    ac_window(sy, iy, Hout, &lo, &hi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = lo; oy <= hi; ++oy) {
+      const float wy = ac_weight(sy, oy, Hin, iy);
+      if (wy == 0.f) continue;
+      float v[8];
+      V8<T>::load(dy + ((b * Hout + oy) * (long)Wout + ox) * lddy + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wy * v[j];
+    }
+    V8<float>::store(tmp + ((b * Hin + iy) * (long)Wout + ox) * C + cv * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_cols_kernel(const float* tmp, T* dx, long lddx, int B, int Hin,
+                                                                    int Win, int Wout, int C) {
   const int CV = C / 8;
   const long total = (long)B * Hin * Win * CV;
-  const float sy = ac_scale(Hin, Hout), sx = ac_scale(Win, Wout);
+  const float sx = ac_scale(Win, Wout);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     long p = i / CV;
     const int ix = (int)(p % Win); p /= Win;
     const int iy = (int)(p % Hin);
     const long b = p / Hin;
-    int ylo, yhi, xlo, xhi;
-    ac_window(sy, iy, Hout, &ylo, &yhi);
-    ac_window(sx, ix, Wout, &xlo, &xhi);
+    int lo, hi;
+    ac_window(sx, ix, Wout, &lo, &hi);
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      const float wy = ac_weight(sy, oy, Hin, iy);
-      if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float w = wy * ac_weight(sx, ox, Win, ix);
-        if (w == 0.f) continue;
-        float v[8];
-        V8<T>::load(dy + ((b * Hout + oy) * (long)Wout + ox) * lddy + cv * 8, v);
+    for (int ox = lo; ox <= hi; ++ox) {
+      const float wx = ac_weight(sx, ox, Win, ix);
+      if (wx == 0.f) continue;
+      float v[8];
+      V8<float>::load(tmp + ((b * Hin + iy) * (long)Wout + ox) * C + cv * 8, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
-      }
+      for (int j = 0; j < 8; ++j) acc[j] += wx * v[j];
     }
     V8<T>::store(dx + ((b * Hin + iy) * (long)Win + ix) * lddx + cv * 8, acc);
   }
@@ -325,20 +354,28 @@ int tss_bilinear_nhwc_fwd(const void* x, long ldx, void* y, long ldy, int B, int
   return tss::check_last("bilinear_nhwc_fwd");
 }
 
-int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int Hin, int Win, int Hout, int Wout,
-                          int C, int dtype, void* stream) {
+int tss_bilinear_nhwc_bwd(const void* dy, long lddy, void* dx, long lddx, float* tmp, int B, int Hin, int Win,
+                          int Hout, int Wout, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(C > 0 && (C % 8) == 0 && (lddy % 8) == 0 && (lddx % 8) == 0 && lddy >= C && lddx >= C, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(dy) && tss::aligned16(dx), TSS_ERR_ALIGN);
-  const long total = (long)B * Hin * Win * (C / 8);
-  if (total == 0) return TSS_OK;
-  tss::ProfScope prof(TSS_K_BILINEAR_BWD, (hipStream_t)stream, ((double)B * Hin * Win + (double)B * Hout * Wout) * C * esz(dtype), 0);
-  if (dtype == TSS_BF16)
-    hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, Hin, Win, Hout, Wout, C);
-  else
-    hipLaunchKernelGGL(bilinear_nhwc_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const float*)dy, lddy, (float*)dx, lddx, B, Hin, Win, Hout, Wout, C);
+  TSS_REQUIRE(tss::aligned16(dy) && tss::aligned16(dx) && tss::aligned16(tmp) && tmp, TSS_ERR_ALIGN);
+  const long t1 = (long)B * Hin * Wout * (C / 8), t2 = (long)B * Hin * Win * (C / 8);
+  if (t1 == 0) return TSS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  {
+    tss::ProfScope prof(TSS_K_BILINEAR_BWD, st, (double)B * Hout * Wout * C * esz(dtype) + (double)B * Hin * Wout * C * 4, 0);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(bilinear_nhwc_bwd_rows_kernel<bf16_t>, dim3(grid_for(t1)), dim3(NT), 0, st, (const bf16_t*)dy, lddy, tmp, B, Hin, Hout, Wout, C);
+    else
+      hipLaunchKernelGGL(bilinear_nhwc_bwd_rows_kernel<float>, dim3(grid_for(t1)), dim3(NT), 0, st, (const float*)dy, lddy, tmp, B, Hin, Hout, Wout, C);
+  }
+  {
+    tss::ProfScope prof(TSS_K_BILINEAR_BWD_COLS, st, (double)B * Hin * Wout * C * 4 + (double)B * Hin * Win * C * esz(dtype), 0);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(bilinear_nhwc_bwd_cols_kernel<bf16_t>, dim3(grid_for(t2)), dim3(NT), 0, st, tmp, (bf16_t*)dx, lddx, B, Hin, Win, Wout, C);
+    else
+      hipLaunchKernelGGL(bilinear_nhwc_bwd_cols_kernel<float>, dim3(grid_for(t2)), dim3(NT), 0, st, tmp, (float*)dx, lddx, B, Hin, Win, Wout, C);
+  }
   return tss::check_last("bilinear_nhwc_bwd");
 }
 

@@ -54,23 +54,39 @@ struct WgradArgs {
   int nsplit;
 };
 
-// transposing store of 8 channel values of one pixel: rows ch0..ch0+7, column px
+// transposing store of a 4-pixel x 8-channel unit: rows ch0..ch0+7, columns 4*pg .. 4*pg+3 (one 8/16-byte
+// store per channel instead of four 2/4-byte ones)
+template <typename T> struct Pack4;
+template <> struct Pack4<bf16_t> {
+  static __device__ __forceinline__ void put(unsigned char* dst, float a, float b, float c, float d) {
+    bf16x4 o; o[0] = (bf16_t)a; o[1] = (bf16_t)b; o[2] = (bf16_t)c; o[3] = (bf16_t)d;
+    *reinterpret_cast<bf16x4*>(dst) = o;
+  }
+};
+template <> struct Pack4<float> {
+  static __device__ __forceinline__ void put(unsigned char* dst, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(dst) = make_float4(a, b, c, d);
+  }
+};
 template <typename T>
-__device__ __forceinline__ void put8(unsigned char* tile, int ch0, int px, const float v[8]) {
-  const int boff = px * (int)sizeof(T);
-  const int chunk = boff >> 4, within = boff & 15;
-  const int swz = (ch0 >> 3) & 7;
-  unsigned char* base = tile + ch0 * ROWB + ((chunk ^ swz) << 4) + within;
+__device__ __forceinline__ unsigned char* unit_addr(unsigned char* tile, int row, int pg) {
+  const int boff = pg * 4 * (int)sizeof(T);
+  return tile + row * ROWB + ((((boff >> 4)) ^ ((row >> 3) & 7)) << 4) + (boff & 15);
+}
+template <typename T>
+__device__ __forceinline__ void put_unit(unsigned char* tile, int ch0, int pg, const float v[4][8]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) *reinterpret_cast<T*>(base + j * ROWB) = (T)v[j];
+  for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_addr<T>(tile, ch0 + j, pg), v[0][j], v[1][j], v[2][j], v[3][j]);
 }
 
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   typedef WMma<T> M;
-  constexpr int PT = M::PT;
+  constexpr int PT = M::PT, NPG = PT / 4;
   __shared__ __align__(16) unsigned char Gt[TN * ROWB];
   __shared__ __align__(16) unsigned char At[TK * ROWB];
+  __shared__ __align__(16) float Cg[4][TN];  // ga, gb, gce, gmu of this N chunk
+  __shared__ __align__(16) float Ca[3][TK];  // mean, scale, bias of this K chunk
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -87,6 +103,9 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   const int ncw = (g.ND - n0 < TN) ? (g.ND - n0) : TN;
   const int kcw = (g.KD - k0 < TK) ? (g.KD - k0) : TK;
   const int nvn = (ncw + 7) >> 3, nvk = (kcw + 7) >> 3;
+  // MFMA fragments this wave actually owns (its 64x64 quadrant may lie partly or wholly outside the tile)
+  int nfn = (ncw - wn * 64 + 15) >> 4; nfn = nfn < 0 ? 0 : (nfn > 4 ? 4 : nfn);
+  int nfk = (kcw - wk * 64 + 15) >> 4; nfk = nfk < 0 ? 0 : (nfk > 4 ? 4 : nfk);
 
   const long nstage = (g.P + PT - 1) / PT;
   const long per = (nstage + g.nsplit - 1) / g.nsplit;
@@ -100,10 +119,21 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // zero both tiles once: rows / chunks that are never staged must read as 0
+  // zero both tiles once (rows / chunks that are never staged must read as 0) and stage the coefficients
   for (int i = tid; i < TN * ROWB / 16; i += NT) {
     reinterpret_cast<uint4*>(Gt)[i] = make_uint4(0, 0, 0, 0);
     reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+  }
+  for (int i = tid; i < TN; i += NT) {
+    const bool in = i < ncw;
+    Cg[0][i] = (in && g.ga) ? g.ga[n0 + i] : 1.f;
+    Cg[1][i] = (in && g.yraw) ? g.gb[n0 + i] : 0.f;
+    Cg[2][i] = (in && g.yraw) ? g.gce[n0 + i] : 0.f;
+    Cg[3][i] = (in && g.yraw) ? g.gmu[n0 + i] : 0.f;
+    const bool ik = i < kcw && g.mode != A_STEM;
+    Ca[0][i] = (ik && g.xs && g.xm) ? g.xm[k0 + i] : 0.f;
+    Ca[1][i] = (ik && g.xs) ? g.xs[k0 + i] : 1.f;
+    Ca[2][i] = (ik && g.xs && g.xb) ? g.xb[k0 + i] : 0.f;
   }
 
   const T* e = reinterpret_cast<const T*>(g.e);
@@ -115,119 +145,134 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   for (long s = s_begin; s < s_end; ++s) {
     const long p0 = s * PT;
     __syncthreads();
-    // ---- G tile
-    for (int idx = tid; idx < PT * nvn; idx += NT) {
-      const int px = idx / nvn, cv = idx - px * nvn;
-      const long p = p0 + px;
-      float v[8];
+    // ---- G tile: units of 4 pixels x 8 channels
+    for (int u = tid; u < NPG * nvn; u += NT) {
+      const int pg = u / nvn, cv = u - pg * nvn;
+      const int ch = n0 + cv * 8;
+      float v[4][8];
+      float ca[8], cb[8], cc[8], cm[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = 0.f;
-      if (p < g.P) {
-        const int ch = n0 + cv * 8;
+      for (int j = 0; j < 8; ++j) {
+        ca[j] = Cg[0][cv * 8 + j]; cb[j] = Cg[1][cv * 8 + j]; cc[j] = Cg[2][cv * 8 + j]; cm[j] = Cg[3][cv * 8 + j];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + pg * 4 + i;
+        const bool ok = p < g.P;
+        const long pc = ok ? p : 0;
         float ev[8];
-        V8<T>::load(e + p * g.lde + ch, ev);
+        V8<T>::load(e + pc * g.lde + ch, ev);
         if (yr) {
           float yv[8];
-          V8<T>::load(yr + p * g.ldyr + ch, yv);
+          V8<T>::load(yr + pc * g.ldyr + ch, yv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (ch + j < g.ND)
-              v[j] = g.ga[ch + j] * (ev[j] - g.gce[ch + j]) + g.gb[ch + j] * (yv[j] - g.gmu[ch + j]);
+          for (int j = 0; j < 8; ++j) v[i][j] = ca[j] * (ev[j] - cc[j]) + cb[j] * (yv[j] - cm[j]);
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (ch + j < g.ND) v[j] = g.ga ? g.ga[ch + j] * ev[j] : ev[j];
+          for (int j = 0; j < 8; ++j) v[i][j] = ca[j] * ev[j];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (!ok || ch + j >= g.ND) v[i][j] = 0.f;
       }
-      put8<T>(Gt, cv * 8, px, v);
+      put_unit<T>(Gt, cv * 8, pg, v);
     }
     // ---- A tile
     if (g.mode == A_STEM) {
       const float* src32 = reinterpret_cast<const float*>(g.x);
-      for (int idx = tid; idx < PT * kcw; idx += NT) {
-        const int px = idx % PT, j = idx / PT;
-        const long p = p0 + px;
-        float v = 0.f;
-        if (p < g.P) {
-          const int c = j / 9, t9 = j - c * 9, sy = t9 / 3, sx = t9 - sy * 3;
-          const long b = p / HWo; const long rem = p - b * HWo;
-          const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-          const int iy = oy * g.stride + (sy - 1) * g.dil, ix = ox * g.stride + (sx - 1) * g.dil;
-          if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
-            const long off = ((b * g.Cin + c) * g.Hin + iy) * (long)g.Win + ix;
-            v = g.x_f32 ? src32[off] : (float)x[off];
-          }
-        }
-        const int boff = px * (int)sizeof(T);
-        *reinterpret_cast<T*>(At + j * ROWB + (((boff >> 4) ^ ((j >> 3) & 7)) << 4) + (boff & 15)) = (T)v;
-      }
-    } else {
-      for (int idx = tid; idx < PT * nvk; idx += NT) {
-        const int px = idx / nvk, cv = idx - px * nvk;
-        const long p = p0 + px;
-        float v[8];
+      for (int u = tid; u < NPG * kcw; u += NT) {
+        const int pg = u % NPG, j = u / NPG;
+        const int c = j / 9, t9 = j - c * 9, sy = t9 / 3, sx = t9 - sy * 3;
+        float v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        long q = -1;
-        if (p < g.P) {
-          if (g.mode == A_PW) {
-            q = p;
-          } else {
+        for (int i = 0; i < 4; ++i) {
+          const long p = p0 + pg * 4 + i;
+          v[i] = 0.f;
+          if (p < g.P) {
             const long b = p / HWo; const long rem = p - b * HWo;
             const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-            const int iy = oy * g.stride + (ky - 1) * g.dil, ix = ox * g.stride + (kx - 1) * g.dil;
-            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
-          }
-        }
-        if (q >= 0) {
-          const int ch = k0 + cv * 8;
-          float xv[8];
-          V8<T>::load(x + q * g.ldx + ch, xv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (ch + j < g.KD) {
-              float a = g.xs ? ((xv[j] - (g.xm ? g.xm[ch + j] : 0.f)) * g.xs[ch + j] + (g.xb ? g.xb[ch + j] : 0.f)) : xv[j];
-              if (g.x_relu) a = a > 0.f ? a : 0.f;
-              v[j] = a;
+            const int iy = oy * g.stride + (sy - 1) * g.dil, ix = ox * g.stride + (sx - 1) * g.dil;
+            if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) {
+              const long off = ((b * g.Cin + c) * g.Hin + iy) * (long)g.Win + ix;
+              v[i] = g.x_f32 ? src32[off] : (float)x[off];
             }
           }
         }
-        put8<T>(At, cv * 8, px, v);
+        Pack4<T>::put(unit_addr<T>(At, j, pg), v[0], v[1], v[2], v[3]);
+      }
+    } else {
+      for (int u = tid; u < NPG * nvk; u += NT) {
+        const int pg = u / nvk, cv = u - pg * nvk;
+        const int ch = k0 + cv * 8;
+        float v[4][8];
+        float cm[8], cs[8], cb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cm[j] = Ca[0][cv * 8 + j]; cs[j] = Ca[1][cv * 8 + j]; cb[j] = Ca[2][cv * 8 + j]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const long p = p0 + pg * 4 + i;
+          long q = -1;
+          if (p < g.P) {
+            if (g.mode == A_PW) {
+              q = p;
+            } else {
+              const long b = p / HWo; const long rem = p - b * HWo;
+              const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+              const int iy = oy * g.stride + (ky - 1) * g.dil, ix = ox * g.stride + (kx - 1) * g.dil;
+              if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+            }
+          }
+          float xv[8];
+          V8<T>::load(x + (q >= 0 ? q : 0) * g.ldx + ch, xv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float a = (xv[j] - cm[j]) * cs[j] + cb[j];
+            if (g.x_relu) a = a > 0.f ? a : 0.f;
+            v[i][j] = (q >= 0 && ch + j < g.KD) ? a : 0.f;
+          }
+        }
+        put_unit<T>(At, cv * 8, pg, v);
       }
     }
     __syncthreads();
     // ---- MFMA over the PT pixels of this stage
-    const unsigned char* grow = Gt + (wn * 64 + fr) * ROWB;
-    const unsigned char* arow = At + (wk * 64 + fr) * ROWB;
+    if (nfn > 0 && nfk > 0) {
+      const unsigned char* grow = Gt + (wn * 64 + fr) * ROWB;
+      const unsigned char* arow = At + (wk * 64 + fr) * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < PT / M::KSTEP; ++ks) {
-      typename M::Frag gf[4], af[4];
+      for (int ks = 0; ks < PT / M::KSTEP; ++ks) {
+        typename M::Frag gf[4], af[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // swizzle key = (row >> 3) & 7 with row = w*64 + i*16 + fr
-        gf[i] = M::ld(grow + i * 16 * ROWB, ((wn * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
-        af[i] = M::ld(arow + i * 16 * ROWB, ((wk * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
+        for (int i = 0; i < 4; ++i) {
+          // swizzle key = (row >> 3) & 7 with row = w*64 + i*16 + fr
+          gf[i] = M::ld(grow + i * 16 * ROWB, ((wn * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
+          af[i] = M::ld(arow + i * 16 * ROWB, ((wk * 64 + i * 16 + fr) >> 3) & 7, ks, fq);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < nfn && j < nfk) acc[i][j] = M::mma(gf[i], af[j], acc[i][j]);
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M::mma(gf[i], af[j], acc[i][j]);
     }
   }
 
   // ---- add the partial tile: D[row = n][col = k]
   float* dwt = g.dw + tap * g.dts;
+  if (s_begin < s_end) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + wk * 64 + j * 16 + fr;
+      for (int j = 0; j < 4; ++j) {
+        if (i < nfn && j < nfk) {
+          const int k = k0 + wk * 64 + j * 16 + fr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
-        if (n < g.ND && k < g.KD && s_begin < s_end) atomicAdd(dwt + (long)n * g.drs + (long)k * g.dcs, acc[i][j][r]);
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
+            if (n < g.ND && k < g.KD) atomicAdd(dwt + (long)n * g.drs + (long)k * g.dcs, acc[i][j][r]);
+          }
+        }
       }
-    }
+  }
 }
 
 int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {

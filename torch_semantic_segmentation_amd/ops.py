@@ -117,7 +117,8 @@ class BNLink:
         self.C, self.count, self.training, self.gamma, self.beta = C, count, training, gamma, beta
         self.vec = torch.empty((6, C), dtype=torch.float32, device=device)
         self.mean, self.invstd, self.scale, self.ga, self.gb, self.gce = self.vec.unbind(0)
-        both = torch.zeros((2, 2 * C), dtype=torch.float64, device=device)
+        # [forward | backward][slab rows][sum, second moment]: written in full by the kernels, never cleared here
+        both = torch.empty((2, N.stat_slabs(), 2 * C), dtype=torch.float64, device=device)
         self.stats, self.bstats = both[0], both[1]
         self.consumed = False
 
@@ -346,7 +347,8 @@ class ConvUnitFn(Function):
             if cfg.kind == 'pw':
                 call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, st)
             elif cfg.kind == 'dw':
-                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cout, s, d, dt, st)
+                ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
+                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, st)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, st)
             if need_dx:
@@ -508,7 +510,8 @@ class BilinearFn(Function):
         B, C, H, W, ho, wo = ctx.geom
         dy = to_nhwc(dy)
         dx = new_nhwc(B, C, H, W, dy.dtype, dy.device)
-        call('tss_bilinear_nhwc_bwd', ptr(dy), ld(dy), ptr(dx), ld(dx), B, H, W, ho, wo, C,
+        tmp = torch.empty((B * H * wo * C,), dtype=torch.float32, device=dy.device)
+        call('tss_bilinear_nhwc_bwd', ptr(dy), ld(dy), ptr(dx), ld(dx), ptr(tmp), B, H, W, ho, wo, C,
              N.dtype_code(dy.dtype), stream())
         return dx, None, None
 
@@ -620,7 +623,8 @@ class ConcatUpFn(Function):
         for off, cb, hb, wb in geoms:
             db = new_nhwc(B, cb, hb, wb, dout.dtype, dout.device)
             sl = dout[:, off:off + cb]
-            call('tss_bilinear_nhwc_bwd', ptr(sl), ld(dout), ptr(db), ld(db), B, hb, wb, H, W, cb, dt, st)
+            tmp = torch.empty((B * hb * W * cb,), dtype=torch.float32, device=dout.device)
+            call('tss_bilinear_nhwc_bwd', ptr(sl), ld(dout), ptr(db), ld(db), ptr(tmp), B, hb, wb, H, W, cb, dt, st)
             grads.append(db)
         return tuple(grads)
 
