@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Run ONE kernel configuration repeatedly (for rocprofv3 --pmc): micro_one.py <pwfwd|pwbwd|wgrad|dwfwd> K N P"""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch_semantic_segmentation_amd import _native as N, ops
+which, K, Nn, P = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+dev = 'cuda:0'; S = N.stat_slabs()
+x = torch.randn(P, K, device=dev).bfloat16(); y = torch.empty(P, Nn, device=dev, dtype=torch.bfloat16)
+e = torch.randn(P, Nn, device=dev).bfloat16(); ein = torch.empty(P, K, device=dev, dtype=torch.bfloat16)
+w = torch.randn(Nn, K, device=dev) * 0.1; dw = torch.zeros(Nn, K, device=dev)
+stats = torch.empty(S, 2 * Nn, dtype=torch.float64, device=dev); bst = torch.empty(S, 2 * K, dtype=torch.float64, device=dev)
+mK = torch.zeros(K, device=dev); sK = torch.ones(K, device=dev); mN = torch.zeros(Nn, device=dev); sN = torch.ones(Nn, device=dev)
+st = N.stream()
+fns = {
+ 'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
+ 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), P, K, Nn, 1, st),
+ 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), P, K, Nn, 1, st),
+}
+if which == 'dwfwd':
+    C, B, H, W = K, 8, Nn, P
+    xi = ops.new_nhwc(B, C, H, W, torch.bfloat16, dev); xi.normal_(); yo = ops.new_nhwc(B, C, H, W, torch.bfloat16, dev)
+    wd = torch.randn(C, 1, 3, 3, device=dev); sd = torch.empty(S, 2 * C, dtype=torch.float64, device=dev)
+    m = torch.zeros(C, device=dev); s1 = torch.ones(C, device=dev)
+    fns['dwfwd'] = lambda: N.call('tss_dwconv3x3_fwd', N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(wd), N.ptr(yo), C, N.ptr(sd), B, H, W, C, 1, 1, 1, st)
+for _ in range(10):
+    fns[which]()
+torch.cuda.synchronize()

@@ -64,7 +64,7 @@ struct GemmArgs {
   int gslots;             // tile slots per XCD per channel chunk
 };
 
-template <typename T>
+template <typename T, bool HAS_A1>
 __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
   typedef Mma<T> M;
   constexpr int KC = M::KC, RS = M::RS, KSTEP = M::KSTEP;
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;  // wave tile: pixels wm*64..+63, channels wn*64..+63 of the block tile
 
   const int nchunks = (g.ND + NCH - 1) / NCH;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -89,17 +90,18 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 
   const int n0 = nc * NCH;
   const int ncw = (g.ND - n0 < NCH) ? (g.ND - n0) : NCH;
-  const int nfr = (ncw + 15) >> 4;
-  const int nrows = nfr * 16;
+  const int nrows = ((ncw + 15) >> 4) * 16;
+  int nfr = (ncw - wn * 64 + 15) >> 4;   // 16-channel fragments this wave owns (0..4)
+  nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
 
   const int kcpt = (g.KD + KC - 1) / KC;  // k-chunks per tap
   const int nkc = g.ntaps * kcpt;
   const bool w_resident = (nkc == 1);
   bool w_loaded = false;
 
-  float st1[8][4], st2[8][4];
+  float st1[4][4], st2[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
 
@@ -110,11 +112,11 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * BM;
-    f32x4 acc[2][8];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int kc = 0; kc < nkc; ++kc) {
       const int tap = kc / kcpt;
@@ -123,6 +125,48 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       const int kwp = (kw + KSTEP - 1) / KSTEP * KSTEP;
       __syncthreads();  // all MFMA reads of the previous chunk are done
 
+      // ---- 1. issue this thread's A-tile loads FIRST (raw, into registers): they are the only HBM round trip of
+      //         the chunk and must overlap the coefficient / weight staging below, not queue behind it
+      constexpr int MAXV = BM * (KC / 8) / NT;  // 16-byte vectors per thread per chunk (8 for bf16, 4 for f32)
+      typename V8<T>::Raw r0[MAXV], r1[HAS_A1 ? MAXV : 1];
+      bool vok[MAXV];
+      const int nvec = (kwp + 7) >> 3;
+      // (row, cv) of this thread's i-th vector.  When nvec divides 256 (16/8/4/2/1: every hot-path layer but the
+      // 48/96-channel ones) cv is fixed per thread and row advances by 256/nvec: one division per chunk, not 16.
+      const bool pow_map = (NT % nvec) == 0;
+      const int row0 = tid / nvec, cv0 = tid - row0 * nvec, rstep = pow_map ? NT / nvec : 0;
+      if (g.mode != A_STEM) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const T* a0 = reinterpret_cast<const T*>(g.a0);
+        const T* a1 = reinterpret_cast<const T*>(g.a1);
+        (void)a1;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+          const int idx = tid + i * NT;
+          int row, cv;
+          if (pow_map) { row = row0 + i * rstep; cv = cv0; } else { row = idx / nvec; cv = idx - row * nvec; }
+          const long p = p0 + row;
+          long q = -1;
+          if (idx < BM * nvec && p < g.P && cv * 8 < kw) {
+            if (g.mode == A_PW) {
+              q = p;
+            } else {
+              const long b = p / HWo; const long rem = p - b * HWo;
+              const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+              const int iy = oy * g.stride + g.tap_sign * (ky - 1) * g.dil;
+              const int ix = ox * g.stride + g.tap_sign * (kx - 1) * g.dil;
+              if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+            }
+          }
+          vok[i] = q >= 0;
+          const long qc = q >= 0 ? q : 0;
+          const int cvc = (cv * 8 < kw) ? cv : 0;
+          r0[i] = V8<T>::load_raw(a0 + qc * g.lda0 + k0 + cvc * 8);
+          if (HAS_A1) r1[i] = V8<T>::load_raw(a1 + qc * g.lda1 + k0 + cvc * 8);
+        }
+      }
+
+      // ---- 2. coefficients and (when not resident) weights
       if (g.mode != A_STEM) {
         for (int j = tid; j < kw; j += NT) {
           Cs[j] = g.c0 ? g.c0[k0 + j] : 1.f;
@@ -135,21 +179,53 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
         const float* wt = g.w + tap * g.wts;
         if (g.wcs == 1 && (kw & 3) == 0 && (g.wrs & 3) == 0) {
           const int vpr = kwp >> 2;  // float4 per row
-          for (int idx = tid; idx < nrows * vpr; idx += NT) {
-            const int n = idx / vpr, jv = idx - n * vpr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < ncw && jv * 4 < kw) v = *reinterpret_cast<const float4*>(wt + (long)(n0 + n) * g.wrs + k0 + jv * 4);
-            T* d = Ws + n * RS + jv * 4;
-            d[0] = (T)v.x; d[1] = (T)v.y; d[2] = (T)v.z; d[3] = (T)v.w;
+          const int total = nrows * vpr;
+          for (int base = 0; base < total; base += NT * 8) {   // 8 independent float4 loads in flight per lane
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int idx = base + tid + u * NT;
+              const int n = idx / vpr, jv = idx - n * vpr;
+              wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (idx < total && n < ncw && jv * 4 < kw)
+                wv[u] = *reinterpret_cast<const float4*>(wt + (long)(n0 + n) * g.wrs + k0 + jv * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int idx = base + tid + u * NT;
+              if (idx < total) {
+                const int n = idx / vpr, jv = idx - n * vpr;
+                T* d = Ws + n * RS + jv * 4;
+                d[0] = (T)wv[u].x; d[1] = (T)wv[u].y; d[2] = (T)wv[u].z; d[3] = (T)wv[u].w;
+              }
+            }
           }
         } else if (g.wrs == 1 && (ncw & 3) == 0 && (g.wcs & 3) == 0) {
-          const int vpc = nrows >> 2;  // float4 per contraction column
-          for (int idx = tid; idx < kwp * vpc; idx += NT) {
-            const int j = idx / vpc, nv = idx - j * vpc;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < kw && nv * 4 < ncw) v = *reinterpret_cast<const float4*>(wt + (long)(k0 + j) * g.wcs + n0 + nv * 4);
-            T* d = Ws + (nv * 4) * RS + j;
-            d[0] = (T)v.x; d[RS] = (T)v.y; d[2 * RS] = (T)v.z; d[3 * RS] = (T)v.w;
+          // transposed source (backward-data): w[(k0+j)*wcs + n].  One float4 = 4 output rows of one contraction
+          // column j.  Lanes run over j (NOT over n): the four 2-byte LDS stores of a lane then land in one row
+          // each with consecutive lanes on consecutive columns -> conflict-free; with lanes over n every store
+          // of a wave would hit 2 banks (row pitch 272 B, 4-row stride).  The 16-byte global reads are L2 hits.
+          const int vpc = nrows >> 2;  // float4 groups of rows
+          const int total = kwp * vpc;
+          for (int base = 0; base < total; base += NT * 8) {
+            float4 wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int idx = base + tid + u * NT;
+              const int nv = idx / kwp, j = idx - nv * kwp;
+              wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (idx < total && j < kw && nv * 4 < ncw)
+                wv[u] = *reinterpret_cast<const float4*>(wt + (long)(k0 + j) * g.wcs + n0 + nv * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int idx = base + tid + u * NT;
+              if (idx < total) {
+                const int nv = idx / kwp, j = idx - nv * kwp;
+                T* d = Ws + (nv * 4) * RS + j;
+                d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
+              }
+            }
           }
         } else {
           for (int idx = tid; idx < nrows * kwp; idx += NT) {
@@ -163,7 +239,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       }
       __syncthreads();  // coefficients (and weights) visible
 
-      // ---- stage the A tile: Xs[row][j] = A(p0+row, k0+j), zero beyond kw / P / image borders
+      // ---- 3. normalise the loaded vectors and write the A tile: Xs[row][j] = A(p0+row, k0+j), zero beyond kw / P / borders
       if (g.mode == A_STEM) {
         const float* src32 = reinterpret_cast<const float*>(g.a0);
         const T* srcT = reinterpret_cast<const T*>(g.a0);
@@ -184,68 +260,60 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
           Xs[row * RS + j] = (T)v;
         }
       } else {
-        const int nvec = (kwp + 7) >> 3;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const T* a0 = reinterpret_cast<const T*>(g.a0);
-        const T* a1 = reinterpret_cast<const T*>(g.a1);
-        for (int idx = tid; idx < BM * nvec; idx += NT) {
-          const int row = idx / nvec, cv = idx - row * nvec;
-          const long p = p0 + row;
-          float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
-          long q = -1;
-          if (p < g.P) {
-            if (g.mode == A_PW) {
-              q = p;
-            } else {
-              const long b = p / HWo; const long rem = p - b * HWo;
-              const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-              const int iy = oy * g.stride + g.tap_sign * (ky - 1) * g.dil;
-              const int ix = ox * g.stride + g.tap_sign * (kx - 1) * g.dil;
-              if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+        for (int i = 0; i < MAXV; ++i) {
+          const int idx = tid + i * NT;
+          if (idx < BM * nvec) {
+            int row, cv;
+            if (pow_map) { row = row0 + i * rstep; cv = cv0; } else { row = idx / nvec; cv = idx - row * nvec; }
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            if (vok[i]) {
+              float x0[8];
+              V8<T>::unpack(r0[i], x0);
+              const float* cc = Cs + cv * 8;
+              if (HAS_A1) {
+                float x1[8];
+                V8<T>::unpack(r1[HAS_A1 ? i : 0], x1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                  v[j] = cc[j] * (x0[j] - cc[2 * KC + j]) + cc[KC + j] * (x1[j] - cc[3 * KC + j]);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (x0[j] - cc[KC + j]) * cc[j] + cc[2 * KC + j];
+              }
+              if (g.a_relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+              }
+              if (cv * 8 + 8 > kw) {   // only the last, partial vector of a chunk
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (cv * 8 + j >= kw) v[j] = 0.f;
+              }
             }
+            V8<T>::store(Xs + row * RS + cv * 8, v);
           }
-          if (q >= 0 && cv * 8 < kw) {
-            float x0[8];
-            V8<T>::load(a0 + q * g.lda0 + k0 + cv * 8, x0);
-            const float* cc = Cs + cv * 8;
-            if (a1) {
-              float x1[8];
-              V8<T>::load(a1 + q * g.lda1 + k0 + cv * 8, x1);
-#pragma unroll
-              for (int j = 0; j < 8; ++j)
-                v[j] = cc[j] * (x0[j] - cc[2 * KC + j]) + cc[KC + j] * (x1[j] - cc[3 * KC + j]);
-            } else {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = (x0[j] - cc[KC + j]) * cc[j] + cc[2 * KC + j];
-            }
-            if (g.a_relu) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) if (cv * 8 + j >= kw) v[j] = 0.f;
-          }
-          V8<T>::store(Xs + row * RS + cv * 8, v);
         }
       }
       __syncthreads();
 
       // ---- MFMA: D[n][p] += W[n][k] * A[p][k]
-      const T* xrow0 = Xs + (wave * 32 + fr) * RS;
-      const T* xrow1 = xrow0 + 16 * RS;
-      const T* wrow = Ws + fr * RS;
-      const int nks = kwp / KSTEP;
-      for (int ks = 0; ks < nks; ++ks) {
-        const typename M::Frag x0 = M::ld(xrow0, ks, fq);
-        const typename M::Frag x1 = M::ld(xrow1, ks, fq);
+      if (nfr > 0) {
+        const T* xrow = Xs + (wm * 64 + fr) * RS;
+        const T* wrow = Ws + (wn * 64 + fr) * RS;
+        const int nks = kwp / KSTEP;
+        for (int ks = 0; ks < nks; ++ks) {
+          typename M::Frag xf[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (i < nfr) {
-            const typename M::Frag wf = M::ld(wrow + i * 16 * RS, ks, fq);
-            acc[0][i] = M::mma(wf, x0, acc[0][i]);
-            acc[1][i] = M::mma(wf, x1, acc[1][i]);
+          for (int m = 0; m < 4; ++m) xf[m] = M::ld(xrow + m * 16 * RS, ks, fq);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < nfr) {
+              const typename M::Frag wf = M::ld(wrow + i * 16 * RS, ks, fq);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) acc[m][i] = M::mma(wf, xf[m], acc[m][i]);
+            }
           }
         }
       }
@@ -255,13 +323,13 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     T* yo = reinterpret_cast<T*>(g.y);
     const T* xm = reinterpret_cast<const T*>(g.xm);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 4; ++i) {
       if (i < nfr) {
-        const int n = n0 + i * 16 + fq * 4;
+        const int n = n0 + wn * 64 + i * 16 + fq * 4;
         double d1[4] = {0.0, 0.0, 0.0, 0.0}, d2[4] = {0.0, 0.0, 0.0, 0.0};  // f32 parity path only
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const long p = p0 + wave * 32 + m * 16 + fr;
+        for (int m = 0; m < 4; ++m) {
+          const long p = p0 + wm * 64 + m * 16 + fr;
           if (p < g.P && n < g.ND) {
             float v[4];
 #pragma unroll
@@ -303,8 +371,8 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int mk = 1; mk <= 8; mk <<= 1) { a += __shfl_xor(a, mk, 64); b += __shfl_xor(b, mk, 64); }
             if (fr == 0) {
-              atomicAdd(&Sacc[(i * 16 + fq * 4 + r) * 2 + 0], a);
-              atomicAdd(&Sacc[(i * 16 + fq * 4 + r) * 2 + 1], b);
+              atomicAdd(&Sacc[(wn * 64 + i * 16 + fq * 4 + r) * 2 + 0], a);
+              atomicAdd(&Sacc[(wn * 64 + i * 16 + fq * 4 + r) * 2 + 1], b);
             }
           }
         }
@@ -321,24 +389,24 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     if (EXACT_STATS) {
       if (tid < ncw) { a = Sacc[tid * 2 + 0]; b = Sacc[tid * 2 + 1]; }
     } else {
-      // bf16 path: f32 partials per lane, 16-lane reduce, 4-wave reduce through LDS
-      float* red = reinterpret_cast<float*>(smem);  // [4][2][NCH], aliases Xs
+      // bf16 path: f32 partials per lane, 16-lane reduce, then the two pixel-halves (wm) through LDS
+      float* red = reinterpret_cast<float*>(smem);  // [2 (wm)][2][NCH], aliases Xs
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float u = st1[i][r], w = st2[i][r];
 #pragma unroll
           for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w += __shfl_xor(w, mk, 64); }
           if (fr == 0) {
-            red[(wave * 2 + 0) * NCH + i * 16 + fq * 4 + r] = u;
-            red[(wave * 2 + 1) * NCH + i * 16 + fq * 4 + r] = w;
+            red[(wm * 2 + 0) * NCH + wn * 64 + i * 16 + fq * 4 + r] = u;
+            red[(wm * 2 + 1) * NCH + wn * 64 + i * 16 + fq * 4 + r] = w;
           }
         }
       __syncthreads();
       if (tid < ncw) {
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) { a += red[(wv * 2 + 0) * NCH + tid]; b += red[(wv * 2 + 1) * NCH + tid]; }
+        for (int wv = 0; wv < 2; ++wv) { a += red[(wv * 2 + 0) * NCH + tid]; b += red[(wv * 2 + 1) * NCH + tid]; }
       }
     }
     if (tid < ncw) {
@@ -356,6 +424,23 @@ template <typename T> size_t smem_bytes() {
   return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 4 * Mma<T>::KC * sizeof(float) + NCH * 2 * sizeof(double);
 }
 
+template <typename T, bool HAS_A1>
+void launch_one(const GemmArgs& g, int grid, hipStream_t stream) {
+  static bool attr = false;  // raise the dynamic-LDS limit once per instantiation
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<T, HAS_A1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<T>());
+    attr = true;
+  }
+  hipLaunchKernelGGL((convgemm_kernel<T, HAS_A1>), dim3(grid), dim3(NT), smem_bytes<T>(), stream, g);
+}
+
+void launch_inst(const GemmArgs& g, int dtype, int grid, hipStream_t stream) {
+  const bool a1 = g.a1 != nullptr;
+  if (dtype == TSS_BF16) { if (a1) launch_one<bf16_t, true>(g, grid, stream); else launch_one<bf16_t, false>(g, grid, stream); }
+  else { if (a1) launch_one<float, true>(g, grid, stream); else launch_one<float, false>(g, grid, stream); }
+}
+
 int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
   if (g.P <= 0) return TSS_OK;
   const int nchunks = (g.ND + NCH - 1) / NCH;
@@ -368,23 +453,7 @@ int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg
   const int grid = 8 * nchunks * (int)gs;
   const double flops = 2.0 * (double)g.P * g.KD * g.ntaps * g.ND;
   tss::ProfScope prof(kernel_id, stream, alg_bytes, flops);
-  if (dtype == TSS_BF16) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<bf16_t>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<bf16_t>());
-      attr = true;
-    }
-    hipLaunchKernelGGL(convgemm_kernel<bf16_t>, dim3(grid), dim3(NT), smem_bytes<bf16_t>(), stream, g);
-  } else {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<float>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<float>());
-      attr = true;
-    }
-    hipLaunchKernelGGL(convgemm_kernel<float>, dim3(grid), dim3(NT), smem_bytes<float>(), stream, g);
-  }
+  launch_inst(g, dtype, grid, stream);
   return tss::check_last("convgemm");
 }
 

@@ -338,6 +338,361 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* 
   dw[i] += (s0 + s1) + (s2 + s3);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Strip kernels: one lane owns 8 channels of FOUR consecutive pixels of a row.  The 3 x NCOL input window of a
+// strip is loaded once (NCOL = 3*S + 2*D + 1 columns: 6 / 9 / 12 for the hot path's (stride, dilation) pairs)
+// and every loaded vector is normalised once, instead of 9 loads + 9 normalisations per pixel: 2-2.4x fewer load
+// instructions and 6-12 independent 16-byte loads in flight per lane.  (S, D) are template parameters so the
+// window -> (pixel, tap) scatter is resolved at compile time.
+constexpr int SW = 4;
+
+template <typename T, int S, int D>
+__global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
+  typedef typename StatAcc<T>::type A;
+  constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) float wl[9 * 768];  // [tap][C]
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* y = reinterpret_cast<T*>(g.y);
+  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+
+  float mu[8], sc[8], sh[8];
+  A s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
+  if (active && g.xs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
+  }
+  __syncthreads();
+  const int nstrip = (g.Wout + SW - 1) / SW;
+  const long U = (long)g.B * g.Hout * nstrip;
+  const long ntiles = (U + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long u = (long)tile * g.NPL + pl;
+    if (!active || u >= U) continue;
+    const int xs = (int)(u % nstrip);
+    const long t2 = u / nstrip;
+    const int oy = (int)(t2 % g.Hout);
+    const long b = t2 / g.Hout;
+    const int x0 = xs * SW;
+    float acc[SW][8];
+#pragma unroll
+    for (int i = 0; i < SW; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * S + (ky - 1) * D;
+      const bool vy = iy >= 0 && iy < g.Hin;
+      const T* row = x + ((b * g.Hin + (vy ? iy : 0)) * (long)g.Win) * g.ldx + c0;
+      typename V8<T>::Raw raw[NCOL];
+      bool ok[NCOL];
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        const int ix = x0 * S - D + c;
+        ok[c] = vy && ix >= 0 && ix < g.Win;
+        raw[c] = V8<T>::load_raw(row + (long)(ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix)) * g.ldx);
+      }
+      float wv[3][8];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0 + 4);
+        wv[kx][0] = w0.x; wv[kx][1] = w0.y; wv[kx][2] = w0.z; wv[kx][3] = w0.w;
+        wv[kx][4] = w1.x; wv[kx][5] = w1.y; wv[kx][6] = w1.z; wv[kx][7] = w1.w;
+      }
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        float v[8];
+        V8<T>::unpack(raw[c], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = (v[j] - mu[j]) * sc[j] + sh[j];
+          if (g.x_relu) a = a > 0.f ? a : 0.f;
+          v[j] = ok[c] ? a : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if (i * S + kx * D == c) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[i][j] += v[j] * wv[kx][j];
+            }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SW; ++i) {
+      if (x0 + i < g.Wout) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[i][j] = V8<T>::round(acc[i][j]);
+          s1[j] += (A)acc[i][j];
+          s2[j] += (A)acc[i][j] * (A)acc[i][j];
+        }
+        V8<T>::store(y + ((b * g.Hout + oy) * (long)g.Wout + x0 + i) * g.ldy + c0, acc[i]);
+      }
+    }
+  }
+  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+}
+
+template <typename T, int S, int D>
+__global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArgs g) {
+  constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
+  __shared__ float sdw[768 * 9];
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const T* x = reinterpret_cast<const T*>(g.x);
+
+  for (int i = tid; i < g.C * 9; i += blockDim.x) sdw[i] = 0.f;
+  float accw[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) accw[t][j] = 0.f;
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (g.ga) ca[j] = g.ga[c0 + j];
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
+      if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
+    }
+  }
+  const int nstrip = (g.Wout + SW - 1) / SW;
+  const long U = (long)g.B * g.Hout * nstrip;
+  const long ntiles = (U + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long u = (long)tile * g.NPL + pl;
+    if (!active || u >= U) continue;
+    const int xs = (int)(u % nstrip);
+    const long t2 = u / nstrip;
+    const int oy = (int)(t2 % g.Hout);
+    const long b = t2 / g.Hout;
+    const int x0 = xs * SW;
+    float gv[SW][8];
+#pragma unroll
+    for (int i = 0; i < SW; ++i) {
+      const bool in = x0 + i < g.Wout;
+      const long q = (b * g.Hout + oy) * (long)g.Wout + (in ? x0 + i : x0);
+      float ev[8];
+      V8<T>::load(e + q * g.lde + c0, ev);
+      if (yr) {
+        float yv[8];
+        V8<T>::load(yr + q * g.ldyr + c0, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[i][j] = in ? ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j]) : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[i][j] = in ? ca[j] * ev[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * S + (ky - 1) * D;
+      const bool vy = iy >= 0 && iy < g.Hin;
+      const T* row = x + ((b * g.Hin + (vy ? iy : 0)) * (long)g.Win) * g.ldx + c0;
+      typename V8<T>::Raw raw[NCOL];
+      bool ok[NCOL];
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        const int ix = x0 * S - D + c;
+        ok[c] = vy && ix >= 0 && ix < g.Win;
+        raw[c] = V8<T>::load_raw(row + (long)(ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix)) * g.ldx);
+      }
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        float v[8];
+        V8<T>::unpack(raw[c], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = (v[j] - mu[j]) * sc[j] + sh[j];
+          if (g.x_relu) a = a > 0.f ? a : 0.f;
+          v[j] = ok[c] ? a : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx)
+            if (i * S + kx * D == c) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) accw[ky * 3 + kx][j] += gv[i][j] * v[j];
+            }
+      }
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(c0 + j) * 9 + t], accw[t][j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < g.C * 9; i += blockDim.x) {
+    g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
+    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.ws[(long)r * g.C * 9 + i] = 0.f;
+  }
+}
+
+// backward-data on strips of 4 INPUT pixels.  Stride 1: the flipped-tap window of g = BN'(e, y), 2*D + 4 columns.
+// Stride 2 (D = 1): only output rows/columns of matching parity contribute: <= 2 rows x 3 columns.
+template <typename T, int S, int D>
+__global__ __launch_bounds__(NT_MAX) void dw_bwd_data_strip_kernel(const DwArgs g) {
+  typedef typename StatAcc<T>::type A;
+  constexpr int NCOL = (S == 1) ? (SW + 2 * D) : 3;
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) float wl[9 * 768];
+  const int tid = threadIdx.x;
+  const int cg = tid % g.CV, pl = tid / g.CV;
+  const bool active = pl < g.NPL;
+  const int c0 = cg * 8;
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* out = reinterpret_cast<T*>(g.y);
+  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+
+  float ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
+  A s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = 0; s2[j] = 0; ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (g.ga) ca[j] = g.ga[c0 + j];
+      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
+      if (g.xm) mu[j] = g.xm[c0 + j];
+      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
+    }
+  }
+  __syncthreads();
+  const int nstrip = (g.Win + SW - 1) / SW;
+  const long U = (long)g.B * g.Hin * nstrip;
+  const long ntiles = (U + g.NPL - 1) / g.NPL;
+  const TileRange tr = xcd_tiles((int)ntiles);
+  for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
+    const long u = (long)tile * g.NPL + pl;
+    if (!active || u >= U) continue;
+    const int xs = (int)(u % nstrip);
+    const long t2 = u / nstrip;
+    const int iy = (int)(t2 % g.Hin);
+    const long b = t2 / g.Hin;
+    const int x0 = xs * SW;
+    float acc[SW][8];
+#pragma unroll
+    for (int i = 0; i < SW; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ny = iy - (ky - 1) * D;  // = oy * S
+      const int oy = ny / S;
+      const bool vy = ny >= 0 && oy * S == ny && oy < g.Hout;
+      if (!vy) continue;                 // parity / border: the whole row contributes nothing
+      const long rowq = (b * g.Hout + oy) * (long)g.Wout;
+      // first output column of the window: stride 1: x0 - D; stride 2: x0 / 2 (x0 is a multiple of 4)
+      const int oc0 = (S == 1) ? (x0 - D) : (x0 / 2);
+      typename V8<T>::Raw re[NCOL], ry[NCOL];
+      bool ok[NCOL];
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        const int ox = oc0 + c;
+        ok[c] = ox >= 0 && ox < g.Wout;
+        const long q = rowq + (ox < 0 ? 0 : (ox >= g.Wout ? g.Wout - 1 : ox));
+        re[c] = V8<T>::load_raw(e + q * g.lde + c0);
+        if (yr) ry[c] = V8<T>::load_raw(yr + q * g.ldyr + c0);
+      }
+      float wv[3][8];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0);
+        const float4 w1 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0 + 4);
+        wv[kx][0] = w0.x; wv[kx][1] = w0.y; wv[kx][2] = w0.z; wv[kx][3] = w0.w;
+        wv[kx][4] = w1.x; wv[kx][5] = w1.y; wv[kx][6] = w1.z; wv[kx][7] = w1.w;
+      }
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) {
+        float gvv[8];
+        V8<T>::unpack(re[c], gvv);
+        if (yr) {
+          float yv[8];
+          V8<T>::unpack(ry[c], yv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * (gvv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]) : 0.f;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * gvv[j] : 0.f;
+        }
+        // input pixel i of the strip sees output column (oc0 + c) through tap kx when
+        //   stride 1:  x0 + i - (kx-1)*D == x0 - D + c      <=>  i + (2 - kx) * D == c   (kx counted from the flip)
+        //   stride 2:  x0 + i - (kx-1)   == 2 * (x0/2 + c)  <=>  kx == i + 1 - 2c
+#pragma unroll
+        for (int i = 0; i < SW; ++i)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bool hit = (S == 1) ? (i + (2 - kx) * D == c) : (kx == i + 1 - 2 * c);
+            if (hit) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[i][j] += gvv[j] * wv[kx][j];
+            }
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < SW; ++i) {
+      if (x0 + i < g.Win) {
+        const long p = (b * g.Hin + iy) * (long)g.Win + x0 + i;
+        if (g.x) {
+          float xv[8];
+          V8<T>::load(x + p * g.ldx + c0, xv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xc = xv[j] - mu[j];
+            if (g.x_relu && !(xc * sc[j] + sh[j] > 0.f)) acc[i][j] = 0.f;
+            acc[i][j] = V8<T>::round(acc[i][j]);
+            s1[j] += (A)acc[i][j];
+            s2[j] += (A)acc[i][j] * (A)xc;
+          }
+        }
+        V8<T>::store(out + p * g.ldy + c0, acc[i]);
+      }
+    }
+  }
+  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+}
+
+template <typename T>
+bool launch_strip(int which, const DwArgs& g, int grid, int threads, hipStream_t st) {
+#define TSS_DW_CASE(SS, DD)                                                                                         \
+  if (g.stride == SS && g.dil == DD) {                                                                              \
+    if (which == 0) hipLaunchKernelGGL((dw_fwd_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g);        \
+    else if (which == 1) hipLaunchKernelGGL((dw_bwd_data_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g); \
+    else hipLaunchKernelGGL((dw_bwd_weight_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g);            \
+    return true;                                                                                                    \
+  }
+  TSS_DW_CASE(1, 1)
+  TSS_DW_CASE(2, 1)
+  TSS_DW_CASE(1, 4)
+#undef TSS_DW_CASE
+  return false;
+}
+
 int geometry(DwArgs& g, int* threads) {
   if (g.C <= 0 || (g.C % 8) != 0 || g.C > 768) return TSS_ERR_SHAPE;
   g.CV = g.C / 8;
@@ -369,11 +724,17 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float
   if (rc) return rc;
   const long P = (long)B * g.Hout * g.Wout;
   if (P == 0) return TSS_OK;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+  const long U = (long)B * g.Hout * ((g.Wout + SW - 1) / SW);
   tss::ProfScope prof(TSS_K_DWCONV_FWD, (hipStream_t)stream,
                       ((double)B * Hin * Win + (double)P) * C * esz(dtype), 18.0 * P * C);
-  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+  const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(0, g, sgrid, threads, (hipStream_t)stream)
+                                       : launch_strip<float>(0, g, sgrid, threads, (hipStream_t)stream);
+  if (!strip) {
+    const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+    if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(dw_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  }
   return tss::check_last("dwconv_fwd");
 }
 
@@ -400,11 +761,17 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   const long P = (long)B * Hin * Win;
   if (P == 0) return TSS_OK;
   const long Po = (long)B * g.Hout * g.Wout;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)Po * (yraw ? 2 : 1) + (double)P * (xraw ? 2 : 1)) * C * esz(dtype), 18.0 * Po * C);
-  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  const long U = (long)B * Hin * ((Win + SW - 1) / SW);
+  const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+  const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(1, g, sgrid, threads, (hipStream_t)stream)
+                                       : launch_strip<float>(1, g, sgrid, threads, (hipStream_t)stream);
+  if (!strip) {
+    const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+    if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  }
   return tss::check_last("dwconv_bwd_data");
 }
 
@@ -426,11 +793,17 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
   if (rc) return rc;
   const long P = (long)B * g.Hout * g.Wout;
   if (P == 0) return TSS_OK;
-  const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   tss::ProfScope prof(TSS_K_DWCONV_BWD_WEIGHT, (hipStream_t)stream,
                       ((double)P * (yraw ? 2 : 1) + (double)B * Hin * Win) * C * esz(dtype), 18.0 * P * C);
-  if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  const long U = (long)B * g.Hout * ((g.Wout + SW - 1) / SW);
+  const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+  const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(2, g, sgrid, threads, (hipStream_t)stream)
+                                       : launch_strip<float>(2, g, sgrid, threads, (hipStream_t)stream);
+  if (!strip) {
+    const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+    if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
+  }
   hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
   return tss::check_last("dwconv_bwd_weight");
 }

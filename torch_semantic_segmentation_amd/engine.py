@@ -87,7 +87,8 @@ def setup_distributed(enable=True, local_rank=None, backend=None):
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ     # under torch.distributed.run, even with 1 rank
+    if (world > 1 or launched) and not dist.is_initialized():
         dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'), init_method='env://')
     if dist.is_initialized():
         return dist.get_world_size(), dist.get_rank(), local_rank
@@ -101,7 +102,7 @@ def shard_batch(n_items, world_size, rank):
 
 def allreduce_mean_(flat, world_size, group=None):
     """ONE collective per step over the flat gradient buffer: sum here, the 1/world factor is folded into AdamW."""
-    if world_size > 1:
+    if world_size > 1 or (dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
@@ -135,7 +136,7 @@ class Trainer:
         return loss
 
     def _reduce_and_step(self):
-        if self.world_size > 1:
+        if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
             if self.flat:
                 allreduce_mean_(self.optimizer.flat_grad, self.world_size)
             else:
