@@ -114,6 +114,7 @@ int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, l
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* x_nchw, int x_is_f32, float* dw,
+                           float* ws /* [tss_stat_slabs()][N*28] f32 workspace, may be NULL (slower path) */,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream);
 
 /* ---- depthwise 3x3 convolution, padding = dilation, weight [C][3][3] --------------------------------

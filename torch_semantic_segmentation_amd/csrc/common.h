@@ -94,6 +94,12 @@ template <> struct V4<bf16_t> {
 
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 
+// Branch-free "ReLU and/or zero": clamp(a, lo, hi) as ONE v_med3_f32.
+//   relu, valid  : (0, +inf)     identity, valid : (-inf, +inf)     invalid tap / padding : (0, 0)
+// A runtime relu flag written as `flag ? max(a,0) : a` costs a compare + select per element instead.
+__device__ __forceinline__ float clamp3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+#define TSS_INF __builtin_inff()
+
 // ---------------------------------------------------------------------------------------------
 // Reductions.
 __device__ __forceinline__ float wave_sum(float v) {

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
 
   const long HWo = (long)g.Hout * g.Wout;
+  const float relu_lo = g.a_relu ? 0.f : -TSS_INF;  // relu as one v_max with a per-kernel constant
   if (EXACT_STATS) {
     for (int i = tid; i < NCH * 2; i += NT) Sacc[i] = 0.0;  // first use is after the tile loop's barriers
   }
@@ -283,10 +284,8 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (x0[j] - cc[KC + j]) * cc[j] + cc[2 * KC + j];
               }
-              if (g.a_relu) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-              }
+              for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
               if (cv * 8 + 8 > kw) {   // only the last, partial vector of a chunk
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (cv * 8 + j >= kw) v[j] = 0.f;
@@ -461,6 +460,9 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 }  // namespace
 
+bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
+                         int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
+
 extern "C" {
 
 int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
@@ -557,6 +559,11 @@ int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, l
   g.w = w; g.wrs = (long)Cin * 9; g.wcs = 1; g.wts = 0;
   g.y = y; g.ldy = ldy; g.stats = stats;
   const double bytes = (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype)) + (double)g.P * N * esz(dtype);
+  if (dtype == TSS_BF16 && Cin <= 3 && N == 32) {   // performance path: direct VALU kernel (stem.hip)
+    tss::ProfScope prof(TSS_K_STEM_FWD, (hipStream_t)stream, bytes, 2.0 * (double)g.P * g.KD * N);
+    if (tss_stem_direct_fwd(x_nchw, x_is_f32, w, y, ldy, stats, B, Cin, Hin, Win, N, stride, dtype, (hipStream_t)stream))
+      return tss::check_last("stem_direct_fwd");
+  }
   return launch(g, dtype, TSS_K_STEM_FWD, (hipStream_t)stream, bytes);
 }
 

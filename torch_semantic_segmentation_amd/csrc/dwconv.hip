@@ -369,6 +369,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
     for (int j = 0; j < 8; ++j) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
   }
   __syncthreads();
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
   const int nstrip = (g.Wout + SW - 1) / SW;
   const long U = (long)g.B * g.Hout * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
@@ -411,12 +412,9 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
       for (int c = 0; c < NCOL; ++c) {
         float v[8];
         V8<T>::unpack(raw[c], v);
+        const float lo = ok[c] ? relu_lo : 0.f, hi = ok[c] ? TSS_INF : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = (v[j] - mu[j]) * sc[j] + sh[j];
-          if (g.x_relu) a = a > 0.f ? a : 0.f;
-          v[j] = ok[c] ? a : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = clamp3((v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
 #pragma unroll
         for (int i = 0; i < SW; ++i)
 #pragma unroll
@@ -471,6 +469,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
       if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
   const int nstrip = (g.Wout + SW - 1) / SW;
   const long U = (long)g.B * g.Hout * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
@@ -517,12 +516,9 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
       for (int c = 0; c < NCOL; ++c) {
         float v[8];
         V8<T>::unpack(raw[c], v);
+        const float lo = ok[c] ? relu_lo : 0.f, hi = ok[c] ? TSS_INF : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float a = (v[j] - mu[j]) * sc[j] + sh[j];
-          if (g.x_relu) a = a > 0.f ? a : 0.f;
-          v[j] = ok[c] ? a : 0.f;
-        }
+        for (int j = 0; j < 8; ++j) v[j] = clamp3((v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
 #pragma unroll
         for (int i = 0; i < SW; ++i)
 #pragma unroll

@@ -121,6 +121,7 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
     sb[j] = g.sb ? g.sb[c0 + j] : 1.f; mb[j] = (g.sb && g.mb) ? g.mb[c0 + j] : 0.f; bb[j] = (g.sb && g.bb) ? g.bb[c0 + j] : 0.f;
   }
   const long stride = (long)gridDim.x * g.NPL;
+  const float relu_lo = g.relu ? 0.f : -__builtin_inff();
   for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
     float v[8];
     V8<T>::load(a + p * g.lda + c0, v);
@@ -132,10 +133,8 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += (u[j] - mb[j]) * sb[j] + bb[j];
     }
-    if (g.relu) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-    }
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
     V8<T>::store(out + p * g.ldo + c0, v);
   }
 }

@@ -223,11 +223,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
           }
           float xv[8];
           V8<T>::load(x + (q >= 0 ? q : 0) * g.ldx + ch, xv);
+          const float vlo = q >= 0 ? (g.x_relu ? 0.f : -TSS_INF) : 0.f, vhi = q >= 0 ? TSS_INF : 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            float a = (xv[j] - cm[j]) * cs[j] + cb[j];
-            if (g.x_relu) a = a > 0.f ? a : 0.f;
-            v[i][j] = (q >= 0 && ch + j < g.KD) ? a : 0.f;
+            v[i][j] = clamp3((xv[j] - cm[j]) * cs[j] + cb[j], vlo, vhi);
+            if (ch + j >= g.KD) v[i][j] = 0.f;
           }
         }
         put_unit<T>(At, cv * 8, pg, v);
@@ -296,6 +296,10 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 }  // namespace
 
+bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
+                           const float* gce, const float* gmu, const void* x_nchw, int x_is_f32, float* dw, float* ws,
+                           int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
+
 extern "C" {
 
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
@@ -338,7 +342,7 @@ int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
 
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
-                           const void* x_nchw, int x_is_f32, float* dw,
+                           const void* x_nchw, int x_is_f32, float* dw, float* ws,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(Cin >= 1 && Cin * 9 <= TK && N > 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N, TSS_ERR_SHAPE);
@@ -350,8 +354,14 @@ int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
   g.x = x_nchw; g.x_f32 = x_is_f32;
   g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 1; g.dts = 0;
-  return launch(g, dtype, TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream,
-                (double)g.P * N * (yraw ? 2 : 1) * esz(dtype) + (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype)));
+  const double bytes = (double)g.P * N * (yraw ? 2 : 1) * esz(dtype) + (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype));
+  if (dtype == TSS_BF16 && Cin <= 3 && N == 32 && ws) {   // performance path: direct kernel (stem.hip)
+    tss::ProfScope prof(TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)g.P * N * Cin * 9);
+    if (tss_stem_direct_wgrad(e, lde, yraw, ldyr, ga, gb, gce, gmu, x_nchw, x_is_f32, dw, ws, B, Cin, Hin, Win, N, stride,
+                              dtype, (hipStream_t)stream))
+      return tss::check_last("stem_direct_wgrad");
+  }
+  return launch(g, dtype, TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream, bytes);
 }
 
 }  // extern "C"

@@ -337,7 +337,8 @@ class ConvUnitFn(Function):
         need_dx = ctx.needs_input_grad[0]
         e_in = None
         if cfg.kind == 'stem':
-            call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw),
+            ws = torch.empty((N.stat_slabs(), Cout * 28), dtype=torch.float32, device=dev)
+            call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw), ptr(ws),
                  B, Cin, Hin, Win, Cout, s, dt, st)
             if need_dx:
                 raise NotImplementedError('HIP path: gradient with respect to the input image is not implemented')
