@@ -52,6 +52,23 @@ __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double
   }
 }
 
+// [C][9] f32 weights -> LDS [tap][C].  All global loads of a lane are issued before the first LDS store (a plain
+// load/store loop is serialised by the compiler: 20 dependent L2 round trips per block at C = 576).
+__device__ __forceinline__ void stage_weights(float* wl, const float* w, int C, int tid, int nthreads) {
+  const int n = C * 9;
+  constexpr int U = 8;
+  for (int base = 0; base < n; base += nthreads * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = base + tid + u * nthreads; v[u] = i < n ? w[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + tid + u * nthreads;
+      if (i < n) { const int c = i / 9, t = i - c * 9; wl[t * C + c] = v[u]; }
+    }
+  }
+}
+
 // Tap geometry of one pixel, branch-free: clamped source coordinates + validity, so that all nine loads of a
 // window can be issued back to back (no divergent skip between them) and invalid taps are zeroed by a select.
 struct Taps { long off[9]; bool ok[9]; };
@@ -67,7 +84,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
   const int c0 = cg * 8;
   const T* x = reinterpret_cast<const T*>(g.x);
   T* y = reinterpret_cast<T*>(g.y);
-  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+  stage_weights(wl, g.w, g.C, tid, blockDim.x);
 
   float mu[8], sc[8], sh[8];
   A s1[8], s2[8];
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
   T* out = reinterpret_cast<T*>(g.y);
-  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+  stage_weights(wl, g.w, g.C, tid, blockDim.x);
 
   float ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
@@ -323,18 +340,19 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
   // partial dW of this block -> its workspace row; rows nobody owns are zeroed; dw_reduce_kernel sums the rows
   for (int i = tid; i < g.C * 9; i += blockDim.x) {
     g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
-    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.ws[(long)r * g.C * 9 + i] = 0.f;
   }
 }
 
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* dw, int n) {
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int r = 0; r < TSS_STAT_SLABS; r += 4) {
+  int r = 0;
+  for (; r + 4 <= rows; r += 4) {
     s0 += ws[(long)r * n + i]; s1 += ws[(long)(r + 1) * n + i];
     s2 += ws[(long)(r + 2) * n + i]; s3 += ws[(long)(r + 3) * n + i];
   }
+  for (; r < rows; ++r) s0 += ws[(long)r * n + i];
   dw[i] += (s0 + s1) + (s2 + s3);
 }
 
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
   const int c0 = cg * 8;
   const T* x = reinterpret_cast<const T*>(g.x);
   T* y = reinterpret_cast<T*>(g.y);
-  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+  stage_weights(wl, g.w, g.C, tid, blockDim.x);
 
   float mu[8], sc[8], sh[8];
   A s1[8], s2[8];
@@ -540,7 +558,6 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
   __syncthreads();
   for (int i = tid; i < g.C * 9; i += blockDim.x) {
     g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
-    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.ws[(long)r * g.C * 9 + i] = 0.f;
   }
 }
 
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_strip_kernel(const DwArgs 
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
   T* out = reinterpret_cast<T*>(g.y);
-  for (int i = tid; i < g.C * 9; i += blockDim.x) { const int c = i / 9, t = i - c * 9; wl[t * g.C + c] = g.w[i]; }
+  stage_weights(wl, g.w, g.C, tid, blockDim.x);
 
   float ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
@@ -795,12 +812,14 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
   const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(2, g, sgrid, threads, (hipStream_t)stream)
                                        : launch_strip<float>(2, g, sgrid, threads, (hipStream_t)stream);
+  int rows = sgrid;
   if (!strip) {
     const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+    rows = grid;
     if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   }
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
   return tss::check_last("dwconv_bwd_weight");
 }
 

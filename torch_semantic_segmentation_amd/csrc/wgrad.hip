@@ -281,9 +281,13 @@ int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double al
   const int tiles = nchn * nchk * g.ntaps;
   const int PT = dtype == TSS_BF16 ? WMma<bf16_t>::PT : WMma<float>::PT;
   const long nstage = (g.P + PT - 1) / PT;
+  // blocks per output tile: enough to fill the chip, but every block must amortise its fixed cost (LDS clear,
+  // 16 K f32 atomics for a full tile) over at least MIN_STAGES pixel stages
+  constexpr long MIN_STAGES = 4;
   long ns = 1024 / tiles;
   if (ns < 1) ns = 1;
-  if (ns > nstage) ns = nstage;
+  if (ns > (nstage + MIN_STAGES - 1) / MIN_STAGES) ns = (nstage + MIN_STAGES - 1) / MIN_STAGES;
+  if (ns < 1) ns = 1;
   g.nsplit = (int)ns;
   const int grid = tiles * (int)ns;
   tss::ProfScope prof(kernel_id, stream, alg_bytes, 2.0 * (double)g.P * g.ND * g.KD * g.ntaps);
