@@ -160,7 +160,7 @@ def test_flat_adamw_and_graph_replay_match_eager():
     x, y = synthetic_batch(2, 64, 128)
     x, y = x.to(DEV), y.to(DEV)
     results = []
-    for mode in ('torch_adamw', 'flat', 'flat_graph'):
+    for mode in ('torch_adamw', 'flat', 'flat_graph', 'flat_fused_head'):
         m = cases.product_model('fastscnn')
         m.load_state_dict(formula_state(m), strict=True)
         cases.zero_dropout(m)
@@ -169,7 +169,9 @@ def test_flat_adamw_and_graph_replay_match_eager():
             opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
         else:
             opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
-        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=(mode == 'flat_graph'))
+        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=(mode == 'flat_graph'),
+                       fuse_head_loss=(mode == 'flat_fused_head'))
+        assert tr.fuse_head_loss == (mode == 'flat_fused_head')
         losses = [tr.step_async(x, y).item() for _ in range(3)]
         results.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).double().cpu(),
                         m.downsample[0][1].running_var.clone().cpu(), int(m.downsample[0][1].num_batches_tracked)))

@@ -154,3 +154,25 @@ def test_unsupported_shapes_fail_loudly():
         ops.conv_unit(torch.randn(2, 16, 8, 8, device=DEV), nn.Conv2d(16, 16, 3, padding=0, bias=False).to(DEV))
     with pytest.raises(TypeError):
         ops.conv_unit(torch.randn(2, 16, 8, 8, device=DEV).half(), nn.Conv2d(16, 16, 1, bias=False).to(DEV))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 5, 6, 4), 4)])
+def test_fused_upsample_cross_entropy_matches_unfused(shape, scale, dtype):
+    """Fused head+loss == cross_entropy(interpolate(low)) in value and gradient."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(7)
+    B, C, h, w = shape
+    low = (2 * torch.randn(*shape, device=DEV)).to(dtype)
+    target = torch.randint(0, C, (B, h * scale, w * scale), device=DEV)
+    target[torch.rand(B, h * scale, w * scale, device=DEV) < 0.1] = 255
+    a = ops.to_nhwc(low).clone().requires_grad_(True)
+    la = tssa.upsample_cross_entropy(a, target, scale_factor=scale, ignore_index=255)
+    (0.7 * la).backward()
+    b = low.float().clone().requires_grad_(True)
+    lb = F.cross_entropy(F.interpolate(b, scale_factor=scale, mode='bilinear', align_corners=True), target, ignore_index=255)
+    (0.7 * lb).backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert abs(la.item() / lb.item() - 1) < tol
+    assert rel(a.grad, b.grad) < tol

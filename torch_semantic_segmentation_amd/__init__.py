@@ -2,6 +2,6 @@
 HIP kernels (libtss_hip.so, include/tss_hip.h) behind the reference's nn.Module API."""
 from . import models                                         # noqa: F401
 from .models import set_compute_dtype                        # noqa: F401
-from .ops import CrossEntropyLoss, cross_entropy, argmax_confusion  # noqa: F401
+from .ops import CrossEntropyLoss, cross_entropy, argmax_confusion, upsample_cross_entropy  # noqa: F401
 
 __version__ = '0.1.0'

@@ -113,7 +113,7 @@ def dtype_code(dtype):
 
 # ----------------------------------------------------------------------------- profiler helpers
 
-K_COUNT = 31
+K_COUNT = 33
 
 
 def prof_enable(on=True):

@@ -134,6 +134,39 @@ __device__ __forceinline__ TileRange xcd_tiles(int ntiles) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Bilinear (align_corners=True) index arithmetic, identical to torch's upsample_bilinear2d: scale = (in-1)/(out-1)
+// in f32 (0 when out == 1), src = scale*dst, i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1.
+__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+struct Tap { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Tap ac_tap(float scale, int dst, int in) {
+  const float src = scale * (float)dst;
+  Tap t;
+  t.i0 = (int)src;
+  if (t.i0 > in - 1) t.i0 = in - 1;
+  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
+  t.l1 = src - (float)t.i0;
+  t.l0 = 1.f - t.l1;
+  return t;
+}
+// outputs whose taps can include source index i: a conservative window [lo, hi]
+__device__ __forceinline__ void ac_window(float scale, int i, int out, int* lo, int* hi) {
+  if (scale <= 0.f) { *lo = 0; *hi = out - 1; return; }
+  int l = (int)floorf((float)(i - 1) / scale) - 1;
+  int h = (int)ceilf((float)(i + 1) / scale) + 1;
+  *lo = l < 0 ? 0 : l;
+  *hi = h > out - 1 ? out - 1 : h;
+}
+// weight with which output `dst` reads source index i (0 if it does not)
+__device__ __forceinline__ float ac_weight(float scale, int dst, int in, int i) {
+  const Tap t = ac_tap(scale, dst, in);
+  float w = 0.f;
+  if (t.i0 == i) w += t.l0;
+  if (t.i1 == i) w += t.l1;
+  return w;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host side: error mapping + optional per-kernel profiling (HIP events on the launch stream).
 namespace tss {
 

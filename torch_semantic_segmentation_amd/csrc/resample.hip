@@ -11,36 +11,6 @@ namespace {
 
 constexpr int NT = 256;
 
-__device__ __forceinline__ float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
-
-struct Tap { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Tap ac_tap(float scale, int dst, int in) {
-  const float src = scale * (float)dst;
-  Tap t;
-  t.i0 = (int)src;
-  if (t.i0 > in - 1) t.i0 = in - 1;
-  t.i1 = t.i0 + (t.i0 < in - 1 ? 1 : 0);
-  t.l1 = src - (float)t.i0;
-  t.l0 = 1.f - t.l1;
-  return t;
-}
-// outputs whose taps can include source index i: a conservative window [lo, hi]
-__device__ __forceinline__ void ac_window(float scale, int i, int out, int* lo, int* hi) {
-  if (scale <= 0.f) { *lo = 0; *hi = out - 1; return; }
-  int l = (int)floorf((float)(i - 1) / scale) - 1;
-  int h = (int)ceilf((float)(i + 1) / scale) + 1;
-  *lo = l < 0 ? 0 : l;
-  *hi = h > out - 1 ? out - 1 : h;
-}
-// weight with which output `dst` reads source index i (0 if it does not)
-__device__ __forceinline__ float ac_weight(float scale, int dst, int in, int i) {
-  const Tap t = ac_tap(scale, dst, in);
-  float w = 0.f;
-  if (t.i0 == i) w += t.l0;
-  if (t.i1 == i) w += t.l1;
-  return w;
-}
-
 // ---------------------------------------------------------------------------- NHWC <-> NHWC
 template <typename T>
 __global__ __launch_bounds__(NT) void bilinear_nhwc_fwd_kernel(const T* x, long ldx, T* y, long ldy, int B, int Hin,
@@ -494,6 +464,22 @@ int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int
   else
     hipLaunchKernelGGL(copy_nhwc_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, P, C);
   return tss::check_last("copy_nhwc");
+}
+
+int tss_upsample_head_bwd_cols(const float* tmp, void* dlow, long ldl, int B, int N, int h, int w, int W,
+                               int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(N > 0 && ldl >= N && h > 0 && w > 0, TSS_ERR_SHAPE);
+  const long t2 = (long)B * N * h * w;
+  if (t2 == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_UPSAMPLE_HEAD_BWD_COLS, (hipStream_t)stream, (double)B * N * h * W * 4 + (double)t2 * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(upsample_head_bwd_cols_kernel<bf16_t>, dim3(grid_for(t2)), dim3(NT), 0, (hipStream_t)stream,
+                       tmp, (bf16_t*)dlow, ldl, B, N, h, w, W);
+  else
+    hipLaunchKernelGGL(upsample_head_bwd_cols_kernel<float>, dim3(grid_for(t2)), dim3(NT), 0, (hipStream_t)stream,
+                       tmp, (float*)dlow, ldl, B, N, h, w, W);
+  return tss::check_last("upsample_head_bwd_cols");
 }
 
 }  // extern "C"

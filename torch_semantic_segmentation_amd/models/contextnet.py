@@ -120,10 +120,15 @@ class ContextNet(nn.Module):
         self.feature_fusion = FeatureFusionModule((128, 128), 128)
         self.classifier = Classifier(128, out_channels)
 
-    def forward(self, input):
+    logit_scale = 8   # the head's F.interpolate(scale_factor=8) (TSS/models/contextnet.py:74-76)
+
+    def forward_lowres(self, input):
+        """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits."""
         spatial = self.spatial(input)
         context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
         context = self.context(context)
         fusion = self.feature_fusion(context, spatial)
-        classes = self.classifier(fusion)
-        return ops.upsample_logits(classes, scale_factor=8)
+        return self.classifier(fusion)
+
+    def forward(self, input):
+        return ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale)

@@ -128,9 +128,15 @@ class FastSCNN(nn.Module):
         self.fusion = FeatureFusionModule((128, 64), 128, scale_factor=4)
         self.classifier = Classifier(128, out_channels)
 
-    def forward(self, input):
+    logit_scale = 8   # the head's F.interpolate(scale_factor=8) (TSS/models/fastscnn.py:63-64)
+
+    def forward_lowres(self, input):
+        """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits.
+        engine.Trainer feeds this to the fused upsample + cross-entropy operator."""
         downsample = self.downsample(input)
         features = self.features(downsample)
         fusion = self.fusion(features, downsample)
-        classes = self.classifier(fusion)
-        return ops.upsample_logits(classes, scale_factor=8)
+        return self.classifier(fusion)
+
+    def forward(self, input):
+        return ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale)

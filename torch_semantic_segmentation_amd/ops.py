@@ -680,6 +680,56 @@ class CrossEntropyLoss(torch.nn.Module):
         return cross_entropy(input, target, self.ignore_index)
 
 
+class UpsampleCrossEntropyFn(Function):
+    """cross_entropy(F.interpolate(low, scale, bilinear, align_corners=True), target) without the full-res logits."""
+
+    @staticmethod
+    def forward(ctx, low, target, ho, wo, ignore_index):
+        B, C, h, w = low.shape
+        dev = low.device
+        target = target.contiguous()
+        lse = torch.empty((B, ho, wo), dtype=torch.float32, device=dev)
+        t8 = torch.empty((B, ho, wo), dtype=torch.uint8, device=dev)
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(lse), ptr(t8), ptr(acc), ptr(scal[0:1]),
+             ptr(scal[1:2]), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
+        ctx.geom = (B, C, h, w, ho, wo, ld(low))
+        ctx.save_for_backward(low, t8, lse, scal)
+        return scal[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        low, t8, lse, scal = ctx.saved_tensors
+        B, C, h, w, ho, wo, ldl = ctx.geom
+        dev = low.device
+        gout = gout.to(torch.float32).contiguous()
+        dt, st = N.dtype_code(low.dtype), stream()
+        tmp = torch.empty((B * C * h * wo,), dtype=torch.float32, device=dev)
+        call('tss_upsample_ce_bwd_rows', ptr(low), ldl, ptr(t8), ptr(lse), ptr(scal[1:2]), ptr(gout), ptr(tmp),
+             B, C, h, w, ho, wo, dt, st)
+        base = torch.zeros((B, h, w, ldl), dtype=low.dtype, device=dev)   # padded channels must read as zeros
+        dlow = base.permute(0, 3, 1, 2)[:, :C]
+        call('tss_upsample_head_bwd_cols', ptr(tmp), ptr(dlow), ldl, B, C, h, w, wo, dt, st)
+        return dlow, None, None, None, None
+
+
+def upsample_cross_entropy(low, target, scale_factor=None, size=None, ignore_index=-100):
+    """Fused decoder head + loss:
+    F.cross_entropy(F.interpolate(low, scale_factor, mode='bilinear', align_corners=True), target, ignore_index)
+    computed from the low-resolution logits; the full-resolution logits are never materialised."""
+    low = to_nhwc(materialize(low))
+    ho, wo = _out_size(low, size, scale_factor)
+    if wo % 8:
+        raise NotImplementedError('HIP path: logits width must be a multiple of 8, got %d' % wo)
+    if low.shape[1] >= 255:
+        raise NotImplementedError('HIP path: fused head supports fewer than 255 classes')
+    if target.dtype != torch.int64 or tuple(target.shape) != (low.shape[0], ho, wo):
+        raise RuntimeError('target must be int64 of shape (B,H,W) = %s' % ((low.shape[0], ho, wo),))
+    _check_device(target)
+    return UpsampleCrossEntropyFn.apply(low, target, ho, wo, ignore_index)
+
+
 def argmax_confusion(logits, target=None, num_classes=None, ignore_index=255, confusion=None, want_pred=True):
     """argmax over dim 1 (lowest index wins ties) and, with a target, the confusion-matrix update
     (rows = truth, cols = prediction) that create_segmentation_evaluator's metrics need (TSS/engine.py:65-72)."""
