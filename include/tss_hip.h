@@ -57,6 +57,8 @@ enum {
 int tss_version(void);                 /* ABI version of this header */
 const char* tss_last_error(void);      /* text of the last HIP error seen by this library (thread-local) */
 const char* tss_arch(void);            /* "gfx950" */
+#define TSS_OPT_DISABLE_FAST_PATHS 1   /* value 1: bf16 calls use the general kernels only (A/B checks of the lean ones) */
+int tss_set_option(int key, int value);
 
 /* ---- profiler: HIP events around every launch, on the launch stream --------------------------------- */
 int tss_prof_enable(int on);           /* 1: record events for every launch from now on; 0: stop */

@@ -89,6 +89,35 @@ def test_block_bf16_tracks_f32(golden, name):
             assert l2(p.grad.cpu().numpy(), ref) < 0.3, pname   # BN-backward cancellation amplifies bf16 rounding
 
 
+@pytest.mark.parametrize('name', ['fast_pw_act', 'fast_pw_noact', 'fast_bneck_res', 'fast_bneck_s2', 'fast_ds_s2',
+                                  'fast_fusion', 'ctx_pw', 'fast_stem', 'fast_classifier'])
+def test_bf16_lean_kernels_agree_with_general_kernels(name):
+    """The performance path has lean bf16 kernels (pwfast.hip, stem.hip) next to the general ones that the f32 parity
+    tests exercise.  Same bf16 inputs through both: they may differ only by bf16 rounding of intermediates."""
+    from torch_semantic_segmentation_amd import _native as N
+
+    def run(disable):
+        N.call('tss_set_option', 1, int(disable))
+        try:
+            m, xs, out = run_block(name, 'train', torch.bfloat16)
+        finally:
+            N.call('tss_set_option', 1, 0)
+        grads = {k: p.grad.detach().float().cpu().numpy() for k, p in m.named_parameters()}
+        dx = [x.grad.detach().float().cpu().numpy() for x in xs if x.grad is not None]
+        return out.detach().float().cpu().numpy(), dx, grads
+
+    def l2(a, b):
+        return np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-12)
+    o1, dx1, g1 = run(False)
+    o0, dx0, g0 = run(True)
+    assert l2(o1, o0) < 1.5e-2
+    for a, b in zip(dx1, dx0):
+        assert l2(a, b) < 5e-2
+    for k in g0:
+        if g0[k].ndim == 4 and np.linalg.norm(g0[k]) > 1e-2:
+            assert l2(g1[k], g0[k]) < 8e-2, k
+
+
 def test_cpu_tensors_raise():
     m = cases.product_block('fast_pw_act')
     with pytest.raises(RuntimeError, match='HIP path only'):

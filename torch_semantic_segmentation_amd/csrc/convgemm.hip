@@ -64,7 +64,9 @@ struct GemmArgs {
   int gslots;             // tile slots per XCD per channel chunk
 };
 
-template <typename T, bool HAS_A1>
+// MODE (A_PW / A_TAPS / A_STEM) and HAS_A1 (second operand = backward prologue) are template parameters: with them
+// runtime, the dead paths alone cost ~150 spilled SGPRs (v_readlane/v_writelane traffic inside the hot loops).
+template <typename T, bool HAS_A1, int MODE>
 __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
   typedef Mma<T> M;
   constexpr int KC = M::KC, RS = M::RS, KSTEP = M::KSTEP;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       // 48/96-channel ones) cv is fixed per thread and row advances by 256/nvec: one division per chunk, not 16.
       const bool pow_map = (NT % nvec) == 0;
       const int row0 = tid / nvec, cv0 = tid - row0 * nvec, rstep = pow_map ? NT / nvec : 0;
-      if (g.mode != A_STEM) {
+      if (MODE != A_STEM) {
         const int ky = tap / 3, kx = tap - ky * 3;
         const T* a0 = reinterpret_cast<const T*>(g.a0);
         const T* a1 = reinterpret_cast<const T*>(g.a1);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
           const long p = p0 + row;
           long q = -1;
           if (idx < BM * nvec && p < g.P && cv * 8 < kw) {
-            if (g.mode == A_PW) {
+            if (MODE == A_PW) {
               q = p;
             } else {
               const long b = p / HWo; const long rem = p - b * HWo;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       }
 
       // ---- 2. coefficients and (when not resident) weights
-      if (g.mode != A_STEM) {
+      if (MODE != A_STEM) {
         for (int j = tid; j < kw; j += NT) {
           Cs[j] = g.c0 ? g.c0[k0 + j] : 1.f;
           Cs[KC + j] = g.c1 ? g.c1[k0 + j] : 0.f;
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       __syncthreads();  // coefficients (and weights) visible
 
       // ---- 3. normalise the loaded vectors and write the A tile: Xs[row][j] = A(p0+row, k0+j), zero beyond kw / P / borders
-      if (g.mode == A_STEM) {
+      if (MODE == A_STEM) {
         const float* src32 = reinterpret_cast<const float*>(g.a0);
         const T* srcT = reinterpret_cast<const T*>(g.a0);
         for (int idx = tid; idx < BM * kwp; idx += NT) {
@@ -423,21 +425,27 @@ template <typename T> size_t smem_bytes() {
   return (size_t)(BM + NCH) * Mma<T>::RS * sizeof(T) + 4 * Mma<T>::KC * sizeof(float) + NCH * 2 * sizeof(double);
 }
 
-template <typename T, bool HAS_A1>
+template <typename T, bool HAS_A1, int MODE>
 void launch_one(const GemmArgs& g, int grid, hipStream_t stream) {
   static bool attr = false;  // raise the dynamic-LDS limit once per instantiation
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<T, HAS_A1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<T, HAS_A1, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<T>());
     attr = true;
   }
-  hipLaunchKernelGGL((convgemm_kernel<T, HAS_A1>), dim3(grid), dim3(NT), smem_bytes<T>(), stream, g);
+  hipLaunchKernelGGL((convgemm_kernel<T, HAS_A1, MODE>), dim3(grid), dim3(NT), smem_bytes<T>(), stream, g);
+}
+
+template <typename T>
+void launch_typed(const GemmArgs& g, int grid, hipStream_t stream) {
+  const bool a1 = g.a1 != nullptr;
+  if (g.mode == A_PW) { if (a1) launch_one<T, true, A_PW>(g, grid, stream); else launch_one<T, false, A_PW>(g, grid, stream); }
+  else if (g.mode == A_TAPS) { if (a1) launch_one<T, true, A_TAPS>(g, grid, stream); else launch_one<T, false, A_TAPS>(g, grid, stream); }
+  else launch_one<T, false, A_STEM>(g, grid, stream);
 }
 
 void launch_inst(const GemmArgs& g, int dtype, int grid, hipStream_t stream) {
-  const bool a1 = g.a1 != nullptr;
-  if (dtype == TSS_BF16) { if (a1) launch_one<bf16_t, true>(g, grid, stream); else launch_one<bf16_t, false>(g, grid, stream); }
-  else { if (a1) launch_one<float, true>(g, grid, stream); else launch_one<float, false>(g, grid, stream); }
+  if (dtype == TSS_BF16) launch_typed<bf16_t>(g, grid, stream); else launch_typed<float>(g, grid, stream);
 }
 
 int launch(GemmArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
@@ -460,6 +468,14 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 }  // namespace
 
+extern int g_tss_disable_fast;   // pwfast.hip
+bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                    const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
+                    hipStream_t stream);                                                                    // pwfast.hip
+bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
+                         const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
+                         const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                         void* e_in, long ldei, double* bstats, long P, int K, int N, hipStream_t stream);  // pwfast.hip
 bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
                          int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
 
@@ -478,6 +494,11 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
   g.Hout = 1; g.Wout = 1;
   g.w = w; g.wrs = K; g.wcs = 1; g.wts = 0; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 128 && (N % 4) == 0) {   // lean single-chunk kernel (pwfast.hip)
+    tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * 2, 2.0 * (double)P * K * N);
+    if (tss_pwfast_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, bias, y, ldy, stats, P, K, N, (hipStream_t)stream))
+      return tss::check_last("pwfast_fwd");
+  }
   return launch(g, dtype, TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * esz(dtype));
 }
 
@@ -502,6 +523,12 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   const double bytes = (double)P * (N * (yraw ? 2 : 1) + K * (xraw ? 2 : 1)) * esz(dtype);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 128 && (N % 8) == 0 && (K % 4) == 0) {
+    tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
+    if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
+                            e_in, ldei, bstats, P, K, N, (hipStream_t)stream))
+      return tss::check_last("pwfast_bwd_data");
+  }
   return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
 }
 
@@ -546,6 +573,11 @@ int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes);
 }
 
+int tss_set_option(int key, int value) {
+  if (key == TSS_OPT_DISABLE_FAST_PATHS) { g_tss_disable_fast = value; return TSS_OK; }
+  return TSS_ERR_SHAPE;
+}
+
 int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
                     int B, int Cin, int Hin, int Win, int N, int stride, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
@@ -559,7 +591,7 @@ int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, l
   g.w = w; g.wrs = (long)Cin * 9; g.wcs = 1; g.wts = 0;
   g.y = y; g.ldy = ldy; g.stats = stats;
   const double bytes = (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype)) + (double)g.P * N * esz(dtype);
-  if (dtype == TSS_BF16 && Cin <= 3 && N == 32) {   // performance path: direct VALU kernel (stem.hip)
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin <= 3 && N == 32) {   // performance path: direct VALU kernel (stem.hip)
     tss::ProfScope prof(TSS_K_STEM_FWD, (hipStream_t)stream, bytes, 2.0 * (double)g.P * g.KD * N);
     if (tss_stem_direct_fwd(x_nchw, x_is_f32, w, y, ldy, stats, B, Cin, Hin, Win, N, stride, dtype, (hipStream_t)stream))
       return tss::check_last("stem_direct_fwd");

@@ -11,7 +11,7 @@ namespace {
 struct KernelInfo { const char* name; const char* symbol; };
 const KernelInfo kInfo[TSS_K_COUNT] = {
     // symbol = the template instantiation rocprofv3 lists: convgemm_kernel<T, HAS_A1> (false: forward, true: backward-data)
-    {"pwconv_fwd", "convgemm_kernel<fwd>"}, {"pwconv_bwd_data", "convgemm_kernel<bwd>"}, {"pwconv_bwd_weight", "wgrad_kernel"},
+    {"pwconv_fwd", "pwfast_kernel<fwd>|convgemm_kernel"}, {"pwconv_bwd_data", "pwfast_kernel<bwd>|convgemm_kernel"}, {"pwconv_bwd_weight", "wgrad_kernel"},
     {"conv3x3_fwd", "convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
     {"stem3x3_fwd", "stem_fwd_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_kernel"},
     {"dwconv3x3_fwd", "dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_strip_kernel"},

@@ -300,6 +300,7 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 }  // namespace
 
+extern int g_tss_disable_fast;   // pwfast.hip
 bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                            const float* gce, const float* gmu, const void* x_nchw, int x_is_f32, float* dw, float* ws,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
@@ -359,7 +360,7 @@ int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   g.x = x_nchw; g.x_f32 = x_is_f32;
   g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 1; g.dts = 0;
   const double bytes = (double)g.P * N * (yraw ? 2 : 1) * esz(dtype) + (double)B * Cin * Hin * Win * (x_is_f32 ? 4 : esz(dtype));
-  if (dtype == TSS_BF16 && Cin <= 3 && N == 32 && ws) {   // performance path: direct kernel (stem.hip)
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin <= 3 && N == 32 && ws) {   // performance path: direct kernel (stem.hip)
     tss::ProfScope prof(TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)g.P * N * Cin * 9);
     if (tss_stem_direct_wgrad(e, lde, yraw, ldyr, ga, gb, gce, gmu, x_nchw, x_is_f32, dw, ws, B, Cin, Hin, Win, N, stride,
                               dtype, (hipStream_t)stream))
