@@ -264,7 +264,6 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
 
-  for (int i = tid; i < g.C * 9; i += blockDim.x) sdw[i] = 0.f;
   float acc[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -329,31 +328,49 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
       }
     }
   }
-  __syncthreads();
-  if (active) {
+  float* red = sdw;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (active) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(c0 + j) * 9 + t], acc[t][j]);
-  }
-  __syncthreads();
-  // partial dW of this block -> its workspace row; rows nobody owns are zeroed; dw_reduce_kernel sums the rows
-  for (int i = tid; i < g.C * 9; i += blockDim.x) {
-    g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
+      for (int j = 0; j < 8; ++j) red[tid * 8 + j] = acc[t][j];
+    }
+    __syncthreads();
+    for (int c = tid; c < g.C; c += blockDim.x) {
+      const int cgc = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int q = 0; q < g.NPL; ++q) sum += red[(q * g.CV + cgc) * 8 + j];
+      g.ws[(long)blockIdx.x * g.C * 9 + c * 9 + t] = sum;
+    }
   }
 }
 
+// dw[i] += sum over the workspace rows.  16 columns x 16 row-groups per block: every lane keeps 8 independent loads in
+// flight and the whole reduction is ~4 dependent round trips (one thread per column walking 512 rows serially took
+// ~100 us per depthwise layer).
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 4 <= rows; r += 4) {
-    s0 += ws[(long)r * n + i]; s1 += ws[(long)(r + 1) * n + i];
-    s2 += ws[(long)(r + 2) * n + i]; s3 += ws[(long)(r + 3) * n + i];
+  __shared__ float part[16][17];
+  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int rg = threadIdx.x >> 4;
+  float s = 0.f;
+  if (col < n) {
+    for (int r0 = rg; r0 < rows; r0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = r < rows ? ws[(long)r * n + col] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   }
-  for (; r < rows; ++r) s0 += ws[(long)r * n + i];
-  dw[i] += (s0 + s1) + (s2 + s3);
+  part[rg][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && col < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+    dw[col] += t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -471,7 +488,6 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
 
-  for (int i = tid; i < g.C * 9; i += blockDim.x) sdw[i] = 0.f;
   float accw[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -548,16 +564,23 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
       }
     }
   }
-  __syncthreads();
-  if (active) {
+  // block reduction over the pixel lanes, one tap at a time through a [threads][8] LDS slab: no atomics (with 32
+  // channels 64 lanes would add to the same 8 LDS words 9 times over), deterministic
+  float* red = sdw;  // [blockDim][8] floats <= 8 KB, reuses the (still unused) sdw storage
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (active) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(c0 + j) * 9 + t], accw[t][j]);
-  }
-  __syncthreads();
-  for (int i = tid; i < g.C * 9; i += blockDim.x) {
-    g.ws[(long)blockIdx.x * g.C * 9 + i] = sdw[i];
+      for (int j = 0; j < 8; ++j) red[tid * 8 + j] = accw[t][j];
+    }
+    __syncthreads();
+    for (int c = tid; c < g.C; c += blockDim.x) {
+      const int cgc = c >> 3, j = c & 7;
+      float sum = 0.f;
+      for (int q = 0; q < g.NPL; ++q) sum += red[(q * g.CV + cgc) * 8 + j];
+      g.ws[(long)blockIdx.x * g.C * 9 + c * 9 + t] = sum;
+    }
   }
 }
 
@@ -819,7 +842,7 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
     if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   }
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
   return tss::check_last("dwconv_bwd_weight");
 }
 

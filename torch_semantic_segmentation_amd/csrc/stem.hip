@@ -201,24 +201,38 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_kernel(const StemWgradArgs g
     const int j = jg * 4 + k;
     if (j < KP) {
       row[n * KP + j] = acc[k];
-      for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.ws[(long)r * N * KP + n * KP + j] = 0.f;
     }
   }
   (void)K;
 }
 
-__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* ws, float* dw, int K) {
+// dW[n][j] += sum over the `rows` workspace rows (16 columns x 16 row-groups per block, 8 loads in flight per lane)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* ws, float* dw, int K, int rows) {
   constexpr int N = 32, KP = 28;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over N * KP
-  if (i >= N * KP) return;
-  const int n = i / KP, j = i - n * KP;
-  if (j >= K) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (int r = 0; r < TSS_STAT_SLABS; r += 4) {
-    s0 += ws[(long)r * N * KP + i]; s1 += ws[(long)(r + 1) * N * KP + i];
-    s2 += ws[(long)(r + 2) * N * KP + i]; s3 += ws[(long)(r + 3) * N * KP + i];
+  __shared__ float part[16][17];
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15);  // column over N * KP
+  const int rg = threadIdx.x >> 4;
+  float s = 0.f;
+  if (i < N * KP) {
+    for (int r0 = rg; r0 < rows; r0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = r < rows ? ws[(long)r * N * KP + i] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   }
-  dw[n * K + j] += (s0 + s1) + (s2 + s3);
+  part[rg][threadIdx.x & 15] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && i < N * KP) {
+    const int n = i / KP, j = i - n * KP;
+    if (j < K) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+      dw[n * K + j] += t;
+    }
+  }
 }
 
 }  // namespace
@@ -253,6 +267,6 @@ bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr,
   if (grid > TSS_STAT_SLABS) grid = TSS_STAT_SLABS;
   if (x_is_f32) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, float>), dim3((int)grid), dim3(NT), 0, stream, g);
   else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, bf16_t>), dim3((int)grid), dim3(NT), 0, stream, g);
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(4), dim3(256), 0, stream, ws, dw, Cin * 9);
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((32 * 28 + 15) / 16), dim3(256), 0, stream, ws, dw, Cin * 9, (int)grid);
   return true;
 }
