@@ -17,7 +17,8 @@ def rel(a, b):
     return cases.rel_err(a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy())
 
 
-@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 16, 4, 8), 4), ((3, 5, 6, 3), 8)])
+@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 16, 4, 8), 4), ((3, 5, 6, 3), 8),
+                                         ((2, 19, 8, 16), 2), ((1, 8, 3, 8), 1)])
 def test_upsample_head_fwd_bwd(shape, scale):
     from torch_semantic_segmentation_amd import ops
     torch.manual_seed(1)

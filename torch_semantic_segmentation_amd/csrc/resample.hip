@@ -121,9 +121,60 @@ __global__ __launch_bounds__(NT) void bilinear_planar_fwd_kernel(const TI* x, TO
 }
 
 // ---------------------------------------------------------------------------- logits head: NHWC(low) -> NCHW planes
-// One thread = 8 consecutive output x of one (b, class, output row): <= 3 source columns x 2 rows.
+// One thread = 8 consecutive output x of one output row, for a GROUP of 8 classes: the taps are computed once,
+// the <= 3 source columns x 2 rows are read as 16-byte channel vectors (8 classes each), and every class plane
+// gets one 16-byte store.  (Per-class threads re-did the tap arithmetic 19x and issued 2-byte gathers.)
 template <typename T>
 __global__ __launch_bounds__(NT) void upsample_head_fwd_kernel(const T* low, long ldl, T* y, int B, int N, int h, int w,
+                                                               int H, int W) {
+  const int W8 = W / 8;
+  const int NG = (N + 7) / 8;                       // class groups; ldl >= NG*8 (host-checked)
+  const long total = (long)B * NG * H * W8;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xg = (int)(i % W8);
+    long p = i / W8;
+    const int oy = (int)(p % H); p /= H;
+    const int ng = (int)(p % NG);
+    const long b = p / NG;
+    const Tap ty = ac_tap(sy, oy, h);
+    const Tap t0 = ac_tap(sx, xg * 8, w);
+    const int c0 = t0.i0;                           // the 8 outputs touch source columns c0 .. c0+3 at most (host-checked)
+    const T* r0 = low + ((b * h + ty.i0) * (long)w) * ldl + ng * 8;
+    const T* r1 = low + ((b * h + ty.i1) * (long)w) * ldl + ng * 8;
+    float col[4][8];                                // vertically blended source columns, 8 classes each
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int cx = (c0 + k < w) ? c0 + k : w - 1;
+      float a[8], bb[8];
+      V8<T>::load(r0 + (long)cx * ldl, a);
+      V8<T>::load(r1 + (long)cx * ldl, bb);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) col[k][q] = ty.l0 * a[q] + ty.l1 * bb[q];
+    }
+    float o[8][8];                                  // [class][pixel]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const Tap tx = ac_tap(sx, xg * 8 + j, w);
+      const int d0 = tx.i0 - c0, d1 = tx.i1 - c0;   // 0..3
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float v0 = d0 == 0 ? col[0][q] : (d0 == 1 ? col[1][q] : (d0 == 2 ? col[2][q] : col[3][q]));
+        const float v1 = d1 == 0 ? col[0][q] : (d1 == 1 ? col[1][q] : (d1 == 2 ? col[2][q] : col[3][q]));
+        o[q][j] = tx.l0 * v0 + tx.l1 * v1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int n = ng * 8 + q;
+      if (n < N) V8<T>::store(y + ((b * N + n) * (long)H + oy) * W + xg * 8, o[q]);
+    }
+  }
+}
+
+// General fallback (any scale): one thread = 8 consecutive output x of one (b, class, output row), scalar gathers.
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample_head_fwd_generic_kernel(const T* low, long ldl, T* y, int B, int N, int h, int w,
                                                                int H, int W) {
   const int W8 = W / 8;
   const long total = (long)B * N * H * W8;
@@ -375,15 +426,29 @@ int tss_upsample_head_fwd(const void* low, long ldl, void* y, int B, int N, int 
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(N > 0 && ldl >= N && (W % 8) == 0 && h > 0 && w > 0, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(y), TSS_ERR_ALIGN);
-  const long total = (long)B * N * H * (W / 8);
-  if (total == 0) return TSS_OK;
+  if ((long)B * N * H * W == 0) return TSS_OK;
   tss::ProfScope prof(TSS_K_UPSAMPLE_HEAD_FWD, (hipStream_t)stream, ((double)B * N * h * w + (double)B * N * H * W) * esz(dtype), 0);
-  if (dtype == TSS_BF16)
-    hipLaunchKernelGGL(upsample_head_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
-  else
-    hipLaunchKernelGGL(upsample_head_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+  // class-vector kernel: needs the 8 outputs of a lane within 4 source columns (7*scale_x < 2, i.e. >= ~x3.5
+  // upsampling), 16-byte channel vectors (pitch covers whole groups of 8 classes) and an aligned source
+  const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const bool fast = 7.f * sx < 1.99f && (ldl % 8) == 0 && ldl >= (N + 7) / 8 * 8 && tss::aligned16(low);
+  if (fast) {
+    const long total = (long)B * ((N + 7) / 8) * H * (W / 8);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(upsample_head_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                         (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
+    else
+      hipLaunchKernelGGL(upsample_head_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                         (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+  } else {
+    const long total = (long)B * N * H * (W / 8);
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(upsample_head_fwd_generic_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                         (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
+    else
+      hipLaunchKernelGGL(upsample_head_fwd_generic_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                         (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+  }
   return tss::check_last("upsample_head_fwd");
 }
 

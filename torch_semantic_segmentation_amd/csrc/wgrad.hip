@@ -283,7 +283,7 @@ int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double al
   const long nstage = (g.P + PT - 1) / PT;
   // blocks per output tile: enough to fill the chip, but every block must amortise its fixed cost (LDS clear,
   // 16 K f32 atomics for a full tile) over at least MIN_STAGES pixel stages
-  constexpr long MIN_STAGES = 4;
+  constexpr long MIN_STAGES = 8;
   long ns = 1024 / tiles;
   if (ns < 1) ns = 1;
   if (ns > (nstage + MIN_STAGES - 1) / MIN_STAGES) ns = (nstage + MIN_STAGES - 1) / MIN_STAGES;
