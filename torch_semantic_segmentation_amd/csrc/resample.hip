@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void bilinear_planar_fwd_kernel(const TI* x, TO
 // One thread = 8 consecutive output x of one output row, for a GROUP of 8 classes: the taps are computed once,
 // the <= 3 source columns x 2 rows are read as 16-byte channel vectors (8 classes each), and every class plane
 // gets one 16-byte store.  (Per-class threads re-did the tap arithmetic 19x and issued 2-byte gathers.)
-template <typename T>
+template <typename T, int NCOLS>   // NCOLS = source columns the 8 outputs of a lane can touch: 3 (>= x8) or 4 (>= ~x3.5)
 __global__ __launch_bounds__(NT) void upsample_head_fwd_kernel(const T* low, long ldl, T* y, int B, int N, int h, int w,
                                                                int H, int W) {
   const int W8 = W / 8;
@@ -142,9 +142,9 @@ __global__ __launch_bounds__(NT) void upsample_head_fwd_kernel(const T* low, lon
     const int c0 = t0.i0;                           // the 8 outputs touch source columns c0 .. c0+3 at most (host-checked)
     const T* r0 = low + ((b * h + ty.i0) * (long)w) * ldl + ng * 8;
     const T* r1 = low + ((b * h + ty.i1) * (long)w) * ldl + ng * 8;
-    float col[4][8];                                // vertically blended source columns, 8 classes each
+    float col[NCOLS][8];                            // vertically blended source columns, 8 classes each
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NCOLS; ++k) {
       const int cx = (c0 + k < w) ? c0 + k : w - 1;
       float a[8], bb[8];
       V8<T>::load(r0 + (long)cx * ldl, a);
@@ -159,8 +159,9 @@ __global__ __launch_bounds__(NT) void upsample_head_fwd_kernel(const T* low, lon
       const int d0 = tx.i0 - c0, d1 = tx.i1 - c0;   // 0..3
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const float v0 = d0 == 0 ? col[0][q] : (d0 == 1 ? col[1][q] : (d0 == 2 ? col[2][q] : col[3][q]));
-        const float v1 = d1 == 0 ? col[0][q] : (d1 == 1 ? col[1][q] : (d1 == 2 ? col[2][q] : col[3][q]));
+        float v0 = d0 == 0 ? col[0][q] : (d0 == 1 ? col[1][q] : col[2][q]);
+        float v1 = d1 == 0 ? col[0][q] : (d1 == 1 ? col[1][q] : col[2][q]);
+        if (NCOLS == 4) { v0 = d0 == 3 ? col[NCOLS - 1][q] : v0; v1 = d1 == 3 ? col[NCOLS - 1][q] : v1; }
         o[q][j] = tx.l0 * v0 + tx.l1 * v1;
       }
     }
@@ -434,12 +435,18 @@ int tss_upsample_head_fwd(const void* low, long ldl, void* y, int B, int N, int 
   const bool fast = 7.f * sx < 1.99f && (ldl % 8) == 0 && ldl >= (N + 7) / 8 * 8 && tss::aligned16(low);
   if (fast) {
     const long total = (long)B * ((N + 7) / 8) * H * (W / 8);
-    if (dtype == TSS_BF16)
-      hipLaunchKernelGGL(upsample_head_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                         (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
-    else
-      hipLaunchKernelGGL(upsample_head_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                         (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+    const bool three = 7.f * sx < 0.99f;   // x8 and up: i0 advances at most once over a lane's 8 outputs
+    if (dtype == TSS_BF16) {
+      if (three) hipLaunchKernelGGL((upsample_head_fwd_kernel<bf16_t, 3>), dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                                    (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
+      else hipLaunchKernelGGL((upsample_head_fwd_kernel<bf16_t, 4>), dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                              (const bf16_t*)low, ldl, (bf16_t*)y, B, N, h, w, H, W);
+    } else {
+      if (three) hipLaunchKernelGGL((upsample_head_fwd_kernel<float, 3>), dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                                    (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+      else hipLaunchKernelGGL((upsample_head_fwd_kernel<float, 4>), dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                              (const float*)low, ldl, (float*)y, B, N, h, w, H, W);
+    }
   } else {
     const long total = (long)B * N * H * (W / 8);
     if (dtype == TSS_BF16)
