@@ -403,6 +403,12 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
   }
+  // bf16 activations: (x-mu)*s+b is evaluated as x*s + (b-mu*s) (one FMA; the rounding difference is far below bf16)
+  constexpr bool FOLD = sizeof(T) == 2;
+  if (FOLD) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] -= mu[j] * sc[j];
+  }
   __syncthreads();
   const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
   const int nstrip = (g.Wout + SW - 1) / SW;
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
         V8<T>::unpack(raw[c], v);
         const float lo = ok[c] ? relu_lo : 0.f, hi = ok[c] ? TSS_INF : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = clamp3((v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
+        for (int j = 0; j < 8; ++j) v[j] = clamp3(FOLD ? v[j] * sc[j] + sh[j] : (v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
 #pragma unroll
         for (int i = 0; i < SW; ++i)
 #pragma unroll
@@ -503,6 +509,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
       if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
+  constexpr bool FOLD = sizeof(T) == 2;
+  float kd[8];   // folded backward constant: g = ga*e + gb*y + kd
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { kd[j] = -(ca[j] * ce[j]) - cb[j] * cm[j]; if (FOLD) sh[j] -= mu[j] * sc[j]; }
   const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
   const int nstrip = (g.Wout + SW - 1) / SW;
   const long U = (long)g.B * g.Hout * nstrip;
@@ -527,7 +537,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
         float yv[8];
         V8<T>::load(yr + q * g.ldyr + c0, yv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gv[i][j] = in ? ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j]) : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const float gj = FOLD ? ca[j] * ev[j] + (cb[j] * yv[j] + kd[j]) : ca[j] * (ev[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
+          gv[i][j] = in ? gj : 0.f;
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) gv[i][j] = in ? ca[j] * ev[j] : 0.f;
@@ -552,7 +565,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
         V8<T>::unpack(raw[c], v);
         const float lo = ok[c] ? relu_lo : 0.f, hi = ok[c] ? TSS_INF : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = clamp3((v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
+        for (int j = 0; j < 8; ++j) v[j] = clamp3(FOLD ? v[j] * sc[j] + sh[j] : (v[j] - mu[j]) * sc[j] + sh[j], lo, hi);
 #pragma unroll
         for (int i = 0; i < SW; ++i)
 #pragma unroll
@@ -617,6 +630,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_strip_kernel(const DwArgs 
       if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
     }
   }
+  constexpr bool FOLD = sizeof(T) == 2;
+  float kd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) kd[j] = -(ca[j] * ce[j]) - cb[j] * cm[j];
   __syncthreads();
   const int nstrip = (g.Win + SW - 1) / SW;
   const long U = (long)g.B * g.Hin * nstrip;
@@ -670,7 +687,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_strip_kernel(const DwArgs 
           float yv[8];
           V8<T>::unpack(ry[c], yv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * (gvv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]) : 0.f;
+          for (int j = 0; j < 8; ++j) {
+            const float gj = FOLD ? ca[j] * gvv[j] + (cb[j] * yv[j] + kd[j]) : ca[j] * (gvv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
+            gvv[j] = ok[c] ? gj : 0.f;
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * gvv[j] : 0.f;

@@ -83,6 +83,7 @@ template <typename T>
 __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   typedef WMma<T> M;
   constexpr int PT = M::PT, NPG = PT / 4;
+  constexpr bool FOLD = sizeof(T) == 2;   // bf16: BatchNorm constants folded into one FMA per element
   __shared__ __align__(16) unsigned char Gt[TN * ROWB];
   __shared__ __align__(16) unsigned char At[TK * ROWB];
   __shared__ __align__(16) float Cg[4][TN];  // ga, gb, gce, gmu of this N chunk
@@ -154,6 +155,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         ca[j] = Cg[0][cv * 8 + j]; cb[j] = Cg[1][cv * 8 + j]; cc[j] = Cg[2][cv * 8 + j]; cm[j] = Cg[3][cv * 8 + j];
+        if (FOLD) cc[j] = -(ca[j] * cc[j]) - cb[j] * cm[j];   // bf16: g = ga*e + gb*y + folded constant
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -166,7 +168,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
           float yv[8];
           V8<T>::load(yr + pc * g.ldyr + ch, yv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] = ca[j] * (ev[j] - cc[j]) + cb[j] * (yv[j] - cm[j]);
+          for (int j = 0; j < 8; ++j)
+            v[i][j] = FOLD ? ca[j] * ev[j] + (cb[j] * yv[j] + cc[j]) : ca[j] * (ev[j] - cc[j]) + cb[j] * (yv[j] - cm[j]);
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[i][j] = ca[j] * ev[j];
@@ -206,7 +209,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
         float v[4][8];
         float cm[8], cs[8], cb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { cm[j] = Ca[0][cv * 8 + j]; cs[j] = Ca[1][cv * 8 + j]; cb[j] = Ca[2][cv * 8 + j]; }
+        for (int j = 0; j < 8; ++j) {
+          cm[j] = Ca[0][cv * 8 + j]; cs[j] = Ca[1][cv * 8 + j]; cb[j] = Ca[2][cv * 8 + j];
+          if (FOLD) cb[j] -= cm[j] * cs[j];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const long p = p0 + pg * 4 + i;
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
           const float vlo = q >= 0 ? (g.x_relu ? 0.f : -TSS_INF) : 0.f, vhi = q >= 0 ? TSS_INF : 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            v[i][j] = clamp3((xv[j] - cm[j]) * cs[j] + cb[j], vlo, vhi);
+            v[i][j] = clamp3(FOLD ? xv[j] * cs[j] + cb[j] : (xv[j] - cm[j]) * cs[j] + cb[j], vlo, vhi);
             if (ch + j >= g.KD) v[i][j] = 0.f;
           }
         }
