@@ -494,7 +494,7 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
   g.Hout = 1; g.Wout = 1;
   g.w = w; g.wrs = K; g.wcs = 1; g.wts = 0; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 128 && (N % 4) == 0) {   // lean single-chunk kernel (pwfast.hip)
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 768 && (N % 4) == 0) {   // lean bf16 kernels (pwfast.hip)
     tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * 2, 2.0 * (double)P * K * N);
     if (tss_pwfast_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, bias, y, ldy, stats, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_fwd");
@@ -523,7 +523,7 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   const double bytes = (double)P * (N * (yraw ? 2 : 1) + K * (xraw ? 2 : 1)) * esz(dtype);
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 128 && (N % 8) == 0 && (K % 4) == 0) {
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 768 && (N % 8) == 0 && (K % 4) == 0) {
     tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
     if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
                             e_in, ldei, bstats, P, K, N, (hipStream_t)stream))

@@ -314,6 +314,301 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Multi-chunk variant: contraction longer than 128 channels (forward of the 1x1 "project" convs, K = 192..768;
+// backward-data of the "expand" convs, contraction over N = 192..768).  Same tiles and epilogue; the contraction is
+// walked in 128-channel chunks with the accumulators kept in registers, each chunk's weights restaged from L2 and
+// the folded BatchNorm constants of all K channels resident in LDS.
+constexpr int KTOT = 768;
+template <bool BWD>
+__global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Xs = reinterpret_cast<T*>(smem);
+  T* Ws = Xs + BM * RS;
+  float* Ck = reinterpret_cast<float*>(Ws + NCH * RS);   // [3][KTOT]: k0, k1, kadd
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nchunks = (g.N + NCH - 1) / NCH;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nc = slot % nchunks, gslot = slot / nchunks;
+  const long ntiles = (g.P + BM - 1) / BM;
+  const long per = (ntiles + 7) >> 3;
+  const long t_begin = xcd * per + gslot;
+  long t_end = xcd * per + per;
+  if (t_end > ntiles) t_end = ntiles;
+
+  const int n0 = nc * NCH;
+  const int ncw = (g.N - n0 < NCH) ? (g.N - n0) : NCH;
+  const int nrows = ((ncw + 15) >> 4) * 16;
+  int nfr = (ncw - wn * 64 + 15) >> 4;
+  nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
+  const int K = g.K;
+  const int nkc = (K + KMAX - 1) / KMAX;
+  const float relu_lo = g.a_relu ? 0.f : -TSS_INF;
+
+  for (int ch = tid; ch < K; ch += NT) {   // folded constants of every contraction channel, once per block
+    if (BWD) {
+      const float ga = g.c0 ? g.c0[ch] : 1.f, gb = g.c1 ? g.c1[ch] : 0.f;
+      Ck[ch] = ga; Ck[KTOT + ch] = gb;
+      Ck[2 * KTOT + ch] = -(ga * (g.c2 ? g.c2[ch] : 0.f)) - gb * (g.c3 ? g.c3[ch] : 0.f);
+    } else {
+      const float sc = g.c0 ? g.c0[ch] : 1.f;
+      Ck[ch] = sc; Ck[KTOT + ch] = 0.f;
+      Ck[2 * KTOT + ch] = (g.c2 ? g.c2[ch] : 0.f) - (g.c1 ? g.c1[ch] : 0.f) * sc;
+    }
+  }
+
+  float st1[4][4], st2[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
+  const int nlane = n0 + wn * 64 + fq * 4;
+
+  for (long tile = t_begin; tile < t_end; tile += g.gslots) {
+    const long p0 = tile * BM;
+    const bool full = p0 + BM <= g.P;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kc = 0; kc < nkc; ++kc) {
+      const int kb = kc * KMAX;
+      const int kw = (K - kb < KMAX) ? (K - kb) : KMAX;
+      const int kwp = (kw + 31) & ~31;
+      const int nvec = kw >> 3, nvecp = kwp >> 3;
+      const int rpp = NT / nvecp, npass = (BM + rpp - 1) / rpp;
+      const int cv = tid % nvecp, r = tid / nvecp;
+      const bool lane_on = r < rpp, cv_real = cv < nvec;
+      __syncthreads();  // previous chunk's MFMA reads are done (and Ck is visible on the first pass)
+
+      // A-tile loads first (the HBM round trip), then the weight chunk from L2, then normalise + store
+      uint4 ra[8], rb[8];
+      if (lane_on) {
+        const T* pa = g.a0 + p0 * g.lda0 + kb + (cv_real ? cv * 8 : 0);
+        const T* pb = BWD ? g.a1 + p0 * g.lda1 + kb + (cv_real ? cv * 8 : 0) : nullptr;
+        const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          if (ps < npass) {
+            const int row = ps * rpp + r;
+            const bool ok = row < BM && (full || p0 + row < g.P);
+            const int rr = ok ? row : 0;
+            ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
+            if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
+          }
+        }
+      }
+      if (!g.w_trans) {
+        const int vpr = kwp >> 2;
+        const int total = nrows * vpr;
+        for (int base = 0; base < total; base += NT * 8) {
+          float4 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + tid + u * NT;
+            const int n = idx / vpr, jv = idx - n * vpr;
+            wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total && n < ncw && jv * 4 < kw) wv[u] = *reinterpret_cast<const float4*>(g.w + (long)(n0 + n) * K + kb + jv * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + tid + u * NT;
+            if (idx < total) {
+              const int n = idx / vpr, jv = idx - n * vpr;
+              bf16x4 o; o[0] = (T)wv[u].x; o[1] = (T)wv[u].y; o[2] = (T)wv[u].z; o[3] = (T)wv[u].w;
+              *reinterpret_cast<bf16x4*>(Ws + n * RS + jv * 4) = o;
+            }
+          }
+        }
+      } else {
+        const int vpc = nrows >> 2;
+        const int total = kwp * vpc;
+        for (int base = 0; base < total; base += NT * 8) {
+          float4 wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + tid + u * NT;
+            const int nv = idx / kwp, j = idx - nv * kwp;
+            wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total && j < kw && nv * 4 < ncw) wv[u] = *reinterpret_cast<const float4*>(g.w + (long)(kb + j) * g.N + n0 + nv * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int idx = base + tid + u * NT;
+            if (idx < total) {
+              const int nv = idx / kwp, j = idx - nv * kwp;
+              T* d = Ws + (nv * 4) * RS + j;
+              d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
+            }
+          }
+        }
+      }
+      if (lane_on) {
+        float k0[8], k1[8], kadd[8];
+        const int cb = kb + (cv_real ? cv * 8 : 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { k0[j] = Ck[cb + j]; k1[j] = Ck[KTOT + cb + j]; kadd[j] = Ck[2 * KTOT + cb + j]; }
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          if (ps < npass) {
+            const int row = ps * rpp + r;
+            if (row < BM) {
+              const bool ok = cv_real && (full || p0 + row < g.P);
+              const uint32_t* ua = reinterpret_cast<const uint32_t*>(&ra[ps]);
+              const uint32_t* ub = reinterpret_cast<const uint32_t*>(&rb[ps]);
+              float v[8];
+#pragma unroll
+              for (int h = 0; h < 4; ++h) {
+                float lo = bits_lo(ua[h]) * k0[2 * h] + kadd[2 * h];
+                float hi = bits_hi(ua[h]) * k0[2 * h + 1] + kadd[2 * h + 1];
+                if (BWD) { lo += bits_lo(ub[h]) * k1[2 * h]; hi += bits_hi(ub[h]) * k1[2 * h + 1]; }
+                v[2 * h] = lo; v[2 * h + 1] = hi;
+              }
+              if (!BWD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
+              }
+              if (!ok) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+              }
+              V8<T>::store(Xs + row * RS + cv * 8, v);
+            }
+          }
+        }
+      }
+      __syncthreads();
+
+      if (nfr > 0) {
+        const T* xrow = Xs + (wm * 64 + fr) * RS + fq * 8;
+        const T* wrow = Ws + (wn * 64 + fr) * RS + fq * 8;
+        const int nks = kwp >> 5;
+        for (int ks = 0; ks < nks; ++ks) {
+          bf16x8 xf[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < nfr) {
+              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RS + ks * 32);
+#pragma unroll
+              for (int m = 0; m < 4; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+
+    // ---- epilogue (identical to pwfast_kernel)
+    T* yrow = g.y + (p0 + wm * 64 + fr) * g.ldy + nlane;
+    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * 64 + fr) * g.ldxm + nlane : nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < nfr) {
+        const int n = nlane + i * 16;
+        const bool nin = n < g.N;
+        float bs[4] = {0.f, 0.f, 0.f, 0.f}, cmm[4] = {0.f, 0.f, 0.f, 0.f}, cms[4] = {1.f, 1.f, 1.f, 1.f}, cmb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nin) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!BWD && g.bias) bs[q] = g.bias[n + q];
+            if (BWD && g.xm) {
+              cmm[q] = g.mm ? g.mm[n + q] : 0.f;
+              cms[q] = g.ms ? g.ms[n + q] : 1.f;
+              cmb[q] = g.mb ? g.mb[n + q] : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const bool pin = full || (p0 + wm * 64 + m * 16 + fr < g.P);
+          if (pin && nin) {
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q] + bs[q];
+            if (BWD && g.xm) {
+              const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
+              const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
+              if (g.m_relu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (!(xc[q] * cms[q] + cmb[q] > 0.f)) v[q] = 0.f;
+              }
+              bf16x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
+              *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
+            } else {
+              bf16x4 o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+              *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (g.stats) {
+    __syncthreads();
+    const int row = xcd + 8 * gslot, rows_used = 8 * g.gslots;
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float u = st1[i][q], w2 = st2[i][q];
+#pragma unroll
+        for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w2 += __shfl_xor(w2, mk, 64); }
+        if (fr == 0) {
+          red[(wm * 2 + 0) * NCH + wn * 64 + i * 16 + fq * 4 + q] = u;
+          red[(wm * 2 + 1) * NCH + wn * 64 + i * 16 + fq * 4 + q] = w2;
+        }
+      }
+    __syncthreads();
+    if (tid < ncw) {
+      const double a = (double)red[0 * NCH + tid] + (double)red[2 * NCH + tid];
+      const double b = (double)red[1 * NCH + tid] + (double)red[3 * NCH + tid];
+      g.stats[(long)row * 2 * g.N + n0 + tid] = a;
+      g.stats[(long)row * 2 * g.N + g.N + n0 + tid] = b;
+      for (int rr = row + rows_used; rr < TSS_STAT_SLABS; rr += rows_used) {
+        g.stats[(long)rr * 2 * g.N + n0 + tid] = 0.0;
+        g.stats[(long)rr * 2 * g.N + g.N + n0 + tid] = 0.0;
+      }
+    }
+  }
+}
+
+constexpr size_t kSmemMc = (size_t)(BM + NCH) * RS * sizeof(T) + 3 * KTOT * sizeof(float);
+
+template <bool BWD>
+void launch_fast_mc(FastArgs& g, hipStream_t stream) {
+  const int nchunks = (g.N + NCH - 1) / NCH;
+  const long ntiles = (g.P + BM - 1) / BM;
+  long gs = (ntiles + 7) / 8;
+  long cap = 64 / nchunks;
+  if (cap < 1) cap = 1;
+  if (gs > cap) gs = cap;
+  g.gslots = (int)gs;
+  const int grid = 8 * nchunks * (int)gs;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemMc);
+    attr = true;
+  }
+  hipLaunchKernelGGL(pwfast_mc_kernel<BWD>, dim3(grid), dim3(NT), kSmemMc, stream, g);
+}
+
 constexpr size_t kSmem = (size_t)(BM + NCH) * RS * sizeof(T);
 
 template <bool BWD>
@@ -342,12 +637,12 @@ int g_tss_disable_fast = 0;   // tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1): 
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream) {
-  if (g_tss_disable_fast || K > KMAX || (K % 8) != 0 || (N % 4) != 0 || P <= 0) return false;
+  if (g_tss_disable_fast || K > KTOT || (K % 8) != 0 || (N % 4) != 0 || P <= 0) return false;
   FastArgs g = {};
   g.P = P; g.K = K; g.N = N;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
-  launch_fast<false>(g, stream);
+  if (K <= KMAX) launch_fast<false>(g, stream); else launch_fast_mc<false>(g, stream);
   return true;
 }
 
@@ -356,12 +651,12 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, long P, int K, int N, hipStream_t stream) {
-  if (g_tss_disable_fast || !yraw || N > KMAX || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
+  if (g_tss_disable_fast || !yraw || N > KTOT || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
   FastArgs g = {};
   g.P = P; g.K = N; g.N = K;
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  launch_fast<true>(g, stream);
+  if (N <= KMAX) launch_fast<true>(g, stream); else launch_fast_mc<true>(g, stream);
   return true;
 }
