@@ -199,6 +199,8 @@ def main():
     roofline = None
     breakdown = None
     if not args.no_roofline and rank == 0:
+        from torch_semantic_segmentation_amd import ops as _ops
+        _ops.overlap_wgrad = False      # one kernel at a time, so that an event pair times exactly one kernel
         eager = make_trainer(False)
         eager.step_async(x, y)
         torch.cuda.synchronize()

@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch_semantic_segmentation_amd import _native as N, ops
 which, K, Nn, P = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 dev = 'cuda:0'; S = N.stat_slabs()
+for kv in os.environ.get('TSS_OPT', '').split(','):   # e.g. TSS_OPT=2=0 -> tss_set_option(2, 0)
+    if kv:
+        N.call('tss_set_option', int(kv.split('=')[0]), int(kv.split('=')[1]))
 x = torch.randn(P, K, device=dev).bfloat16(); y = torch.empty(P, Nn, device=dev, dtype=torch.bfloat16)
 e = torch.randn(P, Nn, device=dev).bfloat16(); ein = torch.empty(P, K, device=dev, dtype=torch.bfloat16)
 w = torch.randn(Nn, K, device=dev) * 0.1; dw = torch.zeros(Nn, K, device=dev)

@@ -44,6 +44,19 @@ class direct_grads:
         return False
 
 
+# Launch a layer's weight gradient on a side stream, concurrently with its input gradient (ConvUnitFn.backward).
+overlap_wgrad = True
+overlap_max_elems = 48 << 20   # only layers too small to fill the chip on their own (large ones just contend)
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def _aff(link):
     """(mean, scale, bias) device pointers of a pending BatchNorm: a = (x - mean) * scale + bias."""
     if link is None:
@@ -336,6 +349,16 @@ class ConvUnitFn(Function):
             dw = dw_ret = torch.zeros_like(weight)
         need_dx = ctx.needs_input_grad[0]
         e_in = None
+        # backward-weight and backward-data of one layer are independent: the weight gradient goes to a side stream
+        # (fork after the finalize above, join before this function returns, so every tensor it reads is still alive
+        # and a HIP-graph capture sees two parallel branches)
+        main = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if (overlap_wgrad and need_dx and cfg.kind != 'stem'
+                                    and P * (Cin + Cout) <= overlap_max_elems) else None
+        wst = st
+        if side is not None:
+            side.wait_stream(main)
+            wst = side.cuda_stream
         if cfg.kind == 'stem':
             ws = torch.empty((N.stat_slabs(), Cout * 28), dtype=torch.float32, device=dev)
             call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw), ptr(ws),
@@ -346,12 +369,12 @@ class ConvUnitFn(Function):
             xargs = (ptr(x), ld(x), *_aff(il), int(cfg.in_relu))
             deferred_in = il is not None or cfg.in_relu
             if cfg.kind == 'pw':
-                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, st)
+                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
-                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, st)
+                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, wst)
             else:
-                call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, st)
+                call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
             if need_dx:
                 e_in = new_nhwc(B, Cin, Hin, Win, e.dtype, dev)
                 margs = xargs if deferred_in else (None, 0, None, None, None, 0)
@@ -375,6 +398,8 @@ class ConvUnitFn(Function):
             if dbias is None:
                 dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
             call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
+        if side is not None:
+            main.wait_stream(side)
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
 
 
