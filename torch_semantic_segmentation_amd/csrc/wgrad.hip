@@ -15,6 +15,8 @@
 // accumulate onto, exactly like autograd's .grad).
 #include "common.h"
 
+extern int g_tss_disable_fast;   // pwfast.hip
+
 namespace {
 
 constexpr int TN = 128, TK = 128, NT = 256;
@@ -281,6 +283,218 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Lean bf16 kernel for the 1x1 layers (the performance path).  Same contraction and LDS layout as wgrad_kernel, but
+//   * software-pipelined: the 16-byte loads of stage s+1 (e, y, x: one 4-pixel x 8-channel unit of each per thread)
+//     are issued right after stage s went to LDS and land under its MFMAs; the generic kernel exposes two memory
+//     round trips and two barriers per 64 pixels (rocprofv3: ~77 % of its wave cycles are waits);
+//   * the unit of a thread is fixed, so its folded BatchNorm constants stay in registers and its addresses advance by
+//     a constant per stage;
+//   * the four waves are assigned by tile shape: a tile narrower than 5 fragments in n or k is not split along that
+//     axis (those waves would idle) but along the pixel axis instead (each wave takes half of the k-steps);
+//   * PT = 128-pixel stages when both chunk widths are <= 64 channels, so that the staging still uses every thread.
+template <int PT>
+__global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
+  typedef bf16_t T;
+  constexpr int NPG = PT / 4, ROW = PT * 2 + 16, NKS = PT / 32;
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned char* Gt = smem;
+  unsigned char* At = smem + TN * ROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
+  int bid = blockIdx.x;
+  const int split = bid % g.nsplit; bid /= g.nsplit;
+  const int nc = bid % nchn; bid /= nchn;
+  const int kc = bid;
+  const int n0 = nc * TN, k0 = kc * TK;
+  const int ncw = (g.ND - n0 < TN) ? (g.ND - n0) : TN;   // multiples of 8 (host-checked)
+  const int kcw = (g.KD - k0 < TK) ? (g.KD - k0) : TK;
+  const int nvn = ncw >> 3, nvk = kcw >> 3;
+  const int FN = (ncw + 15) >> 4, FK = (kcw + 15) >> 4;
+
+  // ---- role of this wave: fragment window [ib, ib+cn) x [jb, jb+ck), k-steps [ks0, ks1)
+  int ib = 0, jb = 0, cn = 4, ck = 4, ks0 = 0, ks1 = NKS;
+  if (FN > 4 && FK > 4) { ib = 4 * (wave >> 1); jb = 4 * (wave & 1); }
+  else {
+    ks0 = (wave & 1) * (NKS / 2); ks1 = ks0 + NKS / 2;
+    if (FN > 4) ib = 4 * (wave >> 1);
+    else if (FK > 4) jb = 4 * (wave >> 1);
+    else if (FN > 2) { ib = 2 * (wave >> 1); cn = 2; }
+    else { jb = 2 * (wave >> 1); ck = 2; }
+  }
+  cn = FN - ib < cn ? FN - ib : cn; cn = cn < 0 ? 0 : cn;
+  ck = FK - jb < ck ? FK - jb : ck; ck = ck < 0 ? 0 : ck;
+
+  const long nstage = (g.P + PT - 1) / PT;
+  const long per = (nstage + g.nsplit - 1) / g.nsplit;
+  const long s_begin = split * per;
+  long s_end = s_begin + per;
+  if (s_end > nstage) s_end = nstage;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int i = tid; i < TN * ROW / 16; i += NT) {   // rows that are never staged must read as 0
+    reinterpret_cast<uint4*>(Gt)[i] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+  }
+
+  // ---- this thread's units and their folded constants
+  const int pgG = tid / nvn, cvG = tid - pgG * nvn;
+  const int pgA = tid / nvk, cvA = tid - pgA * nvk;
+  const bool onG = pgG < NPG, onA = pgA < NPG;
+  float ca[8], cb[8], cc[8], as[8], ab[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int chn = n0 + (onG ? cvG * 8 : 0) + j, chk = k0 + (onA ? cvA * 8 : 0) + j;
+    const float ga = g.ga[chn], gb = g.gb[chn];
+    ca[j] = ga; cb[j] = gb; cc[j] = -(ga * g.gce[chn]) - gb * g.gmu[chn];      // g = ga*e + gb*y + cc
+    const float sc = g.xs ? g.xs[chk] : 1.f;
+    as[j] = sc; ab[j] = g.xs ? (g.xb ? g.xb[chk] : 0.f) - (g.xm ? g.xm[chk] : 0.f) * sc : 0.f;   // a = relu?(x*as + ab)
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+
+  const T* eg = reinterpret_cast<const T*>(g.e) + n0 + (onG ? cvG * 8 : 0);
+  const T* yg = reinterpret_cast<const T*>(g.yraw) + n0 + (onG ? cvG * 8 : 0);
+  const T* xg = reinterpret_cast<const T*>(g.x) + k0 + (onA ? cvA * 8 : 0);
+
+  uint4 re[4], ry[4], rx[4];
+  auto issue = [&](long s) {
+    const long p0 = s * PT;
+    if (onG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + pgG * 4 + i;
+        const long pc = p < g.P ? p : 0;       // clamp + zero afterwards: no predicated loads
+        re[i] = *reinterpret_cast<const uint4*>(eg + pc * g.lde);
+        ry[i] = *reinterpret_cast<const uint4*>(yg + pc * g.ldyr);
+      }
+    }
+    if (onA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + pgA * 4 + i;
+        const long pc = p < g.P ? p : 0;
+        rx[i] = *reinterpret_cast<const uint4*>(xg + pc * g.ldx);
+      }
+    }
+  };
+  auto unit_ptr = [&](unsigned char* tile, int row, int pg) -> unsigned char* {
+    const int boff = pg * 8;
+    return tile + row * ROW + ((((boff >> 4)) ^ ((row >> 3) & 7)) << 4) + (boff & 15);
+  };
+  auto blo = [](uint32_t u) { return __uint_as_float(u << 16); };
+  auto bhi = [](uint32_t u) { return __uint_as_float(u & 0xffff0000u); };
+
+  if (s_begin < s_end) issue(s_begin);
+  for (long s = s_begin; s < s_end; ++s) {
+    const long p0 = s * PT;
+    __syncthreads();   // MFMAs of the previous stage have read the tiles (first pass: the zero fill is complete)
+    if (onG) {
+      float v[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = p0 + pgG * 4 + i < g.P;
+        const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[i]);
+        const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[i]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          v[i][2 * h] = ca[2 * h] * blo(ue[h]) + (cb[2 * h] * blo(uy[h]) + cc[2 * h]);
+          v[i][2 * h + 1] = ca[2 * h + 1] * bhi(ue[h]) + (cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]);
+        }
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(Gt, cvG * 8 + j, pgG), v[0][j], v[1][j], v[2][j], v[3][j]);
+    }
+    if (onA) {
+      float v[4][8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = p0 + pgA * 4 + i < g.P;
+        const uint32_t* ux = reinterpret_cast<const uint32_t*>(&rx[i]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          v[i][2 * h] = fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
+          v[i][2 * h + 1] = fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
+        }
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(At, cvA * 8 + j, pgA), v[0][j], v[1][j], v[2][j], v[3][j]);
+    }
+    __syncthreads();
+    if (s + 1 < s_end) issue(s + 1);
+
+    if (cn > 0 && ck > 0) {
+      const int rg = ib * 16 + fr, rk = jb * 16 + fr;
+      const unsigned char* grow = Gt + rg * ROW;
+      const unsigned char* arow = At + rk * ROW;
+      for (int ks = ks0; ks < ks1; ++ks) {
+        bf16x8 gf[4], af[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < cn) gf[i] = *reinterpret_cast<const bf16x8*>(grow + i * 16 * ROW + (((ks * 4 + fq) ^ (((rg + i * 16) >> 3) & 7)) << 4));
+          if (i < ck) af[i] = *reinterpret_cast<const bf16x8*>(arow + i * 16 * ROW + (((ks * 4 + fq) ^ (((rk + i * 16) >> 3) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < cn && j < ck) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  if (s_begin < s_end) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (i < cn && j < ck) {
+          const int k = k0 + (jb + j) * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = n0 + (ib + i) * 16 + fq * 4 + r;
+            if (n < g.ND && k < g.KD) atomicAdd(g.dw + (long)n * g.drs + (long)k * g.dcs, acc[i][j][r]);
+          }
+        }
+      }
+  }
+}
+
+template <int PT>
+void launch_fast_pt(WgradArgs& g, hipStream_t stream) {
+  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
+  const int tiles = nchn * nchk;
+  const long nstage = (g.P + PT - 1) / PT;
+  constexpr long MIN_STAGES = 512 / PT;   // a block amortises its LDS clear + atomics over >= 512 pixels
+  long ns = 1024 / tiles;
+  if (ns < 1) ns = 1;
+  if (ns > (nstage + MIN_STAGES - 1) / MIN_STAGES) ns = (nstage + MIN_STAGES - 1) / MIN_STAGES;
+  if (ns < 1) ns = 1;
+  g.nsplit = (int)ns;
+  constexpr int smem = 2 * TN * (PT * 2 + 16);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgfast_kernel<PT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr = true;
+  }
+  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(tiles * (int)ns), dim3(NT), smem, stream, g);
+}
+
 int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
   if (g.P <= 0) return TSS_OK;
   const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
@@ -306,7 +520,6 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 }  // namespace
 
-extern int g_tss_disable_fast;   // pwfast.hip
 bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                            const float* gce, const float* gmu, const void* x_nchw, int x_is_f32, float* dw, float* ws,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
@@ -327,8 +540,15 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.Hout = 1; g.Wout = 1;
   g.dw = dw; g.drs = K; g.dcs = 1; g.dts = 0;
-  return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream,
-                (double)P * (N * (yraw ? 2 : 1) + K) * esz(dtype));
+  const double bytes = (double)P * (N * (yraw ? 2 : 1) + K) * esz(dtype);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && (N % 8) == 0 && P > 0) {   // lean pipelined kernel
+    tss::ProfScope prof(TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)P * N * K);
+    const int wmax = (N < TN ? N : TN) > (K < TK ? K : TK) ? (N < TN ? N : TN) : (K < TK ? K : TK);
+    if (wmax <= 64) launch_fast_pt<128>(g, (hipStream_t)stream);
+    else launch_fast_pt<64>(g, (hipStream_t)stream);
+    return tss::check_last("wgfast");
+  }
+  return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes);
 }
 
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
