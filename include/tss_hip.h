@@ -58,7 +58,6 @@ int tss_version(void);                 /* ABI version of this header */
 const char* tss_last_error(void);      /* text of the last HIP error seen by this library (thread-local) */
 const char* tss_arch(void);            /* "gfx950" */
 #define TSS_OPT_DISABLE_FAST_PATHS 1   /* value 1: bf16 calls use the general kernels only (A/B checks of the lean ones) */
-#define TSS_OPT_LINEAR_BWD 2           /* value 0: bf16 1x1 backward-data transforms activations instead of folding into weights */
 int tss_set_option(int key, int value);
 
 /* ---- profiler: HIP events around every launch, on the launch stream --------------------------------- */

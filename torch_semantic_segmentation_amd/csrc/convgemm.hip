@@ -469,7 +469,6 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 }  // namespace
 
 extern int g_tss_disable_fast;   // pwfast.hip
-extern int g_tss_lin_bwd;        // pwfast.hip
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream);                                                                    // pwfast.hip
@@ -576,7 +575,6 @@ int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 
 int tss_set_option(int key, int value) {
   if (key == TSS_OPT_DISABLE_FAST_PATHS) { g_tss_disable_fast = value; return TSS_OK; }
-  if (key == TSS_OPT_LINEAR_BWD) { g_tss_lin_bwd = value; return TSS_OK; }
   return TSS_ERR_SHAPE;
 }
 

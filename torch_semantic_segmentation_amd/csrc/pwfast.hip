@@ -34,6 +34,69 @@ struct FastArgs {
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float bits_lo(uint32_t u) { return __uint_as_float(u << 16); }
 
+// Weight chunk -> LDS as bf16: Ws[n][j] for n in [0, nrows), j in [0, kwp); zero outside [0, ncw) x [0, kw).
+//   w_trans == 0: source w[(n0+n)*ldw + kb + j]   (forward: rows are output channels, ldw = K)
+//   w_trans == 1: source w[(kb+j)*ldw + n0 + n]   (backward-data: the same [N][K] tensor read transposed, ldw = conv K)
+// Fixed 2-D thread maps (no integer division), 8 independent loads in flight per thread, clamp + select instead of
+// predicated loads (a predicated load compiles to a branch with its own s_waitcnt: 16 serial L2 round trips).
+__device__ __forceinline__ void stage_weights(T* Ws, const float* w, int w_trans, long ldw, int n0, int ncw, int nrows,
+                                              int kb, int kw, int kwp, int tid) {
+  if (!w_trans) {
+    const int tx = tid & 31, ty = tid >> 5;   // float4 column, row within a pass of 8
+    const bool cok = tx * 4 < kw;
+    for (int rb = 0; rb < nrows; rb += 64) {
+      float4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = rb + u * 8 + ty;
+        const bool ok = cok && n < ncw;
+        wv[u] = *reinterpret_cast<const float4*>(w + (ok ? (long)(n0 + n) * ldw + kb + tx * 4 : 0));
+        if (!ok) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int n = rb + u * 8 + ty;
+        if (n < nrows && tx * 4 < kwp) {
+          bf16x4 o; o[0] = (T)wv[u].x; o[1] = (T)wv[u].y; o[2] = (T)wv[u].z; o[3] = (T)wv[u].w;
+          *reinterpret_cast<bf16x4*>(Ws + n * RS + tx * 4) = o;
+        }
+      }
+    }
+  } else {
+    const int tj = tid & 127, th = tid >> 7;  // contraction index (conflict-free LDS stores), n-vector within a pass of 2
+    const bool jok = tj < kw;
+    const int nvt = nrows >> 2;
+    for (int vb = 0; vb < nvt; vb += 16) {
+      float4 wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int nv = vb + u * 2 + th;
+        const bool ok = jok && nv * 4 < ncw;
+        wv[u] = *reinterpret_cast<const float4*>(w + (ok ? (long)(kb + tj) * ldw + n0 + nv * 4 : 0));
+        if (!ok) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int nv = vb + u * 2 + th;
+        if (nv < nvt && tj < kwp) {
+          T* d = Ws + (nv * 4) * RS + tj;
+          d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
+        }
+      }
+    }
+  }
+}
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: 4 VALU adds with a row
+// rotate modifier instead of 4 ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 template <bool BWD>
 __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -83,56 +146,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   const bool cv_real = cv < nvec;          // vectors in [nvec, nvecp) are the zero padding of the last k-step
 
   // ---- weights -> LDS once per block (resident): Ws[n][k], zero beyond ncw / K
-  {
-    if (!g.w_trans) {
-      const int vpr = kwp >> 2;
-      const int total = nrows * vpr;
-      for (int base = 0; base < total; base += NT * 8) {
-        float4 wv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + tid + u * NT;
-          const int n = idx / vpr, jv = idx - n * vpr;
-          const bool okw = idx < total && n < ncw && jv * 4 < K;   // clamp + select: predicated loads serialise
-          wv[u] = *reinterpret_cast<const float4*>(g.w + (okw ? (long)(n0 + n) * K + jv * 4 : 0));
-          if (!okw) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + tid + u * NT;
-          if (idx < total) {
-            const int n = idx / vpr, jv = idx - n * vpr;
-            bf16x4 o; o[0] = (T)wv[u].x; o[1] = (T)wv[u].y; o[2] = (T)wv[u].z; o[3] = (T)wv[u].w;
-            *reinterpret_cast<bf16x4*>(Ws + n * RS + jv * 4) = o;
-          }
-        }
-      }
-    } else {
-      // transposed source w[k*N + n]: lanes over the contraction index (conflict-free LDS stores, see convgemm.hip)
-      const int vpc = nrows >> 2;
-      const int total = kwp * vpc;
-      for (int base = 0; base < total; base += NT * 8) {
-        float4 wv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + tid + u * NT;
-          const int nv = idx / kwp, j = idx - nv * kwp;
-          const bool okw = idx < total && j < K && nv * 4 < ncw;
-          wv[u] = *reinterpret_cast<const float4*>(g.w + (okw ? (long)j * g.N + n0 + nv * 4 : 0));
-          if (!okw) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int idx = base + tid + u * NT;
-          if (idx < total) {
-            const int nv = idx / kwp, j = idx - nv * kwp;
-            T* d = Ws + (nv * 4) * RS + j;
-            d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
-          }
-        }
-      }
-    }
-  }
+  stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, 0, K, kwp, tid);
 
   // ---- this lane's prologue coefficients (registers), mean folded into the additive term
   float k0[8], k1[8], kadd[8];
@@ -316,9 +330,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float u = st1[i][q], w2 = st2[i][q];
-#pragma unroll
-        for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w2 += __shfl_xor(w2, mk, 64); }
+        const float u = row16_sum(st1[i][q]), w2 = row16_sum(st2[i][q]);
         if (fr == 0) {
           red[(wm * 2 + 0) * NCH + wn * 64 + i * 16 + fq * 4 + q] = u;
           red[(wm * 2 + 1) * NCH + wn * 64 + i * 16 + fq * 4 + q] = w2;
@@ -441,53 +453,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
           }
         }
       }
-      if (!g.w_trans) {
-        const int vpr = kwp >> 2;
-        const int total = nrows * vpr;
-        for (int base = 0; base < total; base += NT * 8) {
-          float4 wv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            const int n = idx / vpr, jv = idx - n * vpr;
-            const bool okw = idx < total && n < ncw && jv * 4 < kw;
-            wv[u] = *reinterpret_cast<const float4*>(g.w + (okw ? (long)(n0 + n) * K + kb + jv * 4 : 0));
-            if (!okw) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            if (idx < total) {
-              const int n = idx / vpr, jv = idx - n * vpr;
-              bf16x4 o; o[0] = (T)wv[u].x; o[1] = (T)wv[u].y; o[2] = (T)wv[u].z; o[3] = (T)wv[u].w;
-              *reinterpret_cast<bf16x4*>(Ws + n * RS + jv * 4) = o;
-            }
-          }
-        }
-      } else {
-        const int vpc = nrows >> 2;
-        const int total = kwp * vpc;
-        for (int base = 0; base < total; base += NT * 8) {
-          float4 wv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            const int nv = idx / kwp, j = idx - nv * kwp;
-            const bool okw = idx < total && j < kw && nv * 4 < ncw;
-            wv[u] = *reinterpret_cast<const float4*>(g.w + (okw ? (long)(kb + j) * g.N + n0 + nv * 4 : 0));
-            if (!okw) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            if (idx < total) {
-              const int nv = idx / kwp, j = idx - nv * kwp;
-              T* d = Ws + (nv * 4) * RS + j;
-              d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
-            }
-          }
-        }
-      }
+      stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, kb, kw, kwp, tid);
       if (lane_on) {
         float k0[8], k1[8], kadd[8];
         const int cb = kb + (cv_real ? cv * 8 : 0);
@@ -603,9 +569,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float u = st1[i][q], w2 = st2[i][q];
-#pragma unroll
-        for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w2 += __shfl_xor(w2, mk, 64); }
+        const float u = row16_sum(st1[i][q]), w2 = row16_sum(st2[i][q]);
         if (fr == 0) {
           red[(wm * 2 + 0) * NCH + wn * 64 + i * 16 + fq * 4 + q] = u;
           red[(wm * 2 + 1) * NCH + wn * 64 + i * 16 + fq * 4 + q] = w2;
@@ -645,286 +609,6 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   hipLaunchKernelGGL(pwfast_mc_kernel<BWD>, dim3(grid), dim3(NT), kSmemMc, stream, g);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Backward-data with the BatchNorm backward folded into the WEIGHTS instead of the activations.
-//   g[p][n] = ga[n]*(e[p][n] - gce[n]) + gb[n]*(y[p][n] - mu[n])   is linear per channel, so
-//   dX[p][k] = sum_n e[p][n]*(ga[n] W[n][k]) + sum_n y[p][n]*(gb[n] W[n][k]) - c[k],
-//   c[k]     = sum_n gce[n]*(ga[n] W[n][k]) + mu[n]*(gb[n] W[n][k]).
-// The raw bf16 tiles of e and y go to LDS untouched (no unpack / FMA / pack per element: that prologue was the VALU
-// bottleneck of pwfast_kernel<true>), the contraction runs over the virtual index v in [0, 2*NP), NP = N rounded up
-// to 32 (first half e, second half y), and c is formed from the SAME bf16-rounded scaled weights that feed the MFMA,
-// so the result equals sum_n bf16(ga W)(e - gce) + bf16(gb W)(y - mu): only the weights are rounded, exactly like
-// the forward pass.  Chunks of 128 virtual channels; weights resident when one chunk covers everything (N <= 64).
-template <int DUMMY>
-__global__ __launch_bounds__(NT, 2) void pwlin_bwd_kernel(const FastArgs g) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  T* Xs = reinterpret_cast<T*>(smem);
-  T* Ws = Xs + BM * RS;
-  float* Cm = reinterpret_cast<float*>(Ws + NCH * RS);   // [128] subtrahend (gce | mu) of the chunk's virtual channels
-  float* Cp = Cm + KMAX;                                 // [2][128] halves of c[k]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, fq = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nchunks = (g.N + NCH - 1) / NCH;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int nc = slot % nchunks, gslot = slot / nchunks;
-  const long ntiles = (g.P + BM - 1) / BM;
-  const long per = (ntiles + 7) >> 3;
-  const long t_begin = xcd * per + gslot;
-  long t_end = xcd * per + per;
-  if (t_end > ntiles) t_end = ntiles;
-
-  const int n0 = nc * NCH;
-  const int ncw = (g.N - n0 < NCH) ? (g.N - n0) : NCH;
-  const int nrows = ((ncw + 15) >> 4) * 16;
-  int nfr = (ncw - wn * 64 + 15) >> 4;
-  nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
-  const int C = g.K;                       // real contraction channels (conv Cout)
-  const int NP = (C + 31) & ~31;
-  const int V = 2 * NP;
-  const int nkc = (V + KMAX - 1) / KMAX;
-  const int crow = tid & 127, chalf = tid >> 7;   // ownership in the c[k] pass
-
-  float st1[4][4], st2[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
-  const int nlane = n0 + wn * 64 + fq * 4;
-  float cpart = 0.f;
-
-  for (long tile = t_begin; tile < t_end; tile += g.gslots) {
-    const long p0 = tile * BM;
-    const bool full = p0 + BM <= g.P;
-    const bool first = tile == t_begin;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    for (int kc = 0; kc < nkc; ++kc) {
-      const int vb = kc * KMAX;
-      const int vw = (V - vb < KMAX) ? (V - vb) : KMAX;      // multiple of 32
-      const int nvecp = vw >> 3;
-      const int rpp = NT / nvecp, npass = (BM + rpp - 1) / rpp;
-      const int cv = tid % nvecp, r = tid / nvecp;
-      const bool lane_on = r < rpp;
-      const int v0 = vb + cv * 8;
-      const int src = v0 >= NP;
-      const int ch0 = v0 - (src ? NP : 0);
-      const bool cv_real = ch0 < C;
-      __syncthreads();
-
-      uint4 ra[8];
-      if (lane_on) {
-        const T* pa = (src ? g.a1 + p0 * g.lda1 : g.a0 + p0 * g.lda0) + (cv_real ? ch0 : 0);
-        const int lda = src ? (int)g.lda1 : (int)g.lda0;
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          if (ps < npass) {
-            const int row = ps * rpp + r;
-            const bool ok = row < BM && (full || p0 + row < g.P);
-            ra[ps] = *reinterpret_cast<const uint4*>(pa + (ok ? row : 0) * lda);
-          }
-        }
-      }
-      if (nkc > 1 || first) {
-        // scaled weights of this chunk: Ws[k][jj] = coef(v) * W[ch(v)][n0 + k], lanes over the contraction index
-        const int vpc = nrows >> 2;
-        const int total = vw * vpc;
-        for (int base = 0; base < total; base += NT * 8) {
-          float4 wv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            const int nv = idx / vw, jj = idx - nv * vw;
-            const int v = vb + jj;
-            const int sv = v >= NP;
-            const int ch = v - (sv ? NP : 0);
-            wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < total && ch < C && nv * 4 < ncw) {
-              const float4 t4 = *reinterpret_cast<const float4*>(g.w + (long)ch * g.N + n0 + nv * 4);
-              const float cf = sv ? (g.c1 ? g.c1[ch] : 0.f) : (g.c0 ? g.c0[ch] : 1.f);
-              wv[u] = make_float4(t4.x * cf, t4.y * cf, t4.z * cf, t4.w * cf);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int idx = base + tid + u * NT;
-            if (idx < total) {
-              const int nv = idx / vw, jj = idx - nv * vw;
-              T* d = Ws + (nv * 4) * RS + jj;
-              d[0] = (T)wv[u].x; d[RS] = (T)wv[u].y; d[2 * RS] = (T)wv[u].z; d[3 * RS] = (T)wv[u].w;
-            }
-          }
-        }
-        if (first && tid < KMAX) {
-          const int v = vb + tid;
-          const int sv = v >= NP;
-          const int ch = v - (sv ? NP : 0);
-          float mv = 0.f;
-          if (tid < vw && ch < C) mv = sv ? (g.c3 ? g.c3[ch] : 0.f) : (g.c2 ? g.c2[ch] : 0.f);
-          Cm[tid] = mv;
-        }
-      }
-      if (lane_on) {
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-          if (ps < npass) {
-            const int row = ps * rpp + r;
-            if (row < BM) {
-              const bool ok = cv_real && (full || p0 + row < g.P);
-              uint4 o = ra[ps];
-              if (!ok) o = make_uint4(0u, 0u, 0u, 0u);
-              *reinterpret_cast<uint4*>(Xs + row * RS + cv * 8) = o;
-            }
-          }
-        }
-      }
-      __syncthreads();
-
-      if (first) {   // c[k] += sum_jj Ws[k][jj] * m[jj] over this thread's half of the chunk
-        const int hw = vw >> 1;   // multiple of 16
-        const T* wr = Ws + crow * RS + chalf * hw;
-        const float* mr = Cm + chalf * hw;
-        for (int jj = 0; jj < hw; jj += 8) {
-          const uint4 wq = *reinterpret_cast<const uint4*>(wr + jj);
-          const float4 m0 = *reinterpret_cast<const float4*>(mr + jj), m1 = *reinterpret_cast<const float4*>(mr + jj + 4);
-          cpart += bits_lo(wq.x) * m0.x + bits_hi(wq.x) * m0.y + bits_lo(wq.y) * m0.z + bits_hi(wq.y) * m0.w
-                 + bits_lo(wq.z) * m1.x + bits_hi(wq.z) * m1.y + bits_lo(wq.w) * m1.z + bits_hi(wq.w) * m1.w;
-        }
-      }
-
-      if (nfr > 0) {
-        const T* xrow = Xs + (wm * 64 + fr) * RS + fq * 8;
-        const T* wrow = Ws + (wn * 64 + fr) * RS + fq * 8;
-        const int nks = vw >> 5;
-        for (int ks = 0; ks < nks; ++ks) {
-          bf16x8 xf[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (i < nfr) {
-              const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RS + ks * 32);
-#pragma unroll
-              for (int m = 0; m < 4; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-    if (first) {
-      Cp[chalf * KMAX + crow] = cpart;
-      __syncthreads();
-    }
-
-    // ---- epilogue: subtract c, mask with the producer's activation, statistics of what is stored
-    T* yrow = g.y + (p0 + wm * 64 + fr) * g.ldy + nlane;
-    const T* xrow_m = g.xm ? g.xm + (p0 + wm * 64 + fr) * g.ldxm + nlane : nullptr;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < nfr) {
-        const int n = nlane + i * 16;
-        const bool nin = n < g.N;
-        const int nl = wn * 64 + i * 16 + fq * 4;
-        float cc[4], cmm[4] = {0.f, 0.f, 0.f, 0.f}, ck0[4] = {1.f, 1.f, 1.f, 1.f}, ck1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cc[q] = Cp[nl + q] + Cp[KMAX + nl + q];
-        if (nin && g.xm) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            cmm[q] = g.mm ? g.mm[n + q] : 0.f;
-            ck0[q] = g.ms ? g.ms[n + q] : 1.f;
-            ck1[q] = (g.mb ? g.mb[n + q] : 0.f) - cmm[q] * ck0[q];
-          }
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const bool pin = full || (p0 + wm * 64 + m * 16 + fr < g.P);
-          if (pin && nin) {
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q] - cc[q];
-            if (g.xm) {
-              const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
-              const float xv[4] = {bits_lo(xr.x), bits_hi(xr.x), bits_lo(xr.y), bits_hi(xr.y)};
-              if (g.m_relu) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) if (!(xv[q] * ck0[q] + ck1[q] > 0.f)) v[q] = 0.f;
-              }
-              bf16x4 o;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * (xv[q] - cmm[q]); }
-              *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
-            } else {
-              bf16x4 o;
-#pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
-              *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
-            }
-          }
-        }
-      }
-    }
-  }
-
-  if (g.stats) {
-    __syncthreads();
-    const int row = xcd + 8 * gslot, rows_used = 8 * g.gslots;
-    float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float u = st1[i][q], w2 = st2[i][q];
-#pragma unroll
-        for (int mk = 1; mk <= 8; mk <<= 1) { u += __shfl_xor(u, mk, 64); w2 += __shfl_xor(w2, mk, 64); }
-        if (fr == 0) {
-          red[(wm * 2 + 0) * NCH + wn * 64 + i * 16 + fq * 4 + q] = u;
-          red[(wm * 2 + 1) * NCH + wn * 64 + i * 16 + fq * 4 + q] = w2;
-        }
-      }
-    __syncthreads();
-    if (tid < ncw) {
-      const double a = (double)red[0 * NCH + tid] + (double)red[2 * NCH + tid];
-      const double b = (double)red[1 * NCH + tid] + (double)red[3 * NCH + tid];
-      g.stats[(long)row * 2 * g.N + n0 + tid] = a;
-      g.stats[(long)row * 2 * g.N + g.N + n0 + tid] = b;
-      for (int rr = row + rows_used; rr < TSS_STAT_SLABS; rr += rows_used) {
-        g.stats[(long)rr * 2 * g.N + n0 + tid] = 0.0;
-        g.stats[(long)rr * 2 * g.N + g.N + n0 + tid] = 0.0;
-      }
-    }
-  }
-}
-
-constexpr size_t kSmemLin = (size_t)(BM + NCH) * RS * sizeof(T) + 3 * KMAX * sizeof(float);
-
-void launch_lin_bwd(FastArgs& g, hipStream_t stream) {
-  const int nchunks = (g.N + NCH - 1) / NCH;
-  const long ntiles = (g.P + BM - 1) / BM;
-  long gs = (ntiles + 7) / 8;
-  long cap = 64 / nchunks;
-  if (cap < 1) cap = 1;
-  if (gs > cap) gs = cap;
-  g.gslots = (int)gs;
-  const int grid = 8 * nchunks * (int)gs;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwlin_bwd_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemLin);
-    attr = true;
-  }
-  hipLaunchKernelGGL(pwlin_bwd_kernel<0>, dim3(grid), dim3(NT), kSmemLin, stream, g);
-}
-
 constexpr size_t kSmem = (size_t)(BM + NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
 
 template <bool BWD>
@@ -947,7 +631,6 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-int g_tss_lin_bwd = 0;        // tss_set_option(TSS_OPT_LINEAR_BWD, 0): previous activation-side backward-data kernels
 int g_tss_disable_fast = 0;   // tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1): A/B switch for tests
 
 // forward: y = act(x) W^T (+bias).  Returns false when the shape is not covered (caller uses convgemm_kernel).
@@ -974,7 +657,6 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  if (g_tss_lin_bwd) launch_lin_bwd(g, stream);
-  else if (N <= KMAX) launch_fast<true>(g, stream); else launch_fast_mc<true>(g, stream);
+  if (N <= KMAX) launch_fast<true>(g, stream); else launch_fast_mc<true>(g, stream);
   return true;
 }
