@@ -382,10 +382,10 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* 
 constexpr int SW = 4;
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void dw_fwd_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
-  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];  // [tap][C]
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
     for (int i = 0; i < SW; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = oy * S + (ky - 1) * D;
       const bool vy = iy >= 0 && iy < g.Hin;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_strip_kernel(const DwArgs g) {
 }
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_kernel(const DwArgs g) {
   constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
   __shared__ float sdw[768 * 9];
   const int tid = threadIdx.x;
@@ -600,10 +600,10 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_strip_kernel(const DwArg
 // backward-data on strips of 4 INPUT pixels.  Stride 1: the flipped-tap window of g = BN'(e, y), 2*D + 4 columns.
 // Stride 2 (D = 1): only output rows/columns of matching parity contribute: <= 2 rows x 3 columns.
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX) void dw_bwd_data_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   constexpr int NCOL = (S == 1) ? (SW + 2 * D) : 3;
-  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(double)];
+  __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
