@@ -652,12 +652,22 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
     for (int i = 0; i < SW; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    // the producer's raw output under the strip (ReLU mask + statistics in the epilogue): issued first, so the round
+    // trip runs under the three window rows instead of being exposed at the end of every strip
+    const long pbase = (b * g.Hin + iy) * (long)g.Win + x0;
+    typename V8<T>::Raw rx[SW];
+    if (g.x) {
 #pragma unroll
+      for (int i = 0; i < SW; ++i) rx[i] = V8<T>::load_raw(x + (pbase + (x0 + i < g.Win ? i : 0)) * g.ldx + c0);
+    }
+#pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
       const int ny = iy - (ky - 1) * D;  // = oy * S
-      const int oy = ny / S;
-      const bool vy = ny >= 0 && oy * S == ny && oy < g.Hout;
-      if (!vy) continue;                 // parity / border: the whole row contributes nothing
+      const int oyr = ny / S;
+      // parity / border rows contribute nothing: their loads are clamped to row 0 and masked (no branch around the
+      // loads, so the rows can overlap)
+      const bool vy = ny >= 0 && oyr * S == ny && oyr < g.Hout;
+      const int oy = vy ? oyr : 0;
       const long rowq = (b * g.Hout + oy) * (long)g.Wout;
       // first output column of the window: stride 1: x0 - D; stride 2: x0 / 2 (x0 is a multiple of 4)
       const int oc0 = (S == 1) ? (x0 - D) : (x0 / 2);
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
 #pragma unroll
       for (int c = 0; c < NCOL; ++c) {
         const int ox = oc0 + c;
-        ok[c] = ox >= 0 && ox < g.Wout;
+        ok[c] = vy && ox >= 0 && ox < g.Wout;
         const long q = rowq + (ox < 0 ? 0 : (ox >= g.Wout ? g.Wout - 1 : ox));
         re[c] = V8<T>::load_raw(e + q * g.lde + c0);
         if (yr) ry[c] = V8<T>::load_raw(yr + q * g.ldyr + c0);
@@ -713,10 +723,10 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
       if (x0 + i < g.Win) {
-        const long p = (b * g.Hin + iy) * (long)g.Win + x0 + i;
+        const long p = pbase + i;
         if (g.x) {
           float xv[8];
-          V8<T>::load(x + p * g.ldx + c0, xv);
+          V8<T>::unpack(rx[i], xv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xc = xv[j] - mu[j];
