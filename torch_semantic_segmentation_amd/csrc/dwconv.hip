@@ -346,29 +346,29 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
   }
 }
 
-// dw[i] += sum over the workspace rows.  16 columns x 16 row-groups per block: every lane keeps 8 independent loads in
-// flight and the whole reduction is ~4 dependent round trips (one thread per column walking 512 rows serially took
-// ~100 us per depthwise layer).
-__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
-  __shared__ float part[16][17];
-  const int col = blockIdx.x * 16 + (threadIdx.x & 15);
-  const int rg = threadIdx.x >> 4;
+// dw[i] += sum over the workspace rows.  64 columns per block with the lanes along the columns (every load
+// instruction reads one contiguous 256-byte piece of a row), 16 waves taking rows w, w+16, ... with up to 32 loads in
+// flight per lane: one memory round trip for 512 rows, then a 16-way LDS reduction.
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
+  __shared__ float part[RED_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int cc = col < n ? col : 0;
   float s = 0.f;
-  if (col < n) {
-    for (int r0 = rg; r0 < rows; r0 += 16 * 8) {
-      float v[8];
+  for (int r0 = wave; r0 < rows; r0 += RED_WAVES * 32) {
+    float v[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = r < rows ? ws[(long)r * n + col] : 0.f; }
+    for (int u = 0; u < 32; ++u) { const int r = r0 + RED_WAVES * u; v[u] = ws[(long)(r < rows ? r : 0) * n + cc]; }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
-    }
+    for (int u = 0; u < 32; ++u) s += (r0 + RED_WAVES * u < rows) ? v[u] : 0.f;
   }
-  part[rg][threadIdx.x & 15] = s;
+  part[wave][lane] = s;
   __syncthreads();
-  if (threadIdx.x < 16 && col < n) {
+  if (threadIdx.x < 64 && col < n) {
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+    for (int q = 0; q < RED_WAVES; ++q) t += part[q][threadIdx.x];
     dw[col] += t;
   }
 }
@@ -872,7 +872,7 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
     if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   }
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 15) / 16), dim3(256), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
   return tss::check_last("dwconv_bwd_weight");
 }
 

@@ -11,35 +11,45 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------ BN
-// sum of one column pair (c, C + c) over the TSS_STAT_SLABS partial rows: one 64-lane wave per channel, all
-// 2 x 8 loads of a lane issued before the first add (one memory round trip per finalize)
-__device__ __forceinline__ void slab_sum(const double* slabs, int C, int c, int lane, double* s0, double* s1) {
-  constexpr int R = TSS_STAT_SLABS / 64;
-  double va[R], vb[R];
+// Column sums over the TSS_STAT_SLABS partial rows for a group of FIN_CH channels per block.  Lanes run along the
+// channels (lanes 0..31: sum column c, lanes 32..63: second column C + c), so every load instruction of a wave reads
+// two contiguous 256-byte segments of one slab row; the 16 waves of the block take rows w, w+16, ... (32 rows each,
+// all loads of a lane in flight at once) and meet in LDS.  The first version gave one wave per channel with lanes along the
+// ROWS: 64 different cache lines per instruction, ~8-10 us per finalize x 88 launches per step.
+constexpr int FIN_CH = 32, FIN_WAVES = 16, FIN_NT = FIN_WAVES * 64;
+__device__ __forceinline__ void slab_sum(const double* slabs, int C, double* s0, double* s1, int* c_out) {
+  __shared__ double red[FIN_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cl = lane & 31, hs = lane >> 5;
+  const int c = blockIdx.x * FIN_CH + cl;
+  const bool in = c < C;
+  const double* col = slabs + (long)hs * C + (in ? c : 0);
+  constexpr int R = TSS_STAT_SLABS / FIN_WAVES;   // rows per wave
+  double acc = 0.0;
+  double v[R];   // all 32 loads of the lane in flight: one memory round trip per finalize
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const long off = (long)(lane + 64 * i) * 2 * C;
-    va[i] = c < C ? slabs[off + c] : 0.0;
-    vb[i] = c < C ? slabs[off + C + c] : 0.0;
-  }
+  for (int u = 0; u < R; ++u) v[u] = col[(long)(wave + FIN_WAVES * u) * 2 * C];
+#pragma unroll
+  for (int u = 0; u < R; ++u) acc += v[u];
+  red[wave][lane] = in ? acc : 0.0;
+  __syncthreads();
   double a = 0.0, b = 0.0;
+  if (threadIdx.x < FIN_CH) {
 #pragma unroll
-  for (int i = 0; i < R; ++i) { a += va[i]; b += vb[i]; }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
-  *s0 = a; *s1 = b;
+    for (int w = 0; w < FIN_WAVES; ++w) { a += red[w][threadIdx.x]; b += red[w][32 + threadIdx.x]; }
+  }
+  *s0 = a; *s1 = b; *c_out = blockIdx.x * FIN_CH + threadIdx.x;   // valid for threadIdx.x < FIN_CH
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* sums, double count, const float* gamma,
+__global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums, double count, const float* gamma,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    long long* num_batches, float* mean_out, float* invstd_out,
                                    float* scale, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
   double ssum, ssq;
-  slab_sum(sums, C, c, lane, &ssum, &ssq);
-  if (c >= C || lane != 0) return;
+  int c;
+  slab_sum(sums, C, &ssum, &ssq, &c);
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = ssum / count;
   double var = ssq / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -71,14 +81,13 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* running_m
 // training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
 //           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
 // frozen  : g = k*e
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
                                        const float* gamma, int training, int accumulate,
                                        float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
   double se, sey;
-  slab_sum(bstats, C, c, lane, &se, &sey);
-  if (c >= C || lane != 0) return;
+  int c;
+  slab_sum(bstats, C, &se, &sey, &c);
+  if (threadIdx.x >= FIN_CH || c >= C) return;
   const double r = invstd[c];
   const double dg = r * sey;
   const double db = se;
@@ -352,7 +361,7 @@ int tss_bn_finalize(const double* sums, double count, const float* gamma, float 
                     float* mean_out, float* invstd_out, float* scale, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 40.0 * C, 0);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, sums, count,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, sums, count,
                      gamma, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
                      scale, C);
   return tss::check_last("bn_finalize");
@@ -372,7 +381,7 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         float* ga, float* gb, float* gce, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, bstats, count,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, bstats, count,
                      invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C);
   return tss::check_last("bn_bwd_finalize");
 }

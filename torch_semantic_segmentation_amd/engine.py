@@ -158,11 +158,24 @@ class Trainer:
                         p.grad.div_(self.world_size)
         self.optimizer.step()
 
-    def _capture(self, x, y):
-        self._static = (torch.empty_like(x), torch.empty_like(y))
+    def static_batch(self, x, y):
+        """The (image, target) device buffers the captured step reads.  A loader can fill them in place (H2D copy
+        straight into them) and pass them to step_async, which then skips its own device-to-device copy."""
+        if self._static is None:
+            dev = self.device if self.device is not None else x.device
+            self._static = (torch.empty(x.shape, dtype=x.dtype, device=dev), torch.empty(y.shape, dtype=y.dtype, device=dev))
         sx, sy = self._static
-        sx.copy_(x)
-        sy.copy_(y)
+        if tuple(sx.shape) != tuple(x.shape) or tuple(sy.shape) != tuple(y.shape) or sx.dtype != x.dtype or sy.dtype != y.dtype:
+            raise ValueError('HIP-graph trainer: the batch shape/dtype is fixed at the first step '
+                             f'({tuple(sx.shape)} {sx.dtype}); got {tuple(x.shape)} {x.dtype}')
+        if x.data_ptr() != sx.data_ptr():
+            sx.copy_(x, non_blocking=True)
+        if y.data_ptr() != sy.data_ptr():
+            sy.copy_(y, non_blocking=True)
+        return sx, sy
+
+    def _capture(self, x, y):
+        sx, sy = self.static_batch(x, y)
         # warm-up on a side stream (lazily initialised state must exist before capture); buffers that a
         # forward pass mutates (BatchNorm running statistics) are restored so the warm-up leaves no trace
         saved = [(b, b.clone()) for b in self.model.buffers()]
@@ -184,9 +197,8 @@ class Trainer:
         if self.use_graph:
             if self._graph is None:
                 self._capture(x, y)
-            sx, sy = self._static
-            sx.copy_(x, non_blocking=True)
-            sy.copy_(y, non_blocking=True)
+            else:
+                self.static_batch(x, y)
             self._graph.replay()
             loss = self._static_loss
         else:
@@ -198,7 +210,7 @@ class Trainer:
     def update(self, batch):
         """TSS/engine.py:24-39: returns loss.item() (a device->host sync per iteration, as in the reference)."""
         x, y = batch
-        if self.device is not None:
+        if self.device is not None and not self.use_graph:   # graph mode copies straight into the static buffers
             x = x.to(self.device, non_blocking=self.non_blocking)
             y = y.to(self.device, non_blocking=self.non_blocking)
         self.last_loss = self.step_async(x, y).item()
