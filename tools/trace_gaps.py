@@ -29,6 +29,10 @@ for s, e, n in step:
     n = re.sub(r'\(.*', '', n)
     agg[n][0] += e - s
     agg[n][1] += 1
+if len(sys.argv) > 2:
+    with open(sys.argv[2], 'w') as f:
+        for s_, e_, n_ in step:
+            f.write(f'{(s_ - step[0][0]) / 1e3:9.1f} {(e_ - s_) / 1e3:8.1f}  {n_[:110]}\n')
 print(f'kernels {len(step)}  wall {wall / 1e3:.1f} us  sum(durations) {busy / 1e3:.1f} us  idle gaps {gap / 1e3:.1f} us')
 for n, (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
     print(f'{t / 1e3:9.1f} us {c:4d}  avg {t / c / 1e3:7.1f}  {n[:90]}')

@@ -45,7 +45,7 @@ class direct_grads:
 
 
 # Launch a layer's weight gradient on a side stream, concurrently with its input gradient (ConvUnitFn.backward).
-overlap_wgrad = True
+overlap_wgrad = False   # measured: no gain on MI355X once the kernels are pipelined (9.88 ms off vs 9.84-9.95 ms on)
 overlap_max_elems = 48 << 20   # only layers too small to fill the chip on their own (large ones just contend)
 _side_streams = {}
 
