@@ -39,6 +39,8 @@ def parse():
     ap.add_argument('--height', type=int, default=1024)
     ap.add_argument('--width', type=int, default=2048)
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'])
+    ap.add_argument('--fuse-head', default='on', choices=['on', 'off'],
+                    help='decoder upsample + cross-entropy as one operator (same value and gradients)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
@@ -160,7 +162,8 @@ def main():
     x, y = synthetic(args.batch, args.height, args.width, 1234 + rank, device)
 
     def make_trainer(use_graph):
-        return E.Trainer(model, opt, loss_fn, device=None, use_graph=use_graph, world_size=world)
+        return E.Trainer(model, opt, loss_fn, device=None, use_graph=use_graph, world_size=world,
+                         fuse_head_loss=args.fuse_head != 'off')
 
     graph_used = args.graph != 'off'
     trainer = make_trainer(graph_used)

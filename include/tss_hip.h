@@ -49,7 +49,7 @@ enum {
   TSS_K_BILINEAR_FWD, TSS_K_BILINEAR_BWD, TSS_K_BILINEAR_BWD_COLS, TSS_K_BILINEAR_PLANAR_FWD,
   TSS_K_UPSAMPLE_HEAD_FWD, TSS_K_UPSAMPLE_HEAD_BWD_ROWS, TSS_K_UPSAMPLE_HEAD_BWD_COLS,
   TSS_K_POOL_FWD, TSS_K_POOL_BWD, TSS_K_COPY,
-  TSS_K_CE_FWD, TSS_K_CE_BWD, TSS_K_ARGMAX, TSS_K_UPSAMPLE_CE_FWD, TSS_K_UPSAMPLE_CE_BWD_ROWS,
+  TSS_K_CE_FWD, TSS_K_CE_BWD, TSS_K_ARGMAX, TSS_K_UPSAMPLE_CE_FWD, TSS_K_UPSAMPLE_CE_BWD,
   TSS_K_COUNT
 };
 
@@ -207,15 +207,16 @@ int tss_cross_entropy_fwd(const void* logits, const long long* target, float* ls
 int tss_cross_entropy_bwd(const void* logits, const long long* target, const float* lse, const float* inv_count,
                           const float* grad_out, void* dlogits, long B, int C, long HW, int ignore_index,
                           int dtype, void* stream);
-/* Fused decoder head + loss: cross-entropy of the bilinearly upsampled logits straight from the low-res NHWC logits
- * (replaces F.interpolate TSS/models/fastscnn.py:63-64 + the loss call TSS/engine.py:30 as one operator; the
- * full-resolution logits are never materialised).  Backward = tss_upsample_ce_bwd_rows, then tss_upsample_head_bwd_cols. */
-int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* lse, unsigned char* target_u8,
+/* Fused decoder head + loss: cross-entropy (mean over the non-ignored pixels) of the bilinearly upsampled logits,
+ * straight from the low-res NHWC logits (replaces F.interpolate TSS/models/fastscnn.py:63-64 + the loss call
+ * TSS/engine.py:30 as one operator; the full-resolution logits and their gradient are never materialised).
+ * One pass computes the loss AND the unscaled low-res gradient (dlow_acc, f32, caller-zeroed, same [B][h][w][ldl]
+ * layout as low); backward = tss_upsample_ce_bwd: dlow = dlow_acc * grad_out / count.  C <= 24, H >= h, W >= w. */
+int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* dlow_acc,
                         double* acc, float* loss, float* inv_count,
                         int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream);
-int tss_upsample_ce_bwd_rows(const void* low, long ldl, const unsigned char* target_u8, const float* lse,
-                             const float* inv_count, const float* grad_out, float* tmp,
-                             int B, int C, int h, int w, int H, int W, int dtype, void* stream);
+int tss_upsample_ce_bwd(const float* dlow_acc, const float* inv_count, const float* grad_out, void* dlow,
+                        long n, int dtype, void* stream);
 int tss_upsample_head_bwd_cols(const float* tmp, void* dlow, long ldl, int B, int N, int h, int w, int W,
                                int dtype, void* stream);
 int tss_argmax_confusion(const void* logits, const long long* target, unsigned char* pred,

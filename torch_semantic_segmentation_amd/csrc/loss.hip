@@ -90,74 +90,135 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
 
 // ------------------------------------------------------------------------------------------------------------
 // Fused decoder head + loss: cross-entropy of the x`scale` bilinearly upsampled logits
-// computed straight from the LOW-RES NHWC logits.  The (B, C, H, W) full-resolution logits -- 318.8 M elements at
-// 8x1024x2048, the largest tensor of the step -- and their gradient are never written to HBM.
-//   forward : lane = 8 consecutive output pixels of a row; per class the 8 logits are interpolated from <= 3 source
-//             columns x 2 rows, folded into an online log-sum-exp; saves lse (f32) and the target as u8.
-//   backward: rows pass recomputes logit_c(oy, ox), d = (exp(l - lse) - [t == c]) / count and gathers it down the
-//             column window of source row iy (deterministic); the columns pass is tss_upsample_head_bwd's.
-template <typename T>
-__global__ __launch_bounds__(NT) void upsample_ce_fwd_kernel(const T* low, long ldl, const long long* target,
-                                                             float* lse_out, unsigned char* t8, double* acc,
-                                                             int B, int C, int h, int w, int H, int W, int ignore_index) {
+// computed straight from the LOW-RES NHWC logits, loss AND gradient in ONE pass.  The (B, C, H, W) full-resolution
+// logits -- 318.8 M elements at 8x1024x2048, the largest tensor of the step -- and their gradient never exist: the
+// unfused path moves ~3.8 GB for them (upsample, loss, loss backward, two-pass upsample backward: 1.04 ms of a
+// 10 ms step), this kernel reads the target once (134 MB) and is bound by the 19 exponentials per pixel.
+//
+// The mean reduction makes the gradient linear in one unknown scalar (1 / #valid pixels, times grad_out), so the
+// forward pass accumulates the UNSCALED low-res gradient and backward is a scale + cast of 6 M elements.
+//
+//   block  = 256 consecutive output columns x a band of output rows of one image; lane = one output column.
+//   The column taps (i0x, i1x, l0x, l1x) of a lane never change, and the row taps change only every ~scale rows, so
+//   the lane keeps the two horizontally interpolated low-res rows aA[c], aB[c] in registers: a logit is ONE FMA,
+//   z_c = l0y*aA[c] + l1y*aB[c].  Softmax, loss and dz_c = (p_c - [t == c]) stay in registers; dz is accumulated into
+//   gA[c] += l0y*dz_c, gB[c] += l1y*dz_c and only when the row tap advances is a finished low-res row scattered
+//   horizontally (LDS float atomics over the strip's <= 258 cells) and added to the f32 gradient (global atomics:
+//   ~650 per 8 output rows of a block, each address touched by <= 4 blocks).
+template <typename T, int CP>
+__global__ __launch_bounds__(NT) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
+                                                                 float* dlow, double* acc, int B, int C, int h, int w,
+                                                                 int H, int W, int ignore_index, int band_rows) {
+  constexpr int MAXCELL = NT + 2;
+  __shared__ float Acc[MAXCELL * CP];
   __shared__ double red[2][NT / 64];
-  const int W8 = W / 8;
-  const long groups = (long)B * H * W8;
+  const int tid = threadIdx.x;
+  const int nstrip = (W + NT - 1) / NT, nband = (H + band_rows - 1) / band_rows;
+  int bid = blockIdx.x;
+  const int strip = bid % nstrip; bid /= nstrip;
+  const int band = bid % nband;
+  const long b = bid / nband;
   const float sy = ac_scale(h, H), sx = ac_scale(w, W);
-  double lsum = 0.0, lcnt = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += (long)gridDim.x * blockDim.x) {
-    const int xg = (int)(i % W8);
-    long p = i / W8;
-    const int oy = (int)(p % H);
-    const long b = p / H;
-    const Tap ty = ac_tap(sy, oy, h);
-    Tap tx[8];
+  const int x = strip * NT + tid;
+  const bool xin = x < W;
+  const Tap tx = ac_tap(sx, xin ? x : W - 1, w);
+  const int cx0 = ac_tap(sx, strip * NT, w).i0;                     // first low-res column this strip touches
+  const int xl = (strip * NT + NT - 1 < W) ? strip * NT + NT - 1 : W - 1;
+  const int ncell = ac_tap(sx, xl, w).i1 - cx0 + 1;                 // <= NT + 2 for W >= w (host-checked)
+  const int ya = band * band_rows;
+  const int yb = ya + band_rows < H ? ya + band_rows : H;
+  for (int i = tid; i < MAXCELL * CP; i += NT) Acc[i] = 0.f;
+
+  float aA[CP], aB[CP], gA[CP], gB[CP];
+  auto load_row = [&](int r, float* a) {   // a[c] = l0x * L[r][i0x][c] + l1x * L[r][i1x][c]
+    const T* p0 = low + ((b * h + r) * (long)w + tx.i0) * ldl;
+    const T* p1 = low + ((b * h + r) * (long)w + tx.i1) * ldl;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tx[j] = ac_tap(sx, xg * 8 + j, w);
-    const T* r0 = low + ((b * h + ty.i0) * (long)w) * ldl;
-    const T* r1 = low + ((b * h + ty.i1) * (long)w) * ldl;
-    const long pix = (b * H + oy) * (long)W + xg * 8;
-    long long t[8];
+    for (int c4 = 0; c4 < CP; c4 += 4) {
+      float u[4], v[4];
+      V4<T>::load(p0 + c4, u);
+      V4<T>::load(p1 + c4, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = target[pix + j];
-    float m[8], s[8], lt[8];
+      for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? tx.l0 * u[q] + tx.l1 * v[q] : -TSS_INF;
+    }
+  };
+  // finished low-res row r: scatter g[] over the lane's two columns (LDS), then add the strip's cells to dlow
+  auto flush_row = [&](int r, const float* g) {
+    if (xin) {
+      float* c0 = Acc + (tx.i0 - cx0) * CP;
+      float* c1 = Acc + (tx.i1 - cx0) * CP;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; s[j] = 0.f; lt[j] = 0.f; }
-    for (int c = 0; c < C; ++c) {
-      int cached = -1;
-      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (tx[j].i0 != cached) {
-          a0 = (float)r0[(long)tx[j].i0 * ldl + c]; a1 = (float)r1[(long)tx[j].i0 * ldl + c];
-          b0 = (float)r0[(long)tx[j].i1 * ldl + c]; b1 = (float)r1[(long)tx[j].i1 * ldl + c];
-          cached = tx[j].i0;
-        }
-        const float v = ty.l0 * (tx[j].l0 * a0 + tx[j].l1 * b0) + ty.l1 * (tx[j].l0 * a1 + tx[j].l1 * b1);
-        const float mn = fmaxf(m[j], v);
-        s[j] = s[j] * __expf(m[j] - mn) + __expf(v - mn);
-        m[j] = mn;
-        if (t[j] == c) lt[j] = v;
+      for (int c = 0; c < CP; ++c) {
+        if (c < C) { atomicAdd(c0 + c, tx.l0 * g[c]); atomicAdd(c1 + c, tx.l1 * g[c]); }
       }
     }
-    float l[8];
-    unsigned long long packed = 0ull;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      l[j] = m[j] + __logf(s[j]);
-      const bool valid = t[j] != ignore_index;
-      if (valid) { lsum += (double)(l[j] - lt[j]); lcnt += 1.0; }
-      packed |= (unsigned long long)(valid ? (unsigned char)t[j] : 255u) << (8 * j);
+    __syncthreads();
+    float* drow = dlow + ((b * h + r) * (long)w + cx0) * ldl;
+    for (int i = tid; i < ncell * CP; i += NT) {
+      const int cell = i / CP, c = i - cell * CP;
+      const float v = Acc[i];
+      Acc[i] = 0.f;
+      if (c < C && v != 0.f) atomicAdd(drow + (long)cell * ldl + c, v);
     }
-    V8<float>::store(lse_out + pix, l);
-    *reinterpret_cast<unsigned long long*>(t8 + pix) = packed;
-  }
-  lsum = wave_sum(lsum);
-  lcnt = wave_sum(lcnt);
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { red[0][wave] = lsum; red[1][wave] = lcnt; }
+    __syncthreads();
+  };
+
+  int rA = ac_tap(sy, ya, h).i0;
+  int rB = rA + (rA < h - 1 ? 1 : 0);
+  load_row(rA, aA);
+  load_row(rB, aB);
+#pragma unroll
+  for (int c = 0; c < CP; ++c) { gA[c] = 0.f; gB[c] = 0.f; }
   __syncthreads();
-  if (threadIdx.x == 0) {
+
+  float lsum = 0.f, lcnt = 0.f;
+  const long long* trow = target + (b * H + ya) * (long)W + (xin ? x : 0);
+  long long tnext = *trow;
+  for (int y = ya; y < yb; ++y) {
+    const long long t = tnext;
+    if (y + 1 < yb) tnext = trow[(long)(y + 1 - ya) * W];      // next row's target under this row's arithmetic
+    const Tap ty = ac_tap(sy, y, h);                           // uniform over the block
+    if (ty.i0 != rA) {                                         // row tap advanced (by exactly one: H >= h)
+      flush_row(rA, gA);
+      rA = rB;
+      rB = rA + (rA < h - 1 ? 1 : 0);
+#pragma unroll
+      for (int c = 0; c < CP; ++c) { aA[c] = aB[c]; gA[c] = gB[c]; gB[c] = 0.f; }
+      load_row(rB, aB);
+    }
+    float z[CP];
+    float m = -TSS_INF;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      z[c] = (c < C) ? ty.l0 * aA[c] + ty.l1 * aB[c] : -TSS_INF;
+      m = fmaxf(m, z[c]);
+    }
+    float ssum = 0.f, zt = 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      if (t == c) zt = z[c];
+      z[c] = __expf(z[c] - m);          // e_c (0 for the padding classes)
+      ssum += z[c];
+    }
+    const bool valid = xin && t != ignore_index;
+    if (valid) { lsum += m + __logf(ssum) - zt; lcnt += 1.f; }
+    const float inv = valid ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+    const float one = valid ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float dz = z[c] * inv - (t == c ? one : 0.f);
+      gA[c] += ty.l0 * dz;
+      gB[c] += ty.l1 * dz;
+    }
+  }
+  flush_row(rA, gA);
+  if (rB != rA) flush_row(rB, gB);
+
+  double ds = wave_sum((double)lsum), dc = wave_sum((double)lcnt);
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { red[0][wave] = ds; red[1][wave] = dc; }
+  __syncthreads();
+  if (tid == 0) {
     double a = 0.0, c = 0.0;
     for (int wv = 0; wv < NT / 64; ++wv) { a += red[0][wv]; c += red[1][wv]; }
     atomicAdd(acc, a);
@@ -165,60 +226,17 @@ __global__ __launch_bounds__(NT) void upsample_ce_fwd_kernel(const T* low, long 
   }
 }
 
-// tmp[b][c][iy][ox] = sum_oy wy(oy, iy) * (softmax_c(oy, ox) - [t == c]) * valid / count * grad_out
+// dlow = (T)(dlow_acc * grad_out / count), 8 elements per lane
 template <typename T>
-__global__ __launch_bounds__(NT) void upsample_ce_bwd_rows_kernel(const T* low, long ldl, const unsigned char* t8,
-                                                                  const float* lse, const float* inv_count,
-                                                                  const float* grad_out, float* tmp,
-                                                                  int B, int C, int h, int w, int H, int W) {
-  const int W8 = W / 8;
-  const long total = (long)B * C * h * W8;
-  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+__global__ __launch_bounds__(NT) void upsample_ce_scale_kernel(const float* dacc, const float* inv_count,
+                                                               const float* grad_out, T* dlow, long n8) {
   const float gs = (*inv_count) * (grad_out ? *grad_out : 1.f);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int xg = (int)(i % W8);
-    long p = i / W8;
-    const int iy = (int)(p % h); p /= h;
-    const int c = (int)(p % C);
-    const long b = p / C;
-    Tap tx[8];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float v[8];
+    V8<float>::load(dacc + i * 8, v);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tx[j] = ac_tap(sx, xg * 8 + j, w);
-    int lo, hi;
-    ac_window(sy, iy, H, &lo, &hi);
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int oy = lo; oy <= hi; ++oy) {
-      const Tap ty = ac_tap(sy, oy, h);
-      float wy = 0.f;
-      if (ty.i0 == iy) wy += ty.l0;
-      if (ty.i1 == iy) wy += ty.l1;
-      if (wy == 0.f) continue;
-      const T* r0 = low + ((b * h + ty.i0) * (long)w) * ldl + c;
-      const T* r1 = low + ((b * h + ty.i1) * (long)w) * ldl + c;
-      const long pix = (b * H + oy) * (long)W + xg * 8;
-      float l[8];
-      V8<float>::load(lse + pix, l);
-      const unsigned long long tp = *reinterpret_cast<const unsigned long long*>(t8 + pix);
-      int cached = -1;
-      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (tx[j].i0 != cached) {
-          a0 = (float)r0[(long)tx[j].i0 * ldl]; a1 = (float)r1[(long)tx[j].i0 * ldl];
-          b0 = (float)r0[(long)tx[j].i1 * ldl]; b1 = (float)r1[(long)tx[j].i1 * ldl];
-          cached = tx[j].i0;
-        }
-        const float v = ty.l0 * (tx[j].l0 * a0 + tx[j].l1 * b0) + ty.l1 * (tx[j].l0 * a1 + tx[j].l1 * b1);
-        const int tj = (int)((tp >> (8 * j)) & 0xffu);
-        const float d = (tj == 255) ? 0.f : (__expf(v - l[j]) - (tj == c ? 1.f : 0.f));
-        acc[j] += wy * d;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] *= gs;
-    V8<float>::store(tmp + ((b * C + c) * (long)h + iy) * W + xg * 8, acc);
+    for (int j = 0; j < 8; ++j) v[j] *= gs;
+    V8<T>::store(dlow + i * 8, v);
   }
 }
 
@@ -332,45 +350,46 @@ int tss_argmax_confusion(const void* logits, const long long* target, unsigned c
   return tss::check_last("argmax_confusion");
 }
 
-int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* lse, unsigned char* target_u8,
+int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* dlow_acc /*[B][h][w][ldl] f32, zeroed*/,
                         double* acc /*[2], zeroed*/, float* loss, float* inv_count,
                         int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
-  TSS_REQUIRE(C > 0 && C < 255 && ldl >= C && (W % 8) == 0 && h > 0 && w > 0, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(lse) && (reinterpret_cast<uintptr_t>(target_u8) & 7u) == 0, TSS_ERR_ALIGN);
-  const long groups = (long)B * H * (W / 8);
-  if (groups == 0) return TSS_OK;
+  TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(low) && tss::aligned16(dlow_acc), TSS_ERR_ALIGN);
+  if ((long)B * H * W == 0) return TSS_OK;
   {
+    // bands: enough blocks to fill the chip, but every band pays two extra row flushes
+    const int nstrip = (W + NT - 1) / NT;
+    int band_rows = 64;
+    while (band_rows > 16 && (long)B * nstrip * ((H + band_rows - 1) / band_rows) < 1024) band_rows /= 2;
+    const long grid = (long)B * nstrip * ((H + band_rows - 1) / band_rows);
     tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream,
-                        (double)B * h * w * C * esz(dtype) + (double)B * H * W * 13.0, 0);
-    if (dtype == TSS_BF16)
-      hipLaunchKernelGGL(upsample_ce_fwd_kernel<bf16_t>, dim3(grid_for(groups)), dim3(NT), 0, (hipStream_t)stream,
-                         (const bf16_t*)low, ldl, target, lse, target_u8, acc, B, C, h, w, H, W, ignore_index);
-    else
-      hipLaunchKernelGGL(upsample_ce_fwd_kernel<float>, dim3(grid_for(groups)), dim3(NT), 0, (hipStream_t)stream,
-                         (const float*)low, ldl, target, lse, target_u8, acc, B, C, h, w, H, W, ignore_index);
+                        (double)B * h * w * C * (esz(dtype) + 8.0) + (double)B * H * W * 8.0, 0);
+#define TSS_CE_LAUNCH(TT, CPV)                                                                                   \
+    hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, \
+                       (const TT*)low, ldl, target, dlow_acc, acc, B, C, h, w, H, W, ignore_index, band_rows)
+    if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_LAUNCH(bf16_t, 20); else TSS_CE_LAUNCH(bf16_t, 24); }
+    else { if (C <= 20) TSS_CE_LAUNCH(float, 20); else TSS_CE_LAUNCH(float, 24); }
+#undef TSS_CE_LAUNCH
   }
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, loss, inv_count);
   return tss::check_last("upsample_ce_fwd");
 }
 
-int tss_upsample_ce_bwd_rows(const void* low, long ldl, const unsigned char* target_u8, const float* lse,
-                             const float* inv_count, const float* grad_out, float* tmp /*[B*C*h*W] f32*/,
-                             int B, int C, int h, int w, int H, int W, int dtype, void* stream) {
+int tss_upsample_ce_bwd(const float* dlow_acc, const float* inv_count, const float* grad_out, void* dlow,
+                        long n /* = B*h*w*ldl */, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
-  TSS_REQUIRE(C > 0 && C < 255 && ldl >= C && (W % 8) == 0 && h > 0 && w > 0, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(lse) && tss::aligned16(tmp), TSS_ERR_ALIGN);
-  const long total = (long)B * C * h * (W / 8);
-  if (total == 0) return TSS_OK;
-  tss::ProfScope prof(TSS_K_UPSAMPLE_CE_BWD_ROWS, (hipStream_t)stream,
-                      (double)B * H * W * 5.0 + (double)B * C * h * W * 4.0 + (double)B * h * w * C * esz(dtype), 0);
+  TSS_REQUIRE(n >= 0 && (n % 8) == 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dlow_acc) && tss::aligned16(dlow), TSS_ERR_ALIGN);
+  if (n == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_UPSAMPLE_CE_BWD, (hipStream_t)stream, (double)n * (4.0 + esz(dtype)), 0);
   if (dtype == TSS_BF16)
-    hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const bf16_t*)low, ldl, target_u8, lse, inv_count, grad_out, tmp, B, C, h, w, H, W);
+    hipLaunchKernelGGL(upsample_ce_scale_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(NT), 0, (hipStream_t)stream,
+                       dlow_acc, inv_count, grad_out, (bf16_t*)dlow, n / 8);
   else
-    hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
-                       (const float*)low, ldl, target_u8, lse, inv_count, grad_out, tmp, B, C, h, w, H, W);
-  return tss::check_last("upsample_ce_bwd_rows");
+    hipLaunchKernelGGL(upsample_ce_scale_kernel<float>, dim3(grid_for(n / 8)), dim3(NT), 0, (hipStream_t)stream,
+                       dlow_acc, inv_count, grad_out, (float*)dlow, n / 8);
+  return tss::check_last("upsample_ce_bwd");
 }
 
 }  // extern "C"

@@ -706,37 +706,32 @@ class CrossEntropyLoss(torch.nn.Module):
 
 
 class UpsampleCrossEntropyFn(Function):
-    """cross_entropy(F.interpolate(low, scale, bilinear, align_corners=True), target) without the full-res logits."""
+    """cross_entropy(F.interpolate(low, scale, bilinear, align_corners=True), target) without the full-res logits:
+    one pass yields the loss and the unscaled low-res gradient, backward scales it by grad_out / #valid."""
 
     @staticmethod
     def forward(ctx, low, target, ho, wo, ignore_index):
         B, C, h, w = low.shape
         dev = low.device
         target = target.contiguous()
-        lse = torch.empty((B, ho, wo), dtype=torch.float32, device=dev)
-        t8 = torch.empty((B, ho, wo), dtype=torch.uint8, device=dev)
+        dacc = torch.zeros((B, h, w, ld(low)), dtype=torch.float32, device=dev)
         acc = torch.zeros(2, dtype=torch.float64, device=dev)
         scal = torch.empty(2, dtype=torch.float32, device=dev)
-        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(lse), ptr(t8), ptr(acc), ptr(scal[0:1]),
+        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(dacc), ptr(acc), ptr(scal[0:1]),
              ptr(scal[1:2]), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
-        ctx.geom = (B, C, h, w, ho, wo, ld(low))
-        ctx.save_for_backward(low, t8, lse, scal)
+        ctx.geom = (B, C, h, w, ld(low), low.dtype)
+        ctx.save_for_backward(dacc, scal)
         return scal[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
-        low, t8, lse, scal = ctx.saved_tensors
-        B, C, h, w, ho, wo, ldl = ctx.geom
-        dev = low.device
+        dacc, scal = ctx.saved_tensors
+        B, C, h, w, ldl, dtype = ctx.geom
         gout = gout.to(torch.float32).contiguous()
-        dt, st = N.dtype_code(low.dtype), stream()
-        tmp = torch.empty((B * C * h * wo,), dtype=torch.float32, device=dev)
-        call('tss_upsample_ce_bwd_rows', ptr(low), ldl, ptr(t8), ptr(lse), ptr(scal[1:2]), ptr(gout), ptr(tmp),
-             B, C, h, w, ho, wo, dt, st)
-        base = torch.zeros((B, h, w, ldl), dtype=low.dtype, device=dev)   # padded channels must read as zeros
-        dlow = base.permute(0, 3, 1, 2)[:, :C]
-        call('tss_upsample_head_bwd_cols', ptr(tmp), ptr(dlow), ldl, B, C, h, w, wo, dt, st)
-        return dlow, None, None, None, None
+        base = torch.empty((B, h, w, ldl), dtype=dtype, device=dacc.device)   # pad channels of dacc are zero
+        call('tss_upsample_ce_bwd', ptr(dacc), ptr(scal[1:2]), ptr(gout), ptr(base), base.numel(),
+             N.dtype_code(dtype), stream())
+        return base.permute(0, 3, 1, 2)[:, :C], None, None, None, None
 
 
 def upsample_cross_entropy(low, target, scale_factor=None, size=None, ignore_index=-100):
@@ -745,10 +740,9 @@ def upsample_cross_entropy(low, target, scale_factor=None, size=None, ignore_ind
     computed from the low-resolution logits; the full-resolution logits are never materialised."""
     low = to_nhwc(materialize(low))
     ho, wo = _out_size(low, size, scale_factor)
-    if wo % 8:
-        raise NotImplementedError('HIP path: logits width must be a multiple of 8, got %d' % wo)
-    if low.shape[1] >= 255:
-        raise NotImplementedError('HIP path: fused head supports fewer than 255 classes')
+    if low.shape[1] > 24 or ho < low.shape[2] or wo < low.shape[3]:
+        # outside the one-pass kernel's envelope (class registers, upsampling only): same result, unfused
+        return cross_entropy(upsample_logits(low, size=(ho, wo)), target, ignore_index=ignore_index)
     if target.dtype != torch.int64 or tuple(target.shape) != (low.shape[0], ho, wo):
         raise RuntimeError('target must be int64 of shape (B,H,W) = %s' % ((low.shape[0], ho, wo),))
     _check_device(target)
