@@ -26,6 +26,13 @@ if which == 'dwfwd':
     wd = torch.randn(C, 1, 3, 3, device=dev); sd = torch.empty(S, 2 * C, dtype=torch.float64, device=dev)
     m = torch.zeros(C, device=dev); s1 = torch.ones(C, device=dev)
     fns['dwfwd'] = lambda: N.call('tss_dwconv3x3_fwd', N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(wd), N.ptr(yo), C, N.ptr(sd), B, H, W, C, 1, 1, 1, st)
+if which == 'ceup':
+    B, C, h, w, sc = 8, K, Nn, P, 8
+    low = ops.new_nhwc(B, C, h, w, torch.bfloat16, dev); low.normal_()
+    tgt = torch.randint(0, C, (B, h * sc, w * sc), device=dev)
+    dacc = torch.zeros((B, h, w, low.stride(3)), dtype=torch.float32, device=dev)
+    acc = torch.zeros(2, dtype=torch.float64, device=dev); scal = torch.empty(2, dtype=torch.float32, device=dev)
+    fns['ceup'] = lambda: N.call('tss_upsample_ce_fwd', N.ptr(low), low.stride(3), N.ptr(tgt), N.ptr(dacc), N.ptr(acc), N.ptr(scal[0:1]), N.ptr(scal[1:2]), B, C, h, w, h * sc, w * sc, 255, 1, st)
 for _ in range(10):
     fns[which]()
 torch.cuda.synchronize()

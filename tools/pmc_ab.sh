@@ -17,10 +17,10 @@ for sub in 'ab':
             agg[k][r['Counter_Name']] += float(r['Counter_Value']); 
             cnt[(k, r['Counter_Name'])] += 1
     for k, d in agg.items():
-        if 'pw' in k or 'wgrad' in k or 'convgemm' in k or 'dw_' in k:
+        if any(t in k for t in ('pw', 'wg', 'convgemm', 'dw_', 'upsample', 'ce_')):
             print('$tag', k, {c: round(v / cnt[(k, c)]) for c, v in d.items()})
 for f in glob.glob('$out/t/**/*kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(t in r['Name'] for t in ('pw', 'wgrad', 'convgemm', 'dw_')):
+        if any(t in r['Name'] for t in ('pw', 'wg', 'convgemm', 'dw_', 'upsample', 'ce_')):
             print('$tag', r['Name'][:60], 'avg_ns', r['AverageNs'])
 PY

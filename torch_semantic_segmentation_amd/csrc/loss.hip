@@ -102,15 +102,17 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
 //   The column taps (i0x, i1x, l0x, l1x) of a lane never change, and the row taps change only every ~scale rows, so
 //   the lane keeps the two horizontally interpolated low-res rows aA[c], aB[c] in registers: a logit is ONE FMA,
 //   z_c = l0y*aA[c] + l1y*aB[c].  Softmax, loss and dz_c = (p_c - [t == c]) stay in registers; dz is accumulated into
-//   gA[c] += l0y*dz_c, gB[c] += l1y*dz_c and only when the row tap advances is a finished low-res row scattered
-//   horizontally (LDS float atomics over the strip's <= 258 cells) and added to the f32 gradient (global atomics:
+//   gA[c] += l0y*dz_c, gB[c] += l1y*dz_c and only when the row tap advances is a finished low-res row gathered
+//   horizontally through LDS (one thread per low-res cell and class) and added to the f32 gradient (global atomics:
 //   ~650 per 8 output rows of a block, each address touched by <= 4 blocks).
 template <typename T, int CP>
-__global__ __launch_bounds__(NT) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
+__global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
                                                                  float* dlow, double* acc, int B, int C, int h, int w,
                                                                  int H, int W, int ignore_index, int band_rows) {
   constexpr int MAXCELL = NT + 2;
-  __shared__ float Acc[MAXCELL * CP];
+  __shared__ __align__(16) float G[NT * CP];          // per-lane gradients of the row being flushed
+  __shared__ int Li0[NT], Li1[NT], Wlo[MAXCELL], Whi[MAXCELL];
+  __shared__ float Ll1[NT];
   __shared__ double red[2][NT / 64];
   const int tid = threadIdx.x;
   const int nstrip = (W + NT - 1) / NT, nband = (H + band_rows - 1) / band_rows;
@@ -127,7 +129,16 @@ __global__ __launch_bounds__(NT) void upsample_ce_onepass_kernel(const T* low, l
   const int ncell = ac_tap(sx, xl, w).i1 - cx0 + 1;                 // <= NT + 2 for W >= w (host-checked)
   const int ya = band * band_rows;
   const int yb = ya + band_rows < H ? ya + band_rows : H;
-  for (int i = tid; i < MAXCELL * CP; i += NT) Acc[i] = 0.f;
+  Li0[tid] = xin ? tx.i0 - cx0 : -1;      // lanes past the image edge match no cell
+  Li1[tid] = xin ? tx.i1 - cx0 : -1;
+  Ll1[tid] = tx.l1;
+  for (int cell = tid; cell < ncell; cell += NT) {   // lanes of this strip whose taps can include low-res column cx0 + cell
+    int lo, hi;
+    ac_window(sx, cx0 + cell, W, &lo, &hi);
+    lo -= strip * NT; hi -= strip * NT;
+    Wlo[cell] = lo < 0 ? 0 : lo;
+    Whi[cell] = hi > NT - 1 ? NT - 1 : hi;
+  }
 
   float aA[CP], aB[CP], gA[CP], gB[CP];
   auto load_row = [&](int r, float* a) {   // a[c] = l0x * L[r][i0x][c] + l1x * L[r][i1x][c]
@@ -142,23 +153,25 @@ __global__ __launch_bounds__(NT) void upsample_ce_onepass_kernel(const T* low, l
       for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? tx.l0 * u[q] + tx.l1 * v[q] : -TSS_INF;
     }
   };
-  // finished low-res row r: scatter g[] over the lane's two columns (LDS), then add the strip's cells to dlow
+  // finished low-res row r: every lane parks its g[] in LDS (plain stores), then one thread per (cell, class) gathers
+  // the <= ~2*scale+4 lanes whose column taps include that cell and adds the sum to dlow.  (LDS float atomics for the
+  // scatter were measured at ~180 cycles per wave instruction: 550 us of a 790 us kernel.)
   auto flush_row = [&](int r, const float* g) {
-    if (xin) {
-      float* c0 = Acc + (tx.i0 - cx0) * CP;
-      float* c1 = Acc + (tx.i1 - cx0) * CP;
 #pragma unroll
-      for (int c = 0; c < CP; ++c) {
-        if (c < C) { atomicAdd(c0 + c, tx.l0 * g[c]); atomicAdd(c1 + c, tx.l1 * g[c]); }
-      }
-    }
+    for (int c4 = 0; c4 < CP; c4 += 4)
+      *reinterpret_cast<float4*>(G + tid * CP + c4) = make_float4(g[c4], g[c4 + 1], g[c4 + 2], g[c4 + 3]);
     __syncthreads();
     float* drow = dlow + ((b * h + r) * (long)w + cx0) * ldl;
     for (int i = tid; i < ncell * CP; i += NT) {
       const int cell = i / CP, c = i - cell * CP;
-      const float v = Acc[i];
-      Acc[i] = 0.f;
-      if (c < C && v != 0.f) atomicAdd(drow + (long)cell * ldl + c, v);
+      const int llo = Wlo[cell], lhi = Whi[cell];
+      float sum = 0.f;
+      for (int l = llo; l <= lhi; ++l) {
+        const float l1 = Ll1[l];
+        const float wgt = (Li0[l] == cell ? 1.f - l1 : 0.f) + (Li1[l] == cell ? l1 : 0.f);
+        sum += wgt * G[l * CP + c];
+      }
+      if (c < C && sum != 0.f) atomicAdd(drow + (long)cell * ldl + c, sum);
     }
     __syncthreads();
   };
@@ -193,20 +206,21 @@ __global__ __launch_bounds__(NT) void upsample_ce_onepass_kernel(const T* low, l
       z[c] = (c < C) ? ty.l0 * aA[c] + ty.l1 * aB[c] : -TSS_INF;
       m = fmaxf(m, z[c]);
     }
+    const bool valid = xin && t != ignore_index;
+    const int ti = (t >= 0 && t < CP) ? (int)t : -1;     // 32-bit compares below
     float ssum = 0.f, zt = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      if (t == c) zt = z[c];
+      if (ti == c) zt = z[c];
       z[c] = __expf(z[c] - m);          // e_c (0 for the padding classes)
       ssum += z[c];
     }
-    const bool valid = xin && t != ignore_index;
     if (valid) { lsum += m + __logf(ssum) - zt; lcnt += 1.f; }
     const float inv = valid ? __builtin_amdgcn_rcpf(ssum) : 0.f;
     const float one = valid ? 1.f : 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      const float dz = z[c] * inv - (t == c ? one : 0.f);
+      const float dz = z[c] * inv - (ti == c ? one : 0.f);
       gA[c] += ty.l0 * dz;
       gB[c] += ty.l1 * dz;
     }
@@ -361,7 +375,7 @@ int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, floa
     // bands: enough blocks to fill the chip, but every band pays two extra row flushes
     const int nstrip = (W + NT - 1) / NT;
     int band_rows = 64;
-    while (band_rows > 16 && (long)B * nstrip * ((H + band_rows - 1) / band_rows) < 1024) band_rows /= 2;
+    while (band_rows > 16 && (long)B * nstrip * ((H + band_rows - 1) / band_rows) < 2048) band_rows /= 2;
     const long grid = (long)B * nstrip * ((H + band_rows - 1) / band_rows);
     tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream,
                         (double)B * h * w * C * (esz(dtype) + 8.0) + (double)B * H * W * 8.0, 0);

@@ -111,7 +111,7 @@ def allreduce_mean_(flat, world_size, group=None):
 
 class Trainer:
     def __init__(self, model, optimizer, loss_fn, device=None, use_graph=False, world_size=1,
-                 non_blocking=True, fuse_head_loss=False):
+                 non_blocking=True, fuse_head_loss=True):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.device = device
         self.non_blocking = non_blocking
@@ -119,10 +119,9 @@ class Trainer:
         self.use_graph = use_graph
         self.flat = isinstance(optimizer, FlatAdamW)
         # model(x) followed by CrossEntropyLoss == the fused head+loss operator on model.forward_lowres(x): same
-        # value and gradients, but the full-resolution logits never exist (-1.3 GB at 8x1024x2048).  Only taken
-        # when nothing can observe the difference (our loss class, a model that offers forward_lowres, no hooks on
-        # the model itself).  Opt-in: in round 1 the fused backward (0.93 ms) is slower than the three kernels it
-        # replaces (0.48 ms) -- profiles/README.md.
+        # value and gradients, but the full-resolution logits never exist (-1.3 GB and ~0.8 ms at 8x1024x2048:
+        # one 0.26 ms kernel instead of five that move 3.8 GB).  Only taken when nothing can observe the difference
+        # (our loss class, a model that offers forward_lowres, no hooks on the model itself).
         self.fuse_head_loss = bool(fuse_head_loss) and isinstance(loss_fn, ops.CrossEntropyLoss) \
             and hasattr(model, 'forward_lowres') and hasattr(model, 'logit_scale')
         if self.flat:
@@ -225,7 +224,7 @@ class Trainer:
 
 
 def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False, logging=True,
-                                non_blocking=True, use_graph=False, world_size=None, fuse_head_loss=False):
+                                non_blocking=True, use_graph=False, world_size=None, fuse_head_loss=True):
     """Same arguments as TSS/engine.py:22.  `use_f16` selects bf16 activations (f32 master parameters), the
     MI355X counterpart of the reference's apex amp O2 branch (TSS/engine.py:32-34); no loss scaling is needed."""
     from .models import set_compute_dtype
