@@ -494,7 +494,7 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
   g.Hout = 1; g.Wout = 1;
   g.w = w; g.wrs = K; g.wcs = 1; g.wts = 0; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 768 && (N % 4) == 0) {   // lean bf16 kernels (pwfast.hip)
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 768) {   // lean bf16 kernels (pwfast.hip)
     tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * 2, 2.0 * (double)P * K * N);
     if (tss_pwfast_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, bias, y, ldy, stats, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_fwd");

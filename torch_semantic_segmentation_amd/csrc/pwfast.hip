@@ -637,7 +637,10 @@ int g_tss_disable_fast = 0;   // tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1): 
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream) {
-  if (g_tss_disable_fast || K > KTOT || (K % 8) != 0 || (N % 4) != 0 || P <= 0) return false;
+  // a ragged N (the 19-class classifier) is fine when there are no statistics and the row pitch has room for the
+  // zero the last 4-channel group writes into the padding
+  const bool n_ok = (N % 4) == 0 || (!stats && ldy >= (N + 3) / 4 * 4);
+  if (g_tss_disable_fast || K > KTOT || (K % 8) != 0 || !n_ok || P <= 0) return false;
   FastArgs g = {};
   g.P = P; g.K = K; g.N = N;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
