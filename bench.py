@@ -79,6 +79,30 @@ def algorithmic_step_bytes(model_name, batch, h, w, esz):
     return 3 * S_ref * scale * esz + 4 * U * esz + 8 * T
 
 
+def pmc_traffic(symbol, args):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this command, FETCH_SIZE doubled as the gfx950 note in
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed process, so the number is the
+    recorded one for the default workload; any other workload reports null."""
+    import glob
+    import json
+    if (args.model, args.batch, args.height, args.width, args.dtype) != ('fastscnn', 8, 1024, 2048, 'bf16'):
+        return None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None
+    table = json.load(open(files[-1]))
+    tot = n = 0.0
+    for alt in symbol.split('|'):
+        for k, v in table.items():
+            if k.startswith(alt.split('<')[0]) and (('<' not in alt) or k.startswith(alt)):
+                tot += v['hbm_bytes_per_launch'] * v['launches_sampled']
+                n += v['launches_sampled']
+        if n:
+            break       # the first alternative is the kernel the bf16 path actually runs
+    return round(tot / n) if n else None
+
+
 def host_cores():
     """Threads the CPU baseline uses: the cores this process may run on (cgroup/affinity aware), at most 16 --
     a gpurun box exposes 256 logical CPUs but grants a 16-core share per GPU, and torch oversubscribed on 256
@@ -228,7 +252,7 @@ def main():
         sym, top = max(by_symbol.items(), key=lambda kv: kv[1]['ms'])
         gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'kernel': sym, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(sym, args),
                     'launches_per_step': top['launches'] // nprof,
                     'avg_launch_us': round(1e3 * top['ms'] / top['launches'], 2),
                     'alg_bytes_per_launch': round(top['bytes'] / top['launches']),

@@ -10,8 +10,11 @@ namespace {
 
 struct KernelInfo { const char* name; const char* symbol; };
 const KernelInfo kInfo[TSS_K_COUNT] = {
-    // symbol = the template instantiation rocprofv3 lists: convgemm_kernel<T, HAS_A1> (false: forward, true: backward-data)
-    {"pwconv_fwd", "pwfast_kernel<fwd>|convgemm_kernel"}, {"pwconv_bwd_data", "pwfast_kernel<bwd>|convgemm_kernel"}, {"pwconv_bwd_weight", "wgrad_kernel"},
+    // symbol = the kernels rocprofv3 lists for the entry point on the bf16 path (rocprofv3 prints the bool template
+    // argument: <false> forward, <true> backward-data), then the general kernel the f32 / ragged shapes fall back to
+    {"pwconv_fwd", "pwfast_kernel<false>|pwfast_mc_kernel<false>|convgemm_kernel"},
+    {"pwconv_bwd_data", "pwfast_kernel<true>|pwfast_mc_kernel<true>|convgemm_kernel"},
+    {"pwconv_bwd_weight", "wgfast_kernel|wgrad_kernel"},
     {"conv3x3_fwd", "convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
     {"stem3x3_fwd", "stem_fwd_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_kernel"},
     {"dwconv3x3_fwd", "dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_strip_kernel"},
