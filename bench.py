@@ -95,7 +95,7 @@ def pmc_traffic(symbol, args):
     tot = n = 0.0
     for alt in symbol.split('|'):
         for k, v in table.items():
-            if k.startswith(alt.split('<')[0]) and (('<' not in alt) or k.startswith(alt)):
+            if k.startswith(alt.split('<')[0]) and (('<' not in alt) or k.startswith(alt.rstrip('>'))):
                 tot += v['hbm_bytes_per_launch'] * v['launches_sampled']
                 n += v['launches_sampled']
         if n:

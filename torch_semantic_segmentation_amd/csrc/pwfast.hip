@@ -97,11 +97,16 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
-template <bool BWD>
+// TM = pixels per tile.  Forward: 128.  Backward-data: 64 -- it stages two tensors (e, y) and needs the producer's raw
+// output in the epilogue; with 128-pixel tiles those registers leave no room to keep the next tile's loads in flight
+// (an attempt spilled 188 B/lane and lost), with 64-pixel tiles everything is prefetched and nothing spills.
+template <bool BWD, int TM>
 __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
+  constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
+  constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);
-  T* Ws = Xs + BM * RS;
+  T* Ws = Xs + TM * RS;
   float* Ec = reinterpret_cast<float*>(Ws + NCH * RS);   // [3][NCH] epilogue constants of this block's channels
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   const int nchunks = (g.N + NCH - 1) / NCH;
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int nc = slot % nchunks, gslot = slot / nchunks;
-  const long ntiles = (g.P + BM - 1) / BM;
+  const long ntiles = (g.P + TM - 1) / TM;
   const long per = (ntiles + 7) >> 3;
   const long t_begin = xcd * per + gslot;
   long t_end = xcd * per + per;
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   const int nvec = K >> 3;                 // 16-byte vectors per pixel row
   const int nvecp = kwp >> 3;
   const int rpp = NT / nvecp;              // rows staged per pass
-  const int npass = (BM + rpp - 1) / rpp;  // <= 8
+  const int npass = (TM + rpp - 1) / rpp;  // <= NP
   const int cv = tid % nvecp, r = tid / nvecp;
   const bool lane_on = r < rpp;            // lanes beyond rpp*nvecp idle during staging
   const bool cv_real = cv < nvec;          // vectors in [nvec, nvecp) are the zero padding of the last k-step
@@ -182,21 +187,21 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   // The A-tile loads of tile t+1 are issued right after tile t's registers have been stored to LDS, so the HBM round
   // trip runs under tile t's MFMA + epilogue instead of being exposed at the top of every tile (counters: 76 % of the
   // wave cycles were waits at 2 waves/SIMD).  ra/rb are dead between the LDS store and the next tile: no extra VGPRs.
-  uint4 ra[8], rb[8];
+  uint4 ra[NP], rb[NP];
   auto issue_loads = [&](long tile_) {
     if (lane_on) {
       // tile base + this lane's channel vector; rows outside the tile / the tensor re-read row 0 of the tile (always
       // valid) and are zeroed after the load, so no load is ever out of bounds and none is predicated
-      const long q0 = tile_ * BM;
-      const bool full_ = q0 + BM <= g.P;
+      const long q0 = tile_ * TM;
+      const bool full_ = q0 + TM <= g.P;
       const T* pa = g.a0 + q0 * g.lda0 + (cv_real ? cv * 8 : 0);
       const T* pb = BWD ? g.a1 + q0 * g.lda1 + (cv_real ? cv * 8 : 0) : nullptr;
       const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
+      for (int ps = 0; ps < NP; ++ps) {
         if (ps < npass) {
           const int row = ps * rpp + r;
-          const bool ok = row < BM && (full_ || q0 + row < g.P);
+          const bool ok = row < TM && (full_ || q0 + row < g.P);
           const int rr = ok ? row : 0;
           ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
           if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
@@ -207,17 +212,36 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   if (t_begin < t_end) issue_loads(t_begin);
 
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
-    const long p0 = tile * BM;
-    const bool full = p0 + BM <= g.P;
+    const long p0 = tile * TM;
+    const bool full = p0 + TM <= g.P;
     __syncthreads();  // previous tile's MFMA reads of Xs are done
+
+    // bwd: the producer's raw output under this lane's outputs, needed by the epilogue (ReLU mask, statistics).
+    // Issued here, behind the A-tile loads already in flight and ahead of the next tile's prefetch: loads return in
+    // order, so the transform below waits only for the A tile and the epilogue only for these.
+    uint2 rxm[4][MF];
+    if (BWD && g.xm) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nfr) {
+          const int nn = nlane + i * 16;
+          const T* px = g.xm + p0 * g.ldxm + (nn < g.N ? nn : n0);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int row = wm * (TM / 2) + m * 16 + fr;
+            rxm[i][m] = *reinterpret_cast<const uint2*>(px + (long)((full || p0 + row < g.P) ? row : 0) * g.ldxm);
+          }
+        }
+      }
+    }
 
     // ---- normalise + store the A tile whose loads are in flight
     if (lane_on) {
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) {
+      for (int ps = 0; ps < NP; ++ps) {
         if (ps < npass) {
           const int row = ps * rpp + r;
-          if (row < BM) {
+          if (row < TM) {
             const bool ok = cv_real && (full || p0 + row < g.P);
             const uint32_t* ua = reinterpret_cast<const uint32_t*>(&ra[ps]);
             const uint32_t* ub = reinterpret_cast<const uint32_t*>(&rb[ps]);
@@ -246,33 +270,32 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     __syncthreads();
 
     // ---- MFMA: D[n][p] += W[n][k] * A[p][k]
-    f32x4 acc[4][4];
+    f32x4 acc[MF][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MF; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (nfr > 0) {
-      const T* xrow = Xs + (wm * 64 + fr) * RS + fq * 8;
+      const T* xrow = Xs + (wm * (TM / 2) + fr) * RS + fq * 8;
       const T* wrow = Ws + (wn * 64 + fr) * RS + fq * 8;
       const int nks = kwp >> 5;
       for (int ks = 0; ks < nks; ++ks) {
-        bf16x8 xf[4];
+        bf16x8 xf[MF];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
+        for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i < nfr) {
             const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RS + ks * 32);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
+            for (int m = 0; m < MF; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
           }
         }
       }
     }
 
     // ---- epilogue
-    T* yrow = g.y + (p0 + wm * 64 + fr) * g.ldy + nlane;
-    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * 64 + fr) * g.ldxm + nlane : nullptr;
+    T* yrow = g.y + (p0 + wm * (TM / 2) + fr) * g.ldy + nlane;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nfr) {
@@ -288,14 +311,14 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
         const float cmm[4] = {e0.x, e0.y, e0.z, e0.w};                                 // bwd: mean / scale / bias
         const float cms[4] = {e1.x, e1.y, e1.z, e1.w}, cmb[4] = {e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const bool pin = full || (p0 + wm * 64 + m * 16 + fr < g.P);
+        for (int m = 0; m < MF; ++m) {
+          const bool pin = full || (p0 + wm * (TM / 2) + m * 16 + fr < g.P);
           if (pin && nin) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : acc[m][i][q] + bs[q];
             if (BWD && g.xm) {
-              const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
+              const uint2 xr = rxm[i][m];
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
               if (g.m_relu) {
 #pragma unroll
@@ -609,12 +632,11 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   hipLaunchKernelGGL(pwfast_mc_kernel<BWD>, dim3(grid), dim3(NT), kSmemMc, stream, g);
 }
 
-constexpr size_t kSmem = (size_t)(BM + NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
-
-template <bool BWD>
+template <bool BWD, int TM>
 void launch_fast(FastArgs& g, hipStream_t stream) {
+  constexpr size_t smem = (size_t)(TM + NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
   const int nchunks = (g.N + NCH - 1) / NCH;
-  const long ntiles = (g.P + BM - 1) / BM;
+  const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
   long cap = 64 / nchunks;
   if (cap < 1) cap = 1;
@@ -623,10 +645,10 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   const int grid = 8 * nchunks * (int)gs;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(pwfast_kernel<BWD>, dim3(grid), dim3(NT), kSmem, stream, g);
+  hipLaunchKernelGGL((pwfast_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
 }
 
 }  // namespace
@@ -645,7 +667,7 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.P = P; g.K = K; g.N = N;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
-  if (K <= KMAX) launch_fast<false>(g, stream); else launch_fast_mc<false>(g, stream);
+  if (K <= KMAX) launch_fast<false, 128>(g, stream); else launch_fast_mc<false>(g, stream);
   return true;
 }
 
@@ -660,6 +682,6 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  if (N <= KMAX) launch_fast<true>(g, stream); else launch_fast_mc<true>(g, stream);
+  if (N <= KMAX) launch_fast<true, 64>(g, stream); else launch_fast_mc<true>(g, stream);
   return true;
 }
