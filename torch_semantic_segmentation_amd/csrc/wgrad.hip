@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   const T* xg = reinterpret_cast<const T*>(g.x) + k0 + (onA ? cvA * 8 : 0);
 
   uint4 re[4], ry[4], rx[4];
-  auto issue = [&](long s) {
+  auto issue_g = [&](long s) {
     const long p0 = s * PT;
     if (onG) {
 #pragma unroll
@@ -376,6 +376,9 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
         ry[i] = *reinterpret_cast<const uint4*>(yg + pc * g.ldyr);
       }
     }
+  };
+  auto issue_a = [&](long s) {
+    const long p0 = s * PT;
     if (onA) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   auto blo = [](uint32_t u) { return __uint_as_float(u << 16); };
   auto bhi = [](uint32_t u) { return __uint_as_float(u & 0xffff0000u); };
 
-  if (s_begin < s_end) issue(s_begin);
+  if (s_begin < s_end) { issue_g(s_begin); issue_a(s_begin); }
   for (long s = s_begin; s < s_end; ++s) {
     const long p0 = s * PT;
     __syncthreads();   // MFMAs of the previous stage have read the tiles (first pass: the zero fill is complete)
@@ -416,6 +419,9 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(Gt, cvG * 8 + j, pgG), v[0][j], v[1][j], v[2][j], v[3][j]);
     }
+    // the G registers are free again: their next-stage loads go out before the A half is processed, so the memory
+    // pipe is never idle for this block (each half's loads fly under the other half's arithmetic and the MFMAs)
+    if (s + 1 < s_end) issue_g(s + 1);
     if (onA) {
       float v[4][8];
 #pragma unroll
@@ -435,8 +441,8 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(At, cvA * 8 + j, pgA), v[0][j], v[1][j], v[2][j], v[3][j]);
     }
+    if (s + 1 < s_end) issue_a(s + 1);
     __syncthreads();
-    if (s + 1 < s_end) issue(s + 1);
 
     if (cn > 0 && ck > 0) {
       const int rg = ib * 16 + fr, rk = jb * 16 + fr;
