@@ -60,13 +60,24 @@ __global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_rows_kernel(const T* dy,
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int oy = lo; oy <= hi; ++oy) {
-      const float wy = ac_weight(sy, oy, Hin, iy);
-      if (wy == 0.f) continue;
-      float v[8];
-      V8<T>::load(dy + ((b * Hout + oy) * (long)Wout + ox) * lddy + cv * 8, v);
+    // 4 window rows per trip, every load issued before the first use (a `continue` on a zero weight made each
+    // load its own dependent round trip: 32-64 of them for the 1-bin pyramid level); weight 0 just multiplies through
+    for (int o0 = lo; o0 <= hi; o0 += 4) {
+      typename V8<T>::Raw raw[4];
+      float wy[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wy * v[j];
+      for (int u = 0; u < 4; ++u) {
+        const int oy = o0 + u <= hi ? o0 + u : hi;
+        wy[u] = o0 + u <= hi ? ac_weight(sy, oy, Hin, iy) : 0.f;
+        raw[u] = V8<T>::load_raw(dy + ((b * Hout + oy) * (long)Wout + ox) * lddy + cv * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        V8<T>::unpack(raw[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy[u] != 0.f ? wy[u] * v[j] : 0.f;
+      }
     }
     V8<float>::store(tmp + ((b * Hin + iy) * (long)Wout + ox) * C + cv * 8, acc);
   }
@@ -89,13 +100,18 @@ __global__ __launch_bounds__(NT) void bilinear_nhwc_bwd_cols_kernel(const float*
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int ox = lo; ox <= hi; ++ox) {
-      const float wx = ac_weight(sx, ox, Win, ix);
-      if (wx == 0.f) continue;
-      float v[8];
-      V8<float>::load(tmp + ((b * Hin + iy) * (long)Wout + ox) * C + cv * 8, v);
+    for (int o0 = lo; o0 <= hi; o0 += 4) {
+      float v[4][8], wx[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += wx * v[j];
+      for (int u = 0; u < 4; ++u) {
+        const int ox = o0 + u <= hi ? o0 + u : hi;
+        wx[u] = o0 + u <= hi ? ac_weight(sx, ox, Win, ix) : 0.f;
+        V8<float>::load(tmp + ((b * Hin + iy) * (long)Wout + ox) * C + cv * 8, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wx[u] != 0.f ? wx[u] * v[u][j] : 0.f;
     }
     V8<T>::store(dx + ((b * Hin + iy) * (long)Win + ix) * lddx + cv * 8, acc);
   }
@@ -278,12 +294,25 @@ __global__ __launch_bounds__(NT) void adaptive_pool_fwd_kernel(const T* x, long 
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
   const int ww = x1 - x0, n = (y1 - y0) * ww;
   if (active) {
-    for (int k = pl; k < n; k += NPL) {
-      const int yy = y0 + k / ww, xx = x0 + k % ww;
-      float v[8];
-      V8<T>::load(x + ((b * H + yy) * (long)W + xx) * ldx + cg * 8, v);
+    // 8 independent loads in flight per lane (a one-bin pool walks 2048 pixels with 16 pixel lanes: 128 dependent
+    // round trips otherwise)
+    for (int k0 = pl; k0 < n; k0 += NPL * 8) {
+      typename V8<T>::Raw raw[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * NPL;
+        const int kk = k < n ? k : pl;
+        const int yy = y0 + kk / ww, xx = x0 + kk % ww;
+        raw[u] = V8<T>::load_raw(x + ((b * H + yy) * (long)W + xx) * ldx + cg * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float v[8];
+        V8<T>::unpack(raw[u], v);
+        const bool on = k0 + u * NPL < n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += on ? v[j] : 0.f;
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[pl * C + cg * 8 + j] = acc[j];
