@@ -84,11 +84,13 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats,
                         long P, int K, int N, int dtype, void* stream);
-/* dw[n][k] += sum_p g[p][n] * act(x[p][k])   (f32 atomics onto the caller's buffer) */
+/* dw[n][k] += sum_p g[p][n] * act(x[p][k]).  ws: f32 workspace of tss_pwconv_bwd_weight_ws(P, K, N, dtype) floats for the
+ * blocks' partial tiles (summed deterministically by a second kernel); ws NULL, or a size of 0: f32 atomics onto dw. */
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, long P, int K, int N, int dtype, void* stream);
+                          float* dw, float* ws, long P, int K, int N, int dtype, void* stream);
+long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype);
 
 /* ---- dense 3x3 convolution, padding = dilation ------------------------------------------------------
  * replaces: nn.Conv2d(128,128,3,padding=1) of ConvBlock TSS/models/contextnet.py:55 (and any Conv2dBlock k=3, Cin%8==0).

@@ -15,10 +15,12 @@ w = torch.randn(Nn, K, device=dev) * 0.1; dw = torch.zeros(Nn, K, device=dev)
 stats = torch.empty(S, 2 * Nn, dtype=torch.float64, device=dev); bst = torch.empty(S, 2 * K, dtype=torch.float64, device=dev)
 mK = torch.zeros(K, device=dev); sK = torch.ones(K, device=dev); mN = torch.zeros(Nn, device=dev); sN = torch.ones(Nn, device=dev)
 st = N.stream()
+nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1) if which == 'wgrad' else 0
+wsw = torch.empty(nws, device=dev) if nws and os.environ.get('TSS_WG_ATOMIC') != '1' else None
 fns = {
  'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
  'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), P, K, Nn, 1, st),
- 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), P, K, Nn, 1, st),
+ 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), P, K, Nn, 1, st),
 }
 if which in ('dwfwd', 'dwbwd', 'dwwg'):
     C, B, H, W = K, 8, Nn, P
@@ -40,3 +42,13 @@ if which == 'ceup':
 for _ in range(10):
     fns[which]()
 torch.cuda.synchronize()
+if os.environ.get('TSS_TIMING') == '1':
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    N.lib().tss_debug_wg_timing(buf, 1)
+    n = max(buf[7], 1)
+    names = ['barrier_in', 'G_half(wait+xform)', 'A_half', 'barrier_out', 'mfma', 'prologue', 'atomics_tail']
+    tot = sum(buf[q] for q in range(7))
+    for q in range(7):
+        print('%-20s %10.0f cycles/block  %5.1f %%' % (names[q], buf[q] / n, 100.0 * buf[q] / max(tot, 1)))
+    print('blocks', n // 10)

@@ -32,7 +32,8 @@ def _compile(src, force):
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
+    extra = ['-DTSS_TIMING'] if os.environ.get('TSS_TIMING') == '1' else []   # debug: phase timers in wgfast_kernel
+    cmd = [HIPCC] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, res.stdout, res.stderr))

@@ -54,6 +54,7 @@ struct WgradArgs {
   int Hin, Win, Hout, Wout, stride, dil, Cin;
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
+  float* ws;                       // wgfast: partial tiles [tile][2*nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
 };
 
 // transposing store of a 4-pixel x 8-channel unit: rows ch0..ch0+7, columns 4*pg .. 4*pg+3 (one 8/16-byte
@@ -293,10 +294,22 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
 //   * the four waves are assigned by tile shape: a tile narrower than 5 fragments in n or k is not split along that
 //     axis (those waves would idle) but along the pixel axis instead (each wave takes half of the k-steps);
 //   * PT = 128-pixel stages when both chunk widths are <= 64 channels, so that the staging still uses every thread.
+// workspace slot extent along one axis: min(dim, 128) rounded up to the 16-wide MFMA fragment
+__host__ __device__ inline int ws_dim(int d) { return ((d < TN ? d : TN) + 15) & ~15; }
+
+#ifdef TSS_TIMING
+// phase timing of wgfast_kernel (debug builds only: python -m ...build with TSS_TIMING=1): cycles summed over wave 0 of
+// every block for [barrier-in, G half (load wait + transform), A half, barrier-out, MFMA, prologue, atomics tail]
+__device__ unsigned long long g_wg_timing[8];
+#define TSS_T(var) unsigned long long var; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define TSS_T(var)
+#endif
 template <int PT>
 __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   typedef bf16_t T;
   constexpr int NPG = PT / 4, ROW = PT * 2 + 16, NKS = PT / 32;
+  TSS_T(tks);
   extern __shared__ __align__(16) unsigned char smem[];
   unsigned char* Gt = smem;
   unsigned char* At = smem + TN * ROW;
@@ -340,30 +353,13 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int i = tid; i < TN * ROW / 16; i += NT) {   // rows that are never staged must read as 0
-    reinterpret_cast<uint4*>(Gt)[i] = make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
-  }
-
-  // ---- this thread's units and their folded constants
+  // ---- this thread's units: one 4-pixel x 8-channel unit of each operand per stage
   const int pgG = tid / nvn, cvG = tid - pgG * nvn;
   const int pgA = tid / nvk, cvA = tid - pgA * nvk;
   const bool onG = pgG < NPG, onA = pgA < NPG;
-  float ca[8], cb[8], cc[8], as[8], ab[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int chn = n0 + (onG ? cvG * 8 : 0) + j, chk = k0 + (onA ? cvA * 8 : 0) + j;
-    const float ga = g.ga[chn], gb = g.gb[chn];
-    ca[j] = ga; cb[j] = gb; cc[j] = -(ga * g.gce[chn]) - gb * g.gmu[chn];      // g = ga*e + gb*y + cc
-    const float sc = g.xs ? g.xs[chk] : 1.f;
-    as[j] = sc; ab[j] = g.xs ? (g.xb ? g.xb[chk] : 0.f) - (g.xm ? g.xm[chk] : 0.f) * sc : 0.f;   // a = relu?(x*as + ab)
-  }
-  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
-
   const T* eg = reinterpret_cast<const T*>(g.e) + n0 + (onG ? cvG * 8 : 0);
   const T* yg = reinterpret_cast<const T*>(g.yraw) + n0 + (onG ? cvG * 8 : 0);
   const T* xg = reinterpret_cast<const T*>(g.x) + k0 + (onA ? cvA * 8 : 0);
-
   uint4 re[4], ry[4], rx[4];
   auto issue_g = [&](long s) {
     const long p0 = s * PT;
@@ -395,10 +391,50 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   auto blo = [](uint32_t u) { return __uint_as_float(u << 16); };
   auto bhi = [](uint32_t u) { return __uint_as_float(u & 0xffff0000u); };
 
+#ifdef TSS_TIMING
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
+  // first stage's loads go out before anything else: the block's set-up (LDS clear, constants) runs under them
   if (s_begin < s_end) { issue_g(s_begin); issue_a(s_begin); }
+
+  for (int i = tid; i < TN * ROW / 16; i += NT) {   // rows that are never staged must read as 0
+    reinterpret_cast<uint4*>(Gt)[i] = make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(At)[i] = make_uint4(0, 0, 0, 0);
+  }
+  // folded constants of this thread's channel vectors: unconditional 16-byte loads (a `ptr ? ptr[i] : c` per element
+  // compiles to a branch + wait per load: ~15 us of dependent round trips per block before this was hoisted)
+  float ca[8], cb[8], cc[8], as[8], ab[8];
+  {
+    const int chn = n0 + (onG ? cvG * 8 : 0), chk = k0 + (onA ? cvA * 8 : 0);
+    const float* pxs = g.xs ? g.xs : g.ga;      // any readable address when the input has no pending BatchNorm
+    const float* pxb = (g.xs && g.xb) ? g.xb : g.ga;
+    const float* pxm = (g.xs && g.xm) ? g.xm : g.ga;
+    const int cks = g.xs ? chk : 0;
+    float vga[8], vgb[8], vce[8], vmu[8], vs[8], vb[8], vm[8];
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      V4<float>::load(g.ga + chn + h, vga + h); V4<float>::load(g.gb + chn + h, vgb + h);
+      V4<float>::load(g.gce + chn + h, vce + h); V4<float>::load(g.gmu + chn + h, vmu + h);
+      V4<float>::load(pxs + cks + h, vs + h); V4<float>::load(pxb + cks + h, vb + h); V4<float>::load(pxm + cks + h, vm + h);
+    }
+    const bool has_s = g.xs != nullptr, has_b = has_s && g.xb != nullptr, has_m = has_s && g.xm != nullptr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ca[j] = vga[j]; cb[j] = vgb[j]; cc[j] = -(vga[j] * vce[j]) - vgb[j] * vmu[j];      // g = ga*e + gb*y + cc
+      const float sc = has_s ? vs[j] : 1.f;
+      as[j] = sc; ab[j] = (has_b ? vb[j] : 0.f) - (has_m ? vm[j] : 0.f) * sc;             // a = relu?(x*as + ab)
+    }
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+  TSS_T(tk1);
+#ifdef TSS_TIMING
+  tph[5] += tk1 - tks;
+#endif
   for (long s = s_begin; s < s_end; ++s) {
     const long p0 = s * PT;
+    TSS_T(t0);
     __syncthreads();   // MFMAs of the previous stage have read the tiles (first pass: the zero fill is complete)
+    TSS_T(t1);
     if (onG) {
       float v[4][8];
 #pragma unroll
@@ -419,6 +455,7 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(Gt, cvG * 8 + j, pgG), v[0][j], v[1][j], v[2][j], v[3][j]);
     }
+    TSS_T(t2);
     // the G registers are free again: their next-stage loads go out before the A half is processed, so the memory
     // pipe is never idle for this block (each half's loads fly under the other half's arithmetic and the MFMAs)
     if (s + 1 < s_end) issue_g(s + 1);
@@ -442,7 +479,9 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
       for (int j = 0; j < 8; ++j) Pack4<T>::put(unit_ptr(At, cvA * 8 + j, pgA), v[0][j], v[1][j], v[2][j], v[3][j]);
     }
     if (s + 1 < s_end) issue_a(s + 1);
+    TSS_T(t3);
     __syncthreads();
+    TSS_T(t4);
 
     if (cn > 0 && ck > 0) {
       const int rg = ib * 16 + fr, rk = jb * 16 + fr;
@@ -462,9 +501,33 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
             if (i < cn && j < ck) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], af[j], acc[i][j], 0, 0, 0);
       }
     }
+    TSS_T(t5);
+#ifdef TSS_TIMING
+    tph[0] += t1 - t0; tph[1] += t2 - t1; tph[2] += t3 - t2; tph[3] += t4 - t3; tph[4] += t5 - t4;
+#endif
   }
 
-  if (s_begin < s_end) {
+  TSS_T(tkl);
+  if (g.ws) {
+    // partial tile -> this block's workspace slot, row-major [n_local][k_local] (plain stores; blocks without stages
+    // write their zeros).  Waves that split the pixels of a stage own one of two slots.  wg_reduce_kernel sums the
+    // slots: measured on the 128x128 layer at 1/8 resolution the f32 atomics of 512 blocks onto one 64 KB tile cost
+    // 42 us of an 86 us kernel whose streaming loop already runs at HBM speed.
+    const int tile = kc * nchn + nc;
+    const int slot = split * 2 + ((FN > 4 && FK > 4) ? 0 : (wave & 1));
+    const int TNe = ws_dim(g.ND), TKe = ws_dim(g.KD);     // slot = the largest tile of this layer, 16-padded
+    float* wt = g.ws + ((long)tile * 2 * g.nsplit + slot) * (TNe * TKe);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (i < cn && j < ck) {
+          const int kl = (jb + j) * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) wt[((ib + i) * 16 + fq * 4 + r) * TKe + kl] = acc[i][j][r];
+        }
+      }
+  } else if (s_begin < s_end) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -479,26 +542,88 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
         }
       }
   }
+#ifdef TSS_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_T(tk2);
+  tph[6] = tk2 - tkl;
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 7; ++q) atomicAdd(&g_wg_timing[q], tph[q]);
+    atomicAdd(&g_wg_timing[7], 1ull);
+  }
+#endif
+}
+
+// dW[n][k] += sum over the workspace slots of a tile.  64 consecutive elements of a slot per block, lanes along them
+// (256-byte loads), 16 waves over the slots with up to 32 loads in flight per lane.
+constexpr int WR_WAVES = 16;
+__global__ __launch_bounds__(WR_WAVES * 64) void wg_reduce_kernel(const float* ws, float* dw, int nsplit, int nchn,
+                                                                 int ND, int KD, long drs, long dcs) {
+  __shared__ float part[WR_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int TNe = ws_dim(ND), TKe = ws_dim(KD);
+  const int slot_n = TNe * TKe, segs = slot_n >> 6;               // multiple of 256 elements: whole segments
+  const int tile = blockIdx.x / segs, seg = blockIdx.x - tile * segs;
+  const int idx = seg * 64 + lane;
+  const int nl = idx / TKe, kl = idx - nl * TKe;
+  const int nc = tile % nchn, kc = tile / nchn;
+  const int n = nc * TN + nl, k = kc * TK + kl;
+  const int ncw = (ND - nc * TN < TN) ? (ND - nc * TN) : TN, kcw = (KD - kc * TK < TK) ? (KD - kc * TK) : TK;
+  const int FN = (ncw + 15) >> 4, FK = (kcw + 15) >> 4;
+  const bool unsplit = FN > 4 && FK > 4;                           // those roles only fill the even slots
+  const int rows = nsplit * (unsplit ? 1 : 2), rstep = unsplit ? 2 : 1;
+  const bool valid = nl < FN * 16 && kl < FK * 16;                 // written by the blocks of this tile
+  const float* col = ws + (long)tile * 2 * nsplit * slot_n + (valid ? idx : 0);
+  float sacc = 0.f;
+  for (int r0 = wave; r0 < rows; r0 += WR_WAVES * 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) { const int r = r0 + WR_WAVES * u; v[u] = col[(long)((r < rows ? r : 0) * rstep) * slot_n]; }
+#pragma unroll
+    for (int u = 0; u < 32; ++u) sacc += (r0 + WR_WAVES * u < rows) ? v[u] : 0.f;
+  }
+  part[wave][lane] = sacc;
+  __syncthreads();
+  if (threadIdx.x < 64 && valid && n < ND && k < KD) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < WR_WAVES; ++q) t += part[q][threadIdx.x];
+    dw[(long)n * drs + (long)k * dcs] += t;
+  }
 }
 
 template <int PT>
-void launch_fast_pt(WgradArgs& g, hipStream_t stream) {
+long fast_split(const WgradArgs& g, int* tiles_out) {
   const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
   const int tiles = nchn * nchk;
   const long nstage = (g.P + PT - 1) / PT;
-  constexpr long MIN_STAGES = 512 / PT;   // a block amortises its LDS clear + atomics over >= 512 pixels
+  constexpr long MIN_STAGES = 512 / PT;   // a block amortises its LDS clear + partial tile over >= 512 pixels
   long ns = 1024 / tiles;
   if (ns < 1) ns = 1;
   if (ns > (nstage + MIN_STAGES - 1) / MIN_STAGES) ns = (nstage + MIN_STAGES - 1) / MIN_STAGES;
   if (ns < 1) ns = 1;
-  g.nsplit = (int)ns;
+  *tiles_out = tiles;
+  return ns;
+}
+
+template <int PT>
+void launch_fast_pt(WgradArgs& g, hipStream_t stream) {
+  int tiles;
+  g.nsplit = (int)fast_split<PT>(g, &tiles);
   constexpr int smem = 2 * TN * (PT * 2 + 16);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgfast_kernel<PT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(tiles * (int)ns), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(tiles * g.nsplit), dim3(NT), smem, stream, g);
+  if (g.ws)
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(tiles * (ws_dim(g.ND) * ws_dim(g.KD) / 64)), dim3(WR_WAVES * 64), 0, stream, g.ws, g.dw, g.nsplit,
+                       (g.ND + TN - 1) / TN, g.ND, g.KD, g.drs, g.dcs);
+}
+
+inline bool fast_uses_pt128(int K, int N) {
+  const int wn = N < TN ? N : TN, wk = K < TK ? K : TK;
+  return (wn > wk ? wn : wk) <= 64;
 }
 
 int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
@@ -535,7 +660,7 @@ extern "C" {
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, long P, int K, int N, int dtype, void* stream) {
+                          float* dw, float* ws, long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldx % 8) == 0 && ldx >= K, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gce && gmu), TSS_ERR_SHAPE);
@@ -549,12 +674,21 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   const double bytes = (double)P * (N * (yraw ? 2 : 1) + K) * esz(dtype);
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && (N % 8) == 0 && P > 0) {   // lean pipelined kernel
     tss::ProfScope prof(TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)P * N * K);
-    const int wmax = (N < TN ? N : TN) > (K < TK ? K : TK) ? (N < TN ? N : TN) : (K < TK ? K : TK);
-    if (wmax <= 64) launch_fast_pt<128>(g, (hipStream_t)stream);
+    g.ws = ws;
+    if (fast_uses_pt128(K, N)) launch_fast_pt<128>(g, (hipStream_t)stream);
     else launch_fast_pt<64>(g, (hipStream_t)stream);
     return tss::check_last("wgfast");
   }
   return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes);
+}
+
+long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype) {
+  if (dtype != TSS_BF16 || g_tss_disable_fast || (N % 8) != 0 || (K % 8) != 0 || P <= 0) return 0;
+  WgradArgs g = {};
+  g.P = P; g.ND = N; g.KD = K;
+  int tiles;
+  const long ns = fast_uses_pt128(K, N) ? fast_split<128>(g, &tiles) : fast_split<64>(g, &tiles);
+  return (long)tiles * 2 * ns * ws_dim(N) * ws_dim(K);
 }
 
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
@@ -600,5 +734,13 @@ int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   }
   return launch(g, dtype, TSS_K_STEM_BWD_WEIGHT, (hipStream_t)stream, bytes);
 }
+
+#ifdef TSS_TIMING
+int tss_debug_wg_timing(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_wg_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg_timing), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -369,7 +369,9 @@ class ConvUnitFn(Function):
             xargs = (ptr(x), ld(x), *_aff(il), int(cfg.in_relu))
             deferred_in = il is not None or cfg.in_relu
             if cfg.kind == 'pw':
-                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), P, Cin, Cout, dt, wst)
+                nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
+                ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
                 call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, wst)
