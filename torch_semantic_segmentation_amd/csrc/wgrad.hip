@@ -54,7 +54,7 @@ struct WgradArgs {
   int Hin, Win, Hout, Wout, stride, dil, Cin;
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
-  float* ws;                       // wgfast: partial tiles [tile][2*nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
+  float* ws;                       // wgfast: partial tiles [tile][nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
 };
 
 // transposing store of a 4-pixel x 8-channel unit: rows ch0..ch0+7, columns 4*pg .. 4*pg+3 (one 8/16-byte
@@ -510,23 +510,44 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   TSS_T(tkl);
   if (g.ws) {
     // partial tile -> this block's workspace slot, row-major [n_local][k_local] (plain stores; blocks without stages
-    // write their zeros).  Waves that split the pixels of a stage own one of two slots.  wg_reduce_kernel sums the
-    // slots: measured on the 128x128 layer at 1/8 resolution the f32 atomics of 512 blocks onto one 64 KB tile cost
-    // 42 us of an 86 us kernel whose streaming loop already runs at HBM speed.
-    const int tile = kc * nchn + nc;
-    const int slot = split * 2 + ((FN > 4 && FK > 4) ? 0 : (wave & 1));
-    const int TNe = ws_dim(g.ND), TKe = ws_dim(g.KD);     // slot = the largest tile of this layer, 16-padded
-    float* wt = g.ws + ((long)tile * 2 * g.nsplit + slot) * (TNe * TKe);
+    // write their zeros); wg_reduce_kernel sums the slots.  Measured on the 128x128 layer at 1/8 resolution: the f32
+    // atomics of 512 blocks onto one 64 KB tile cost 42 us of an 86 us kernel whose streaming loop already runs at
+    // HBM speed.  Waves that split the pixels of a stage (same fragment window, other k-steps) first meet in LDS.
+    const bool psplit = !(FN > 4 && FK > 4);
+    if (psplit) {
+      __syncthreads();                                   // the tiles are dead: reuse them as the exchange buffer
+      f32x4* xch = reinterpret_cast<f32x4*>(smem) + (wave >> 1) * 16 * 64;
+      if (wave & 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (i < cn && j < ck) {
-          const int kl = (jb + j) * 16 + fr;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) wt[((ib + i) * 16 + fq * 4 + r) * TKe + kl] = acc[i][j][r];
-        }
+          for (int j = 0; j < 4; ++j)
+            if (i < cn && j < ck) xch[(i * 4 + j) * 64 + lane] = acc[i][j];
       }
+      __syncthreads();
+      if (!(wave & 1)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (i < cn && j < ck) acc[i][j] += xch[(i * 4 + j) * 64 + lane];
+      }
+    }
+    if (!psplit || !(wave & 1)) {
+      const int tile = kc * nchn + nc;
+      const int TNe = ws_dim(g.ND), TKe = ws_dim(g.KD);     // slot = the largest tile of this layer, 16-padded
+      float* wt = g.ws + ((long)tile * g.nsplit + split) * (TNe * TKe);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (i < cn && j < ck) {
+            const int kl = (jb + j) * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wt[((ib + i) * 16 + fq * 4 + r) * TKe + kl] = acc[i][j][r];
+          }
+        }
+    }
   } else if (s_begin < s_end) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -553,41 +574,45 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #endif
 }
 
-// dW[n][k] += sum over the workspace slots of a tile.  64 consecutive elements of a slot per block, lanes along them
-// (256-byte loads), 16 waves over the slots with up to 32 loads in flight per lane.
-constexpr int WR_WAVES = 16;
+// dW[n][k] += sum over the workspace slots of a tile.  A block sums 256 consecutive elements of the slots (one float4
+// per lane: 1 KB per wave load), its 4 waves taking slots w, w+4, ... with up to 16 loads in flight per lane.
+constexpr int WR_WAVES = 4;
 __global__ __launch_bounds__(WR_WAVES * 64) void wg_reduce_kernel(const float* ws, float* dw, int nsplit, int nchn,
                                                                  int ND, int KD, long drs, long dcs) {
-  __shared__ float part[WR_WAVES][64];
+  __shared__ float4 part[WR_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int TNe = ws_dim(ND), TKe = ws_dim(KD);
-  const int slot_n = TNe * TKe, segs = slot_n >> 6;               // multiple of 256 elements: whole segments
+  const int slot_n = TNe * TKe, segs = slot_n >> 8;               // slot_n is a multiple of 256
   const int tile = blockIdx.x / segs, seg = blockIdx.x - tile * segs;
-  const int idx = seg * 64 + lane;
+  const int idx = seg * 256 + lane * 4;                           // 4 consecutive k of one row (TKe % 16 == 0)
   const int nl = idx / TKe, kl = idx - nl * TKe;
   const int nc = tile % nchn, kc = tile / nchn;
-  const int n = nc * TN + nl, k = kc * TK + kl;
   const int ncw = (ND - nc * TN < TN) ? (ND - nc * TN) : TN, kcw = (KD - kc * TK < TK) ? (KD - kc * TK) : TK;
   const int FN = (ncw + 15) >> 4, FK = (kcw + 15) >> 4;
-  const bool unsplit = FN > 4 && FK > 4;                           // those roles only fill the even slots
-  const int rows = nsplit * (unsplit ? 1 : 2), rstep = unsplit ? 2 : 1;
   const bool valid = nl < FN * 16 && kl < FK * 16;                 // written by the blocks of this tile
-  const float* col = ws + (long)tile * 2 * nsplit * slot_n + (valid ? idx : 0);
-  float sacc = 0.f;
-  for (int r0 = wave; r0 < rows; r0 += WR_WAVES * 32) {
-    float v[32];
+  const float* col = ws + (long)tile * nsplit * slot_n + (valid ? idx : 0);
+  float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r0 = wave; r0 < nsplit; r0 += WR_WAVES * 16) {
+    float4 v[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) { const int r = r0 + WR_WAVES * u; v[u] = col[(long)((r < rows ? r : 0) * rstep) * slot_n]; }
+    for (int u = 0; u < 16; ++u) { const int r = r0 + WR_WAVES * u; v[u] = *reinterpret_cast<const float4*>(col + (long)(r < nsplit ? r : 0) * slot_n); }
 #pragma unroll
-    for (int u = 0; u < 32; ++u) sacc += (r0 + WR_WAVES * u < rows) ? v[u] : 0.f;
+    for (int u = 0; u < 16; ++u) {
+      if (r0 + WR_WAVES * u < nsplit) { sacc.x += v[u].x; sacc.y += v[u].y; sacc.z += v[u].z; sacc.w += v[u].w; }
+    }
   }
   part[wave][lane] = sacc;
   __syncthreads();
-  if (threadIdx.x < 64 && valid && n < ND && k < KD) {
-    float t = 0.f;
+  if (threadIdx.x < 64 && valid) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < WR_WAVES; ++q) t += part[q][threadIdx.x];
-    dw[(long)n * drs + (long)k * dcs] += t;
+    for (int q = 0; q < WR_WAVES; ++q) { const float4 p4 = part[q][threadIdx.x]; t[0] += p4.x; t[1] += p4.y; t[2] += p4.z; t[3] += p4.w; }
+    const int n = nc * TN + nl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = kc * TK + kl + q;
+      if (n < ND && k < KD) dw[(long)n * drs + (long)k * dcs] += t[q];
+    }
   }
 }
 
@@ -617,7 +642,7 @@ void launch_fast_pt(WgradArgs& g, hipStream_t stream) {
   }
   hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(tiles * g.nsplit), dim3(NT), smem, stream, g);
   if (g.ws)
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3(tiles * (ws_dim(g.ND) * ws_dim(g.KD) / 64)), dim3(WR_WAVES * 64), 0, stream, g.ws, g.dw, g.nsplit,
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(tiles * (ws_dim(g.ND) * ws_dim(g.KD) / 256)), dim3(WR_WAVES * 64), 0, stream, g.ws, g.dw, g.nsplit,
                        (g.ND + TN - 1) / TN, g.ND, g.KD, g.drs, g.dcs);
 }
 
@@ -688,7 +713,7 @@ long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype) {
   g.P = P; g.ND = N; g.KD = K;
   int tiles;
   const long ns = fast_uses_pt128(K, N) ? fast_split<128>(g, &tiles) : fast_split<64>(g, &tiles);
-  return (long)tiles * 2 * ns * ws_dim(N) * ws_dim(K);
+  return (long)tiles * ns * ws_dim(N) * ws_dim(K);
 }
 
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
