@@ -150,30 +150,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   const bool lane_on = r < rpp;            // lanes beyond rpp*nvecp idle during staging
   const bool cv_real = cv < nvec;          // vectors in [nvec, nvecp) are the zero padding of the last k-step
 
-  // ---- weights -> LDS once per block (resident): Ws[n][k], zero beyond ncw / K
-  stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, 0, K, kwp, tid);
-
-  // ---- this lane's prologue coefficients (registers), mean folded into the additive term
-  float k0[8], k1[8], kadd[8];
-  const float relu_lo = g.a_relu ? 0.f : -TSS_INF;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; kadd[j] = 0.f; }
-  if (lane_on && cv_real) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = cv * 8 + j;
-      if (BWD) {       // g = c0*(e - c2) + c1*(y - c3)
-        const float ga = g.c0 ? g.c0[ch] : 1.f, gb = g.c1 ? g.c1[ch] : 0.f;
-        k0[j] = ga; k1[j] = gb;
-        kadd[j] = -(ga * (g.c2 ? g.c2[ch] : 0.f)) - gb * (g.c3 ? g.c3[ch] : 0.f);
-      } else {         // a = (x - c1)*c0 + c2
-        const float sc = g.c0 ? g.c0[ch] : 1.f;
-        k0[j] = sc;
-        kadd[j] = (g.c2 ? g.c2[ch] : 0.f) - (g.c1 ? g.c1[ch] : 0.f) * sc;
-      }
-    }
-  }
-
   float st1[4][4], st2[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -210,6 +186,40 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     }
   };
   if (t_begin < t_end) issue_loads(t_begin);
+
+  // block set-up under the first tile's loads
+  // ---- weights -> LDS once per block (resident): Ws[n][k], zero beyond ncw / K
+  stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, 0, K, kwp, tid);
+
+  // ---- this lane's prologue coefficients (registers), mean folded into the additive term.  Unconditional 16-byte
+  // loads through null-safe pointers: a `ptr ? ptr[i] : c` per element is a branch + wait per load.
+  float k0[8], k1[8], kadd[8];
+  const float relu_lo = g.a_relu ? 0.f : -TSS_INF;
+  {
+    const float* safe = g.w;                                   // any readable f32 address for absent vectors
+    const int ch = (lane_on && cv_real) ? cv * 8 : 0;
+    const float* p0c = g.c0 ? g.c0 + ch : safe; const float* p1c = g.c1 ? g.c1 + ch : safe;
+    const float* p2c = g.c2 ? g.c2 + ch : safe; const float* p3c = (BWD && g.c3) ? g.c3 + ch : safe;
+    float v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      V4<float>::load(p0c + h, v0 + h); V4<float>::load(p1c + h, v1 + h);
+      V4<float>::load(p2c + h, v2 + h); V4<float>::load(p3c + h, v3 + h);
+    }
+    const bool on = lane_on && cv_real;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float c0v = (on && g.c0) ? v0[j] : 1.f, c1v = (on && g.c1) ? v1[j] : 0.f;
+      const float c2v = (on && g.c2) ? v2[j] : 0.f, c3v = (on && BWD && g.c3) ? v3[j] : 0.f;
+      if (BWD) {       // g = c0*(e - c2) + c1*(y - c3)
+        k0[j] = c0v; k1[j] = c1v; kadd[j] = -(c0v * c2v) - c1v * c3v;
+      } else {         // a = (x - c1)*c0 + c2
+        k0[j] = c0v; k1[j] = 0.f; kadd[j] = c2v - c1v * c0v;
+      }
+    }
+  }
+
+  __syncthreads();
 
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * TM;
