@@ -69,6 +69,19 @@ __device__ __forceinline__ void stage_weights(float* wl, const float* w, int C, 
   }
 }
 
+// 8 per-channel constants of a lane: two unconditional 16-byte loads through a null-safe pointer, then a select
+// (a `ptr ? ptr[c] : dflt` per element compiles to a branch and a wait per load: a serial chain of L2 round trips at
+// the top of every block)
+__device__ __forceinline__ void coef8(const float* p, const float* safe, int c0, bool active, float dflt, float out[8]) {
+  const bool has = p != nullptr;
+  const float* q = has ? p + (active ? c0 : 0) : safe;
+  float v[8];
+  V4<float>::load(q, v);
+  V4<float>::load(q + 4, v + 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (has && active) ? v[j] : dflt;
+}
+
 // Tap geometry of one pixel, branch-free: clamped source coordinates + validity, so that all nine loads of a
 // window can be issued back to back (no divergent skip between them) and invalid taps are zeroed by a select.
 struct Taps { long off[9]; bool ok[9]; };
@@ -398,11 +411,10 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
   float mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f; }
-  if (active && g.xs) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
-  }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; }
+  coef8(g.xs, g.w, c0, active, 1.f, sc);
+  coef8(g.xs ? g.xm : nullptr, g.w, c0, active, 0.f, mu);
+  coef8(g.xs ? g.xb : nullptr, g.w, c0, active, 0.f, sh);
   // bf16 activations: (x-mu)*s+b is evaluated as x*s + (b-mu*s) (one FMA; the rounding difference is far below bf16)
   constexpr bool FOLD = sizeof(T) == 2;
   if (FOLD) {
@@ -497,18 +509,17 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
   float accw[9][8], ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t) accw[t][j] = 0.f;
   }
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (g.ga) ca[j] = g.ga[c0 + j];
-      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
-      if (g.xs) { sc[j] = g.xs[c0 + j]; mu[j] = g.xm ? g.xm[c0 + j] : 0.f; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
-    }
-  }
+  const float* safe = reinterpret_cast<const float*>(g.ws);   // any readable f32 address
+  coef8(g.ga, safe, c0, active, 1.f, ca);
+  coef8(g.yraw ? g.gb : nullptr, safe, c0, active, 0.f, cb);
+  coef8(g.yraw ? g.gce : nullptr, safe, c0, active, 0.f, ce);
+  coef8(g.yraw ? g.gmu : nullptr, safe, c0, active, 0.f, cm);
+  coef8(g.xs, safe, c0, active, 1.f, sc);
+  coef8(g.xs ? g.xm : nullptr, safe, c0, active, 0.f, mu);
+  coef8(g.xs ? g.xb : nullptr, safe, c0, active, 0.f, sh);
   constexpr bool FOLD = sizeof(T) == 2;
   float kd[8];   // folded backward constant: g = ga*e + gb*y + kd
 #pragma unroll
@@ -618,18 +629,14 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   float ca[8], cb[8], ce[8], cm[8], mu[8], sc[8], sh[8];
   A s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s1[j] = 0; s2[j] = 0; ca[j] = 1.f; cb[j] = 0.f; ce[j] = 0.f; cm[j] = 0.f; mu[j] = 0.f; sc[j] = 1.f; sh[j] = 0.f;
-  }
-  if (active) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (g.ga) ca[j] = g.ga[c0 + j];
-      if (g.yraw) { cb[j] = g.gb[c0 + j]; ce[j] = g.gce[c0 + j]; cm[j] = g.gmu[c0 + j]; }
-      if (g.xm) mu[j] = g.xm[c0 + j];
-      if (g.xs) { sc[j] = g.xs[c0 + j]; sh[j] = g.xb ? g.xb[c0 + j] : 0.f; }
-    }
-  }
+  for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; }
+  coef8(g.ga, g.w, c0, active, 1.f, ca);
+  coef8(g.yraw ? g.gb : nullptr, g.w, c0, active, 0.f, cb);
+  coef8(g.yraw ? g.gce : nullptr, g.w, c0, active, 0.f, ce);
+  coef8(g.yraw ? g.gmu : nullptr, g.w, c0, active, 0.f, cm);
+  coef8(g.xm, g.w, c0, active, 0.f, mu);
+  coef8(g.xs, g.w, c0, active, 1.f, sc);
+  coef8(g.xs ? g.xb : nullptr, g.w, c0, active, 0.f, sh);
   constexpr bool FOLD = sizeof(T) == 2;
   float kd[8];
 #pragma unroll

@@ -128,17 +128,17 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   int nfr = (ncw - wn * 64 + 15) >> 4;
   nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
 
-  if (tid < NCH) {
+  if (tid < NCH) {   // three independent loads (null-safe pointers + select), not three branches with a wait each
     const int n = n0 + tid;
     const bool in = n < g.N;
-    if (BWD) {
-      Ec[tid] = (in && g.xm && g.mm) ? g.mm[n] : 0.f;
-      Ec[NCH + tid] = (in && g.xm && g.ms) ? g.ms[n] : 1.f;
-      Ec[2 * NCH + tid] = (in && g.xm && g.mb) ? g.mb[n] : 0.f;
-    } else {
-      Ec[tid] = (in && g.bias) ? g.bias[n] : 0.f;
-      Ec[NCH + tid] = 0.f; Ec[2 * NCH + tid] = 0.f;
-    }
+    const int nn = in ? n : 0;
+    const bool hm = BWD ? (g.xm && g.mm) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
+    const float e0 = (hm ? (BWD ? g.mm : g.bias) : g.w)[hm ? nn : 0];
+    const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
+    const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
+    Ec[tid] = (in && hm) ? e0 : 0.f;
+    Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
+    Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
   }
   const int K = g.K;
   const int kwp = (K + 31) & ~31;          // MFMA k-steps cover kwp columns; columns >= K are zero in both tiles
@@ -415,31 +415,30 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const int nrows = ((ncw + 15) >> 4) * 16;
   int nfr = (ncw - wn * 64 + 15) >> 4;
   nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
-  if (tid < NCH) {
+  if (tid < NCH) {   // three independent loads (null-safe pointers + select), not three branches with a wait each
     const int n = n0 + tid;
     const bool in = n < g.N;
-    if (BWD) {
-      Ec[tid] = (in && g.xm && g.mm) ? g.mm[n] : 0.f;
-      Ec[NCH + tid] = (in && g.xm && g.ms) ? g.ms[n] : 1.f;
-      Ec[2 * NCH + tid] = (in && g.xm && g.mb) ? g.mb[n] : 0.f;
-    } else {
-      Ec[tid] = (in && g.bias) ? g.bias[n] : 0.f;
-      Ec[NCH + tid] = 0.f; Ec[2 * NCH + tid] = 0.f;
-    }
+    const int nn = in ? n : 0;
+    const bool hm = BWD ? (g.xm && g.mm) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
+    const float e0 = (hm ? (BWD ? g.mm : g.bias) : g.w)[hm ? nn : 0];
+    const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
+    const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
+    Ec[tid] = (in && hm) ? e0 : 0.f;
+    Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
+    Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
   }
   const int K = g.K;
   const int nkc = (K + KMAX - 1) / KMAX;
   const float relu_lo = g.a_relu ? 0.f : -TSS_INF;
 
   for (int ch = tid; ch < K; ch += NT) {   // folded constants of every contraction channel, once per block
-    if (BWD) {
-      const float ga = g.c0 ? g.c0[ch] : 1.f, gb = g.c1 ? g.c1[ch] : 0.f;
-      Ck[ch] = ga; Ck[KTOT + ch] = gb;
-      Ck[2 * KTOT + ch] = -(ga * (g.c2 ? g.c2[ch] : 0.f)) - gb * (g.c3 ? g.c3[ch] : 0.f);
-    } else {
-      const float sc = g.c0 ? g.c0[ch] : 1.f;
-      Ck[ch] = sc; Ck[KTOT + ch] = 0.f;
-      Ck[2 * KTOT + ch] = (g.c2 ? g.c2[ch] : 0.f) - (g.c1 ? g.c1[ch] : 0.f) * sc;
+    const float v0 = (g.c0 ? g.c0 : g.w)[g.c0 ? ch : 0], v1 = (g.c1 ? g.c1 : g.w)[g.c1 ? ch : 0];
+    const float v2 = (g.c2 ? g.c2 : g.w)[g.c2 ? ch : 0], v3 = (g.c3 ? g.c3 : g.w)[g.c3 ? ch : 0];
+    const float c0v = g.c0 ? v0 : 1.f, c1v = g.c1 ? v1 : 0.f, c2v = g.c2 ? v2 : 0.f, c3v = g.c3 ? v3 : 0.f;
+    if (BWD) {       // g = c0*(e - c2) + c1*(y - c3)
+      Ck[ch] = c0v; Ck[KTOT + ch] = c1v; Ck[2 * KTOT + ch] = -(c0v * c2v) - c1v * c3v;
+    } else {         // a = (x - c1)*c0 + c2
+      Ck[ch] = c0v; Ck[KTOT + ch] = 0.f; Ck[2 * KTOT + ch] = c2v - c1v * c0v;
     }
   }
 
