@@ -30,6 +30,8 @@ def test_library_exports_every_declared_symbol():
     lib = N.lib()                              # binds argtypes for every declared function
     assert lib.tss_arch() == b'gfx950' and lib.tss_version() == 1
     assert set(N.parse_header()) <= declared
+    assert {'tss_pwconv_bwd_weight_ws', 'tss_upsample_ce_fwd', 'tss_upsample_ce_bwd', 'tss_prof_records'} <= declared
+    assert lib.tss_pwconv_bwd_weight_ws(4096, 64, 128, 1) > 0 and lib.tss_pwconv_bwd_weight_ws(4096, 64, 128, 0) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

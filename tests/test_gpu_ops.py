@@ -177,3 +177,57 @@ def test_fused_upsample_cross_entropy_matches_unfused(shape, scale, dtype):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert abs(la.item() / lb.item() - 1) < tol
     assert rel(a.grad, b.grad) < tol
+
+
+@pytest.mark.parametrize('K,Nn,P', [(128, 128, 1000), (64, 384, 4096), (384, 64, 2500), (32, 48, 8192 + 37), (96, 576, 777),
+                                    (576, 96, 64)])
+def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
+    """tss_pwconv_bwd_weight on the bf16 path: the workspace + reduce form (deterministic) == the f32-atomics form ==
+    an f32 torch evaluation of dW = G^T A on the same bf16 operands, for full, ragged and multi-tile shapes."""
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(5)
+    e = torch.randn(P, Nn, device=DEV).bfloat16()
+    y = torch.randn(P, Nn, device=DEV).bfloat16()
+    x = torch.randn(P, K, device=DEV).bfloat16()
+    ga, gb = torch.rand(Nn, device=DEV) + 0.5, torch.randn(Nn, device=DEV) * 0.3
+    gce, gmu = torch.randn(Nn, device=DEV) * 0.1, torch.randn(Nn, device=DEV) * 0.2
+    xm, xs, xb = torch.randn(K, device=DEV) * 0.2, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    st = N.stream()
+
+    def run(ws):
+        dw = torch.zeros(Nn, K, device=DEV)
+        N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+               N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1, N.ptr(dw), N.ptr(ws), P, K, Nn, 1, st)
+        return dw
+
+    nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1)
+    assert nws > 0
+    ws = torch.full((nws,), float('nan'), device=DEV)          # every slot element that is read must have been written
+    d_ws, d_ws2, d_at = run(ws), run(ws), run(None)
+    assert torch.equal(d_ws, d_ws2)                            # deterministic
+    g = (ga * (e.float() - gce) + gb * (y.float() - gmu)).bfloat16().float()
+    a = torch.relu((x.float() - xm) * xs + xb).bfloat16().float()
+    ref = g.t() @ a
+    assert rel(d_ws, d_at) < 2e-5
+    assert rel(d_ws, ref) < 5e-3
+
+
+def test_trainer_static_batch_skips_the_staging_copy_and_checks_shapes():
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd.models.fastscnn import FastSCNN
+    torch.manual_seed(3)
+    model = FastSCNN(3, 19).to(DEV)
+    tssa.set_compute_dtype(model, torch.bfloat16)
+    opt = E.FlatAdamW(model.parameters(), lr=1e-3)
+    tr = E.Trainer(model, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=True)
+    x = torch.randn(2, 3, 64, 128, device=DEV)
+    y = torch.randint(0, 19, (2, 64, 128), device=DEV)
+    l0 = tr.step_async(x, y).item()                            # captures; copies into the static buffers
+    sx, sy = tr.static_batch(x, y)
+    assert sx.data_ptr() != x.data_ptr() and torch.equal(sx, x) and torch.equal(sy, y)
+    sx.copy_(x * 0.5)                                          # a loader writing the next batch in place
+    l1 = tr.step_async(sx, sy).item()                          # no staging copy: same storage
+    assert l0 == l0 and l1 == l1 and l0 != l1
+    with pytest.raises(ValueError):
+        tr.step_async(torch.randn(2, 3, 32, 128, device=DEV), y)

@@ -42,7 +42,23 @@ if which == 'ceup':
 for _ in range(10):
     fns[which]()
 torch.cuda.synchronize()
-if os.environ.get('TSS_TIMING') == '1':
+if os.environ.get('TSS_TIMING') == '1' and which.startswith('pw'):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    N.lib().tss_debug_pw_timing(buf, 1)
+    n = max(buf[7], 1)
+    for q, nm in enumerate(['prologue', 'loop', 'tail']):
+        print('%-10s %10.0f cycles/block' % (nm, buf[q] / n))
+    print('blocks', n // 10)
+elif os.environ.get('TSS_TIMING') == '1' and which.startswith('dw'):
+    import ctypes
+    buf = (ctypes.c_ulonglong * 8)()
+    N.lib().tss_debug_dw_timing(buf, 1)
+    n = max(buf[7], 1)
+    for q, nm in enumerate(['prologue', 'loop', 'tail']):
+        print('%-10s %10.0f cycles/block' % (nm, buf[q] / n))
+    print('blocks', n // 10)
+elif os.environ.get('TSS_TIMING') == '1':
     import ctypes
     buf = (ctypes.c_ulonglong * 8)()
     N.lib().tss_debug_wg_timing(buf, 1)

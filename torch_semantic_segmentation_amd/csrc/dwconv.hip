@@ -15,6 +15,13 @@ namespace {
 
 constexpr int NT_MAX = 256;
 
+#ifdef TSS_TIMING
+__device__ unsigned long long g_dw_timing[8];   // debug builds: [prologue, loop, tail, -, -, -, -, blocks] cycles of wave 0
+#define TSS_T(var) unsigned long long var; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define TSS_T(var)
+#endif
+
 struct DwArgs {
   const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu;
   const float* w;  // [C][9]
@@ -56,11 +63,11 @@ __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double
 // load/store loop is serialised by the compiler: 20 dependent L2 round trips per block at C = 576).
 __device__ __forceinline__ void stage_weights(float* wl, const float* w, int C, int tid, int nthreads) {
   const int n = C * 9;
-  constexpr int U = 8;
+  constexpr int U = 14;   // C <= 768 with >= 192 threads: at most three trips (one for C <= 384)
   for (int base = 0; base < n; base += nthreads * U) {
     float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = base + tid + u * nthreads; v[u] = i < n ? w[i] : 0.f; }
+    for (int u = 0; u < U; ++u) { const int i = base + tid + u * nthreads; v[u] = w[i < n ? i : 0]; }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base + tid + u * nthreads;
@@ -616,6 +623,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   constexpr int NCOL = (S == 1) ? (SW + 2 * D) : 3;
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];
+  TSS_T(tq0);
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
   const bool active = pl < g.NPL;
@@ -646,6 +654,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   const long U = (long)g.B * g.Hin * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles);
+  TSS_T(tq1);
   for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
     const long u = (long)tile * g.NPL + pl;
     if (!active || u >= U) continue;
@@ -747,7 +756,14 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_T(tq2);
   if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+#ifdef TSS_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_T(tq3);
+  if (threadIdx.x == 0) { atomicAdd(&g_dw_timing[0], tq1 - tq0); atomicAdd(&g_dw_timing[1], tq2 - tq1); atomicAdd(&g_dw_timing[2], tq3 - tq2); atomicAdd(&g_dw_timing[7], 1ull); }
+#endif
 }
 
 template <typename T>
@@ -882,5 +898,13 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
   hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
   return tss::check_last("dwconv_bwd_weight");
 }
+
+#ifdef TSS_TIMING
+int tss_debug_dw_timing(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dw_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dw_timing), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 }  // extern "C"

@@ -17,6 +17,13 @@
 namespace {
 
 constexpr int BM = 128, NCH = 128, NT = 256, KMAX = 128, RS = KMAX + 8;
+
+#ifdef TSS_TIMING
+__device__ unsigned long long g_pw_timing[8];   // debug builds: [prologue, loop, tail, ..., blocks] cycles of wave 0
+#define TSS_T(var) unsigned long long var; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define TSS_T(var)
+#endif
 typedef bf16_t T;
 
 struct FastArgs {
@@ -104,6 +111,7 @@ template <bool BWD, int TM>
 __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
   constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
+  TSS_T(tq0);
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);
   T* Ws = Xs + TM * RS;
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 
   __syncthreads();
 
+  TSS_T(tq1);
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * TM;
     const bool full = p0 + TM <= g.P;
@@ -354,6 +363,8 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     }
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_T(tq2);
   // ---- statistics slab row of this block (see convgemm.hip)
   if (g.stats) {
     __syncthreads();
@@ -381,6 +392,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
       }
     }
   }
+#ifdef TSS_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_T(tq3);
+  if (threadIdx.x == 0) { atomicAdd(&g_pw_timing[0], tq1 - tq0); atomicAdd(&g_pw_timing[1], tq2 - tq1); atomicAdd(&g_pw_timing[2], tq3 - tq2); atomicAdd(&g_pw_timing[7], 1ull); }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -661,6 +677,14 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
 }
 
 }  // namespace
+
+#ifdef TSS_TIMING
+extern "C" int tss_debug_pw_timing(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_pw_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pw_timing), z, sizeof(z)); }
+  return 0;
+}
+#endif
 
 int g_tss_disable_fast = 0;   // tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1): A/B switch for tests
 
