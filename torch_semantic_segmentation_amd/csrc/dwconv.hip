@@ -756,7 +756,9 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
       }
     }
   }
+#ifdef TSS_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   TSS_T(tq2);
   if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
 #ifdef TSS_TIMING

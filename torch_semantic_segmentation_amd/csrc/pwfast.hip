@@ -363,7 +363,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     }
   }
 
+#ifdef TSS_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   TSS_T(tq2);
   // ---- statistics slab row of this block (see convgemm.hip)
   if (g.stats) {
