@@ -44,6 +44,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--host-batch', action='store_true',
+                    help='also report the PCIe-inclusive rate: the batch is copied from pinned host memory every step '
+                         '(never the headline value; printed to stderr)')
     ap.add_argument('--stock', action='store_true', help='also time the stock PyTorch-ROCm (MIOpen) path of the oracle modules')
     return ap.parse_args()
 
@@ -226,6 +229,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss)
+
+    if args.host_batch and rank == 0:
+        hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
+        for _ in range(2):
+            trainer.step_async(hx, hy)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step_async(hx, hy)       # H2D straight into the captured step's buffers, same stream: no overlap
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / args.steps
+        print('host-batch (PCIe-inclusive, un-overlapped): %.3f ms/step, %.1f images/s, %.1f GB/s H2D-equivalent' % (
+            1e3 * dt, args.batch / dt, (hx.numel() * hx.element_size() + hy.numel() * hy.element_size()) / dt / 1e9),
+            file=sys.stderr)
 
     roofline = None
     breakdown = None
