@@ -78,18 +78,21 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
                    const float* w, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
- * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask. */
+ * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
+ * wg_ws / wg_dw (optional): the workspace and dW of a tss_pwconv_bwd_weight(..., defer_reduce = 1) call of the SAME layer
+ * (same P, K, N): its slot reduction is carried by the first blocks of this launch instead of a kernel of its own. */
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                        void* e_in, long ldei, double* bstats,
+                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                         long P, int K, int N, int dtype, void* stream);
 /* dw[n][k] += sum_p g[p][n] * act(x[p][k]).  ws: f32 workspace of tss_pwconv_bwd_weight_ws(P, K, N, dtype) floats for the
- * blocks' partial tiles (summed deterministically by a second kernel); ws NULL, or a size of 0: f32 atomics onto dw. */
+ * blocks' partial tiles (summed deterministically by a second kernel, or -- defer_reduce = 1 -- by the backward-data
+ * launch of the same layer, see tss_pwconv_bwd_data); ws NULL, or a size of 0: f32 atomics onto dw. */
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, float* ws, long P, int K, int N, int dtype, void* stream);
+                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, void* stream);
 long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype);
 
 /* ---- dense 3x3 convolution, padding = dilation ------------------------------------------------------

@@ -197,7 +197,7 @@ def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
     def run(ws):
         dw = torch.zeros(Nn, K, device=DEV)
         N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
-               N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1, N.ptr(dw), N.ptr(ws), P, K, Nn, 1, st)
+               N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1, N.ptr(dw), N.ptr(ws), 0, P, K, Nn, 1, st)
         return dw
 
     nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1)
@@ -231,3 +231,34 @@ def test_trainer_static_batch_skips_the_staging_copy_and_checks_shapes():
     assert l0 == l0 and l1 == l1 and l0 != l1
     with pytest.raises(ValueError):
         tr.step_async(torch.randn(2, 3, 32, 128, device=DEV), y)
+
+
+@pytest.mark.parametrize('K,Nn,P', [(128, 128, 3000), (64, 384, 4096), (384, 64, 1500), (32, 48, 5000)])
+def test_pw_weight_gradient_reduce_carried_by_backward_data(K, Nn, P):
+    """defer_reduce = 1: the slot reduction rides in front of the same layer's backward-data launch (wgreduce.h) and both
+    results equal the two stand-alone calls."""
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(9)
+    e = torch.randn(P, Nn, device=DEV).bfloat16(); y = torch.randn(P, Nn, device=DEV).bfloat16()
+    x = torch.randn(P, K, device=DEV).bfloat16(); w = torch.randn(Nn, K, device=DEV) * 0.1
+    ga, gb = torch.rand(Nn, device=DEV) + 0.5, torch.randn(Nn, device=DEV) * 0.3
+    gce, gmu = torch.randn(Nn, device=DEV) * 0.1, torch.randn(Nn, device=DEV) * 0.2
+    xm, xs, xb = torch.randn(K, device=DEV) * 0.2, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    st = N.stream()
+    S = N.stat_slabs()
+    nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1)
+
+    def run(defer):
+        dw = torch.zeros(Nn, K, device=DEV); ein = torch.empty(P, K, device=DEV, dtype=torch.bfloat16)
+        bst = torch.empty(S, 2 * K, dtype=torch.float64, device=DEV)
+        ws = torch.full((nws,), float('nan'), device=DEV)
+        gargs = (N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu))
+        xargs = (N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1)
+        N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), defer, P, K, Nn, 1, st)
+        N.call('tss_pwconv_bwd_data', *gargs, N.ptr(w), *xargs, N.ptr(ein), K, N.ptr(bst),
+               N.ptr(ws) if defer else None, N.ptr(dw) if defer else None, P, K, Nn, 1, st)
+        return dw, ein.float(), bst.sum(0)
+
+    a, b = run(0), run(1)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[0].abs().max() > 0

@@ -19,8 +19,8 @@ nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1) if which == 'wgrad' else 0
 wsw = torch.empty(nws, device=dev) if nws and os.environ.get('TSS_WG_ATOMIC') != '1' else None
 fns = {
  'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
- 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), P, K, Nn, 1, st),
- 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), P, K, Nn, 1, st),
+ 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st),
+ 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), 0, P, K, Nn, 1, st),
 }
 if which in ('dwfwd', 'dwbwd', 'dwwg'):
     C, B, H, W = K, 8, Nn, P

@@ -30,9 +30,9 @@ for (K, Nn) in ((128, 128), (64, 384), (384, 64), (32, 48), (128, 768), (768, 12
         fwd = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st)
         fwd0 = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, None, None, None, 0, N.ptr(w), None, N.ptr(y), Nn, None, P, K, Nn, 1, st)
         bwd = lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w),
-                             N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), P, K, Nn, 1, st)
+                             N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st)
         wg = lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN),
-                            N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), None, P, K, Nn, 1, st)
+                            N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), None, 0, P, K, Nn, 1, st)
         tf, tf0, tb, tw = timeit(fwd), timeit(fwd0), timeit(bwd), timeit(wg)
         mbf = P * (K + Nn) * 2 / 1e6; mbb = P * (2 * Nn + 2 * K) * 2 / 1e6; mbw = P * (2 * Nn + K) * 2 / 1e6
         print('pw K=%3d N=%3d P=%8d | fwd %7.1f us %5.0f GB/s (plain %7.1f us %5.0f) | bwd_data %7.1f us %5.0f GB/s | wgrad %7.1f us %5.0f GB/s'

@@ -475,7 +475,9 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                          const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                         void* e_in, long ldei, double* bstats, long P, int K, int N, hipStream_t stream);  // pwfast.hip
+                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
+                         long P, int K, int N, hipStream_t stream);  // pwfast.hip
+void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream);  // wgrad.hip
 bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
                          int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
 
@@ -505,7 +507,7 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                        void* e_in, long ldei, double* bstats,
+                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                         long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldei % 4) == 0 && ldei >= K,
@@ -526,9 +528,10 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 768 && (N % 8) == 0 && (K % 4) == 0) {
     tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
     if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
-                            e_in, ldei, bstats, P, K, N, (hipStream_t)stream))
+                            e_in, ldei, bstats, wg_ws, wg_dw, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_bwd_data");
   }
+  if (wg_ws && wg_dw) tss_wg_reduce_standalone(wg_ws, wg_dw, P, K, N, (hipStream_t)stream);   // nobody else will
   return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
 }
 

@@ -13,6 +13,7 @@
 //   * the epilogue derives the statistics from the bits it is about to store and writes through 4 row pointers.
 // The f32 parity path, K > 128, dense 3x3 and ragged channel counts stay on convgemm_kernel.
 #include "common.h"
+#include "wgreduce.h"
 
 namespace {
 
@@ -36,6 +37,8 @@ struct FastArgs {
   T* y; long ldy; double* stats;
   const T* xm; long ldxm; const float* mm; const float* ms; const float* mb; int m_relu;
   int gslots;
+  tss_wg::ReduceArgs red;               // bwd: pending weight-gradient slot reduction of the same layer (nred == 0: none)
+  int nred8;                            // its block count rounded up to 8 (keeps blockIdx % 8 == XCD for the main blocks)
 };
 
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -121,8 +124,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   const int fr = lane & 15, fq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
+  // the first nred8 blocks of a backward-data grid sum the weight-gradient workspace of the same layer (wgreduce.h)
+  if (BWD && g.nred8 > 0 && (int)blockIdx.x < g.nred8) {
+    if ((int)blockIdx.x < g.red.nred) tss_wg::reduce_block(g.red, blockIdx.x, reinterpret_cast<float4*>(smem));
+    return;
+  }
+  const int bidx = BWD ? (int)blockIdx.x - g.nred8 : (int)blockIdx.x;
+
   const int nchunks = (g.N + NCH - 1) / NCH;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bidx & 7, slot = bidx >> 3;
   const int nc = slot % nchunks, gslot = slot / nchunks;
   const long ntiles = (g.P + TM - 1) / TM;
   const long per = (ntiles + 7) >> 3;
@@ -419,8 +429,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const int fr = lane & 15, fq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
+  // the first nred8 blocks of a backward-data grid sum the weight-gradient workspace of the same layer (wgreduce.h)
+  if (BWD && g.nred8 > 0 && (int)blockIdx.x < g.nred8) {
+    if ((int)blockIdx.x < g.red.nred) tss_wg::reduce_block(g.red, blockIdx.x, reinterpret_cast<float4*>(smem));
+    return;
+  }
+  const int bidx = BWD ? (int)blockIdx.x - g.nred8 : (int)blockIdx.x;
+
   const int nchunks = (g.N + NCH - 1) / NCH;
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bidx & 7, slot = bidx >> 3;
   const int nc = slot % nchunks, gslot = slot / nchunks;
   const long ntiles = (g.P + BM - 1) / BM;
   const long per = (ntiles + 7) >> 3;
@@ -650,7 +667,7 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   if (cap < 1) cap = 1;
   if (gs > cap) gs = cap;
   g.gslots = (int)gs;
-  const int grid = 8 * nchunks * (int)gs;
+  const int grid = 8 * nchunks * (int)gs + g.nred8;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemMc);
@@ -669,7 +686,7 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   if (cap < 1) cap = 1;
   if (gs > cap) gs = cap;
   g.gslots = (int)gs;
-  const int grid = 8 * nchunks * (int)gs;
+  const int grid = 8 * nchunks * (int)gs + g.nred8;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -710,9 +727,14 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                          const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                         void* e_in, long ldei, double* bstats, long P, int K, int N, hipStream_t stream) {
+                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
+                         long P, int K, int N, hipStream_t stream) {
   if (g_tss_disable_fast || !yraw || N > KTOT || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
   FastArgs g = {};
+  if (red_ws && red_dw) {   // the layer's weight-gradient slots are summed by the first blocks of this launch
+    g.red = tss_wg::reduce_args(red_ws, red_dw, P, K, N);
+    g.nred8 = (g.red.nred + 7) & ~7;
+  }
   g.P = P; g.K = N; g.N = K;
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;

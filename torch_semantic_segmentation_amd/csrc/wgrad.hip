@@ -14,6 +14,7 @@
 // add their partial tile to dW with f32 atomics (dW must be zero-initialised or hold a value to
 // accumulate onto, exactly like autograd's .grad).
 #include "common.h"
+#include "wgreduce.h"
 
 extern int g_tss_disable_fast;   // pwfast.hip
 
@@ -294,8 +295,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
 //   * the four waves are assigned by tile shape: a tile narrower than 5 fragments in n or k is not split along that
 //     axis (those waves would idle) but along the pixel axis instead (each wave takes half of the k-steps);
 //   * PT = 128-pixel stages when both chunk widths are <= 64 channels, so that the staging still uses every thread.
-// workspace slot extent along one axis: min(dim, 128) rounded up to the 16-wide MFMA fragment
-__host__ __device__ inline int ws_dim(int d) { return ((d < TN ? d : TN) + 15) & ~15; }
+using tss_wg::ws_dim;
 
 #ifdef TSS_TIMING
 // phase timing of wgfast_kernel (debug builds only: python -m ...build with TSS_TIMING=1): cycles summed over wave 0 of
@@ -574,81 +574,29 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 #endif
 }
 
-// dW[n][k] += sum over the workspace slots of a tile.  A block sums 256 consecutive elements of the slots (one float4
-// per lane: 1 KB per wave load), its 4 waves taking slots w, w+4, ... with up to 16 loads in flight per lane.
-constexpr int WR_WAVES = 4;
-__global__ __launch_bounds__(WR_WAVES * 64) void wg_reduce_kernel(const float* ws, float* dw, int nsplit, int nchn,
-                                                                 int ND, int KD, long drs, long dcs) {
-  __shared__ float4 part[WR_WAVES][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int TNe = ws_dim(ND), TKe = ws_dim(KD);
-  const int slot_n = TNe * TKe, segs = slot_n >> 8;               // slot_n is a multiple of 256
-  const int tile = blockIdx.x / segs, seg = blockIdx.x - tile * segs;
-  const int idx = seg * 256 + lane * 4;                           // 4 consecutive k of one row (TKe % 16 == 0)
-  const int nl = idx / TKe, kl = idx - nl * TKe;
-  const int nc = tile % nchn, kc = tile / nchn;
-  const int ncw = (ND - nc * TN < TN) ? (ND - nc * TN) : TN, kcw = (KD - kc * TK < TK) ? (KD - kc * TK) : TK;
-  const int FN = (ncw + 15) >> 4, FK = (kcw + 15) >> 4;
-  const bool valid = nl < FN * 16 && kl < FK * 16;                 // written by the blocks of this tile
-  const float* col = ws + (long)tile * nsplit * slot_n + (valid ? idx : 0);
-  float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int r0 = wave; r0 < nsplit; r0 += WR_WAVES * 16) {
-    float4 v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { const int r = r0 + WR_WAVES * u; v[u] = *reinterpret_cast<const float4*>(col + (long)(r < nsplit ? r : 0) * slot_n); }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      if (r0 + WR_WAVES * u < nsplit) { sacc.x += v[u].x; sacc.y += v[u].y; sacc.z += v[u].z; sacc.w += v[u].w; }
-    }
-  }
-  part[wave][lane] = sacc;
-  __syncthreads();
-  if (threadIdx.x < 64 && valid) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < WR_WAVES; ++q) { const float4 p4 = part[q][threadIdx.x]; t[0] += p4.x; t[1] += p4.y; t[2] += p4.z; t[3] += p4.w; }
-    const int n = nc * TN + nl;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int k = kc * TK + kl + q;
-      if (n < ND && k < KD) dw[(long)n * drs + (long)k * dcs] += t[q];
-    }
-  }
+// stand-alone form of the slot reduction (wgreduce.h); normally these blocks ride on the layer's backward-data launch
+__global__ __launch_bounds__(NT) void wg_reduce_kernel(const tss_wg::ReduceArgs r) {
+  __shared__ float4 part[4 * 64];
+  tss_wg::reduce_block(r, blockIdx.x, part);
 }
 
-template <int PT>
-long fast_split(const WgradArgs& g, int* tiles_out) {
-  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
-  const int tiles = nchn * nchk;
-  const long nstage = (g.P + PT - 1) / PT;
-  constexpr long MIN_STAGES = 512 / PT;   // a block amortises its LDS clear + partial tile over >= 512 pixels
-  long ns = 1024 / tiles;
-  if (ns < 1) ns = 1;
-  if (ns > (nstage + MIN_STAGES - 1) / MIN_STAGES) ns = (nstage + MIN_STAGES - 1) / MIN_STAGES;
-  if (ns < 1) ns = 1;
-  *tiles_out = tiles;
-  return ns;
-}
+using tss_wg::reduce_args;
 
 template <int PT>
-void launch_fast_pt(WgradArgs& g, hipStream_t stream) {
-  int tiles;
-  g.nsplit = (int)fast_split<PT>(g, &tiles);
+void launch_fast_pt(WgradArgs& g, hipStream_t stream, bool defer_reduce) {
+  const tss_wg::Split sp = tss_wg::split_for(g.P, g.KD, g.ND);
+  g.nsplit = sp.nsplit;
   constexpr int smem = 2 * TN * (PT * 2 + 16);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgfast_kernel<PT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr = true;
   }
-  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(tiles * g.nsplit), dim3(NT), smem, stream, g);
-  if (g.ws)
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3(tiles * (ws_dim(g.ND) * ws_dim(g.KD) / 256)), dim3(WR_WAVES * 64), 0, stream, g.ws, g.dw, g.nsplit,
-                       (g.ND + TN - 1) / TN, g.ND, g.KD, g.drs, g.dcs);
-}
-
-inline bool fast_uses_pt128(int K, int N) {
-  const int wn = N < TN ? N : TN, wk = K < TK ? K : TK;
-  return (wn > wk ? wn : wk) <= 64;
+  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(sp.tiles * g.nsplit), dim3(NT), smem, stream, g);
+  if (g.ws && !defer_reduce) {
+    const tss_wg::ReduceArgs r = reduce_args(g.ws, g.dw, g.P, g.KD, g.ND);
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3(r.nred), dim3(NT), 0, stream, r);
+  }
 }
 
 int launch(WgradArgs& g, int dtype, int kernel_id, hipStream_t stream, double alg_bytes) {
@@ -680,12 +628,18 @@ bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr,
                            const float* gce, const float* gmu, const void* x_nchw, int x_is_f32, float* dw, float* ws,
                            int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
 
+// pending slot reduction of a layer, launched on its own (pwfast.hip calls this when its kernels cannot carry it)
+void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream) {
+  const tss_wg::ReduceArgs r = reduce_args(ws, dw, P, K, N);
+  hipLaunchKernelGGL(wg_reduce_kernel, dim3(r.nred), dim3(NT), 0, stream, r);
+}
+
 extern "C" {
 
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, float* ws, long P, int K, int N, int dtype, void* stream) {
+                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldx % 8) == 0 && ldx >= K, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gce && gmu), TSS_ERR_SHAPE);
@@ -700,8 +654,8 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && (N % 8) == 0 && P > 0) {   // lean pipelined kernel
     tss::ProfScope prof(TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)P * N * K);
     g.ws = ws;
-    if (fast_uses_pt128(K, N)) launch_fast_pt<128>(g, (hipStream_t)stream);
-    else launch_fast_pt<64>(g, (hipStream_t)stream);
+    if (tss_wg::split_for(P, K, N).pt == 128) launch_fast_pt<128>(g, (hipStream_t)stream, ws && defer_reduce);
+    else launch_fast_pt<64>(g, (hipStream_t)stream, ws && defer_reduce);
     return tss::check_last("wgfast");
   }
   return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes);
@@ -709,11 +663,8 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
 
 long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype) {
   if (dtype != TSS_BF16 || g_tss_disable_fast || (N % 8) != 0 || (K % 8) != 0 || P <= 0) return 0;
-  WgradArgs g = {};
-  g.P = P; g.ND = N; g.KD = K;
-  int tiles;
-  const long ns = fast_uses_pt128(K, N) ? fast_split<128>(g, &tiles) : fast_split<64>(g, &tiles);
-  return (long)tiles * ns * ws_dim(N) * ws_dim(K);
+  const tss_wg::Split sp = tss_wg::split_for(P, K, N);
+  return (long)sp.tiles * sp.nsplit * ws_dim(N) * ws_dim(K);
 }
 
 int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,

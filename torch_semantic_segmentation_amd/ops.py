@@ -371,7 +371,8 @@ class ConvUnitFn(Function):
             if cfg.kind == 'pw':
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
-                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt, wst)
+                defer = 1 if (ws is not None and need_dx and side is None) else 0   # backward-data carries the reduce
+                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, P, Cin, Cout, dt, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
                 call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, wst)
@@ -383,7 +384,7 @@ class ConvUnitFn(Function):
                 bst = ptr(il.bstats) if il is not None else None
                 if cfg.kind == 'pw':
                     call('tss_pwconv_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
-                         P, Cin, Cout, dt, st)
+                         ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
                 elif cfg.kind == 'dw':
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cout, s, d, dt, st)
