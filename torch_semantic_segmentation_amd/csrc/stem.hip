@@ -206,6 +206,134 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_kernel(const StemWgradArgs g
   (void)K;
 }
 
+// MFMA form of the stem weight gradient (the performance path).  The VALU kernel above reads LDS twice per four FMAs
+// (512 LDS instructions per lane per 256-pixel tile: LDS-bound, 360 us); here the contraction over the pixels is
+// 8 v_mfma_f32_16x16x32_bf16 per wave per tile on operands kept pixel-major in LDS:
+//   Xt[k][p] = tap k of pixel p (bf16, written by the lane that owns pixel p: conflict-free 2-byte stores)
+//   Gt[n][p] = BatchNorm-backward of (e, y) for channel n of pixel p
+// D = Gt x Xt^T accumulates in registers over all tiles of the block; the four waves (a 64-pixel quarter each) meet in
+// LDS at the end and the block's [32][28] partial goes to its workspace row (summed by stem_wgrad_reduce_kernel).
+template <typename TX>
+__global__ __launch_bounds__(NT, 2) void stem_wgrad_mfma_kernel(const StemWgradArgs g) {
+  typedef bf16_t T;
+  constexpr int N = 32, TP = 256, KP = 28, ROW = TP + 8;   // bf16 elements per LDS row (16-byte aligned rows)
+  __shared__ __align__(16) T Gt[N * ROW];
+  __shared__ __align__(16) T Xt[32 * ROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const T* e = reinterpret_cast<const T*>(g.e);
+  const T* yr = reinterpret_cast<const T*>(g.yraw);
+  const TX* x = reinterpret_cast<const TX*>(g.x);
+  const long P = (long)g.B * g.Hout * g.Wout;
+  const long HWo = (long)g.Hout * g.Wout;
+  const long plane = (long)g.Hin * g.Win;
+  const long ntiles = (P + TP - 1) / TP;
+  for (int i = tid; i < 5 * ROW; i += NT) Xt[27 * ROW + i] = (T)0.f;   // taps 27..31 pad the MFMA k-fragment
+  const int gcv = tid & 3;
+  float ca[8], cb[8], cc[8];
+  {
+    float v0[8], v1[8], v2[8], v3[8];
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      V4<float>::load(g.ga + gcv * 8 + h, v0 + h); V4<float>::load(g.gb + gcv * 8 + h, v1 + h);
+      V4<float>::load(g.gce + gcv * 8 + h, v2 + h); V4<float>::load(g.gmu + gcv * 8 + h, v3 + h);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ca[j] = v0[j]; cb[j] = v1[j]; cc[j] = -(v0[j] * v2[j]) - v1[j] * v3[j]; }   // g = ca*e + cb*y + cc
+  }
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p0 = tile * TP;
+    __syncthreads();
+    // gradient vectors first (two 16-byte loads x 4), then the 27 strided tap loads of this lane's pixel
+    uint4 re[4], ry[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long p = p0 + (tid >> 2) + 64 * i;
+      const long pc = p < P ? p : 0;
+      re[i] = *reinterpret_cast<const uint4*>(e + pc * g.lde + gcv * 8);
+      ry[i] = *reinterpret_cast<const uint4*>(yr + pc * g.ldyr + gcv * 8);
+    }
+    {
+      const long p = p0 + tid;
+      const bool in = p < P;
+      const long pc = in ? p : 0;
+      const long b = pc / HWo; const long rem = pc - b * HWo;
+      const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+      float v[27];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy * g.stride + ky - 1;
+          const bool vy = iy >= 0 && iy < g.Hin;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * g.stride + kx - 1;
+            const bool ok = in && c < g.Cin && vy && ix >= 0 && ix < g.Win;
+            const long off = (b * g.Cin + (c < g.Cin ? c : 0)) * plane + (vy ? iy : 0) * (long)g.Win +
+                             (ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix));
+            const float t = (float)x[off];
+            v[c * 9 + ky * 3 + kx] = ok ? t : 0.f;
+          }
+        }
+#pragma unroll
+      for (int k = 0; k < 27; ++k) Xt[k * ROW + tid] = (T)v[k];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int px = (tid >> 2) + 64 * i;
+      const bool in = p0 + px < P;
+      const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[i]);
+      const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[i]);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        const float lo = ca[2 * h] * __uint_as_float(ue[h] << 16) + (cb[2 * h] * __uint_as_float(uy[h] << 16) + cc[2 * h]);
+        const float hi = ca[2 * h + 1] * __uint_as_float(ue[h] & 0xffff0000u) +
+                         (cb[2 * h + 1] * __uint_as_float(uy[h] & 0xffff0000u) + cc[2 * h + 1]);
+        Gt[(gcv * 8 + 2 * h) * ROW + px] = (T)(in ? lo : 0.f);
+        Gt[(gcv * 8 + 2 * h + 1) * ROW + px] = (T)(in ? hi : 0.f);
+      }
+    }
+    __syncthreads();
+    // this wave's 64 pixels: two k-steps of 32
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int col = wave * 64 + ks * 32 + fq * 8;
+      bf16x8 gf[2], xf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        gf[i] = *reinterpret_cast<const bf16x8*>(Gt + (i * 16 + fr) * ROW + col);
+        xf[i] = *reinterpret_cast<const bf16x8*>(Xt + (i * 16 + fr) * ROW + col);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // the four waves' partials meet in LDS (Gt is dead): red[wave][n][k], then one thread per (n, k < 28)
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(Gt);   // 4 * 32 * 32 floats = 16 KB <= sizeof(Gt)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 32 + i * 16 + fq * 4 + r) * 32 + j * 16 + fr] = acc[i][j][r];
+  __syncthreads();
+  float* row = g.ws + (long)blockIdx.x * N * KP;
+  for (int i = tid; i < N * KP; i += NT) {
+    const int n = i / KP, k = i - n * KP;
+    row[i] = red[n * 32 + k] + red[(32 + n) * 32 + k] + red[(64 + n) * 32 + k] + red[(96 + n) * 32 + k];
+  }
+}
+
 // dW[n][j] += sum over the `rows` workspace rows (16 columns x 16 row-groups per block, 8 loads in flight per lane)
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* ws, float* dw, int K, int rows) {
   constexpr int N = 32, KP = 28;
@@ -265,7 +393,10 @@ bool tss_stem_direct_wgrad(const void* e, long lde, const void* yraw, long ldyr,
   const long P = (long)B * g.Hout * g.Wout;
   long grid = (P + 255) / 256;
   if (grid > TSS_STAT_SLABS) grid = TSS_STAT_SLABS;
-  if (x_is_f32) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, float>), dim3((int)grid), dim3(NT), 0, stream, g);
+  if (yraw && ga && gb && gce && gmu) {   // MFMA form (train-mode BatchNorm behind the stem, the usual case)
+    if (x_is_f32) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<float>), dim3((int)grid), dim3(NT), 0, stream, g);
+    else hipLaunchKernelGGL((stem_wgrad_mfma_kernel<bf16_t>), dim3((int)grid), dim3(NT), 0, stream, g);
+  } else if (x_is_f32) hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, float>), dim3((int)grid), dim3(NT), 0, stream, g);
   else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t, bf16_t>), dim3((int)grid), dim3(NT), 0, stream, g);
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((32 * 28 + 15) / 16), dim3(256), 0, stream, ws, dw, Cin * 9, (int)grid);
   return true;
