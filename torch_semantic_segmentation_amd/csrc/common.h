@@ -166,6 +166,16 @@ __device__ __forceinline__ float ac_weight(float scale, int dst, int in, int i) 
   return w;
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: 4 VALU adds with a row
+// rotate modifier instead of 4 ds_bpermute round trips
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side: error mapping + optional per-kernel profiling (HIP events on the launch stream).
 namespace tss {

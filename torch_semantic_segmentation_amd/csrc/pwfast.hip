@@ -97,16 +97,6 @@ __device__ __forceinline__ void stage_weights(T* Ws, const float* w, int w_trans
   }
 }
 
-// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: 4 VALU adds with a row
-// rotate modifier instead of 4 ds_bpermute round trips
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
-  return v;
-}
-
 // TM = pixels per tile.  Forward: 128.  Backward-data: 64 -- it stages two tensors (e, y) and needs the producer's raw
 // output in the epilogue; with 128-pixel tiles those registers leave no room to keep the next tile's loads in flight
 // (an attempt spilled 188 B/lane and lost), with 64-pixel tiles everything is prefetched and nothing spills.

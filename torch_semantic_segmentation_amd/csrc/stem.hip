@@ -101,6 +101,109 @@ __global__ __launch_bounds__(NT) void stem_fwd_kernel(const StemArgs g) {
   }
 }
 
+// MFMA form of the stem forward (the performance path).  The VALU kernel above spends 864 FMAs per pixel (VALU-bound,
+// ~190 us); here the lane that owns a pixel packs its 27 taps as one bf16 row [pixel][32] in LDS (80-byte pitch:
+// conflict-free 16-byte stores and fragment reads), the 32x27 weights sit in registers as two MFMA A-fragments per
+// lane, and a wave needs 8 v_mfma_f32_16x16x32_bf16 for its 64 pixels.  D = W x patches^T: a lane holds 4 consecutive
+// channels of one pixel (8-byte NHWC stores, DPP row sums for the statistics), exactly like pwfast_kernel.
+template <typename TX>
+__global__ __launch_bounds__(NT, 2) void stem_fwd_mfma_kernel(const StemArgs g) {
+  typedef bf16_t T;
+  constexpr int N = 32, TP = 256, PITCH = 40;
+  __shared__ __align__(16) T Xp[TP * PITCH];
+  __shared__ float red[NT / 64][2][N];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int K = g.Cin * 9;
+  bf16x8 wf[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = fq * 8 + j;
+      wf[i][j] = (T)(g.w[(i * 16 + fr) * K + (k < K ? k : 0)] * (k < K ? 1.f : 0.f));
+    }
+  const TX* x = reinterpret_cast<const TX*>(g.x);
+  T* y = reinterpret_cast<T*>(g.y);
+  float st1[2][4], st2[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
+  const long P = (long)g.B * g.Hout * g.Wout;
+  const long HWo = (long)g.Hout * g.Wout;
+  const long plane = (long)g.Hin * g.Win;
+  const long ntiles = (P + TP - 1) / TP;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p0 = tile * TP;
+    {
+      const long p = p0 + tid;
+      const bool in = p < P;
+      const long pc = in ? p : 0;
+      const long b = pc / HWo; const long rem = pc - b * HWo;
+      const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
+      float v[32];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = oy * g.stride + ky - 1;
+          const bool vy = iy >= 0 && iy < g.Hin;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * g.stride + kx - 1;
+            const bool ok = in && c < g.Cin && vy && ix >= 0 && ix < g.Win;
+            const long off = (b * g.Cin + (c < g.Cin ? c : 0)) * plane + (vy ? iy : 0) * (long)g.Win +
+                             (ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix));
+            const float t = (float)x[off];
+            v[c * 9 + ky * 3 + kx] = ok ? t : 0.f;
+          }
+        }
+#pragma unroll
+      for (int k = 27; k < 32; ++k) v[k] = 0.f;
+      __syncthreads();   // the previous tile's fragment reads are done
+#pragma unroll
+      for (int h = 0; h < 4; ++h) V8<T>::store(Xp + tid * PITCH + h * 8, v + h * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int prow = wave * 64 + m * 16 + fr;
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xp + prow * PITCH + fq * 8);
+      const long p = p0 + prow;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (p < P) {
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (T)d[q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+          *reinterpret_cast<bf16x4*>(y + p * g.ldy + i * 16 + fq * 4) = o;
+        }
+      }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = row16_sum(st1[i][q]), b = row16_sum(st2[i][q]);
+        if (fr == 0) { red[wave][0][i * 16 + fq * 4 + q] = a; red[wave][1][i * 16 + fq * 4 + q] = b; }
+      }
+    __syncthreads();
+    for (int i = tid; i < 2 * N; i += NT) {
+      const int which = i / N, n = i - which * N;
+      double s = 0.0;
+      for (int wv = 0; wv < NT / 64; ++wv) s += (double)red[wv][which][n];
+      g.stats[(long)blockIdx.x * 2 * N + i] = s;
+      for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.stats[(long)r * 2 * N + i] = 0.0;
+    }
+  }
+}
+
 // Weight gradient of the stem: dW[n][j] = sum_p g[p][n] * patch[p][j], g = ga*(e-ce) + gb*(y-mu).
 // Tiles of 256 pixels: lane = pixel for staging (its 27 taps + its 32 gradient channels go to LDS, one HBM round
 // trip per tile), then lane = (n, 4 taps) for the contraction over the tile's pixels (2 LDS reads per 4 FMAs).
@@ -375,8 +478,8 @@ bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void*
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
   const long P = (long)B * g.Hout * g.Wout;
   const int grid = tss::persistent_blocks((P + NT - 1) / NT, TSS_STAT_SLABS);
-  if (x_is_f32) hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, float, 4>), dim3(grid), dim3(NT), 0, stream, g);
-  else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t, bf16_t, 4>), dim3(grid), dim3(NT), 0, stream, g);
+  if (x_is_f32) hipLaunchKernelGGL((stem_fwd_mfma_kernel<float>), dim3(grid), dim3(NT), 0, stream, g);
+  else hipLaunchKernelGGL((stem_fwd_mfma_kernel<bf16_t>), dim3(grid), dim3(NT), 0, stream, g);
   return true;
 }
 
