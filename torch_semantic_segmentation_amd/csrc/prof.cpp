@@ -16,7 +16,7 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     {"pwconv_bwd_data", "pwfast_kernel<true>|pwfast_mc_kernel<true>|convgemm_kernel"},
     {"pwconv_bwd_weight", "wgfast_kernel|wgrad_kernel"},
     {"conv3x3_fwd", "convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
-    {"stem3x3_fwd", "stem_fwd_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_mfma_kernel|stem_wgrad_kernel"},
+    {"stem3x3_fwd", "stem_fwd_mfma_kernel|convgemm_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_mfma_kernel|stem_wgrad_kernel"},
     {"dwconv3x3_fwd", "dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_strip_kernel"},
     {"dwconv3x3_bwd_weight", "dw_bwd_weight_strip_kernel"},
     {"bn_finalize", "bn_finalize_kernel"}, {"bn_bwd_finalize", "bn_bwd_finalize_kernel"},

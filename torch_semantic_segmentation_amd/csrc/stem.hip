@@ -1,15 +1,13 @@
-// Stem: 3x3 stride-s convolution of the NCHW image (Cin*9 <= 32 taps) into 32/any-multiple-of-8 NHWC channels.
-// K = 27 is too short to be worth an MFMA tile (the im2col gather into LDS dominated): this is a direct VALU kernel.
-// One lane = one output pixel: its 27 input taps are loaded once into registers (27 independent loads in flight),
-// the weights sit in LDS and are read as wave-uniform broadcasts, the N outputs of the pixel leave as contiguous
-// 16-byte NHWC stores, and per-channel sum / sum-of-squares go to the block's statistics slab row.
+// Stem: 3x3 stride-2 convolution of the NCHW f32 image (Cin*9 = 27 taps) into 32 NHWC bf16 channels, forward and weight
+// gradient.  One lane gathers the 27 taps of one output pixel straight from the image planes (9 dword-aligned 16-byte
+// loads), both contractions run on v_mfma_f32_16x16x32_bf16 with the taps padded to one 32-deep k-step.
+// History (profiles/README.md): VALU kernels first (864 FMAs per pixel forward: 196 us; an LDS-bound per-pixel outer
+// product for the gradient: 368 us), then these: 120 us and 158 us.
 #include "common.h"
 
 namespace {
 
 constexpr int NT = 256;
-constexpr int MAXK = 32;   // Cin * 9 padded
-constexpr int MAXN = 64;
 
 struct StemArgs {
   const void* x; int x_f32;
@@ -17,88 +15,51 @@ struct StemArgs {
   int B, Cin, Hin, Win, Hout, Wout, N, stride;
 };
 
-template <typename T, typename TX, int NCH8>  // TX = image element type, NCH8 = N / 8 output channel vectors per pixel
-__global__ __launch_bounds__(NT) void stem_fwd_kernel(const StemArgs g) {
-  constexpr int N = NCH8 * 8;
-  __shared__ __align__(16) float wl[MAXK * N];      // [k][n]: one tap's N weights are contiguous (broadcast reads)
-  __shared__ float red[NT / 64][2][N];
-  const int tid = threadIdx.x;
-  const int K = g.Cin * 9;
-  for (int i = tid; i < MAXK * N; i += NT) {
-    const int k = i / N, n = i - k * N;
-    wl[i] = k < K ? g.w[n * K + k] : 0.f;
-  }
-  __syncthreads();
-  const TX* x = reinterpret_cast<const TX*>(g.x);
-  T* y = reinterpret_cast<T*>(g.y);
-  float s1[N], s2[N];
+// The 27 taps (3 channels x 3 x 3, padding 1) of output pixel (b, oy, ox) of the stride-`stride` stem, zero where the
+// window leaves the image.  f32 image, stride 2: the three kx taps of a (channel, row) are adjacent floats, so ONE
+// 16-byte load (dword-aligned; gfx950 runs global memory in unaligned-access mode) replaces three scalar loads --
+// 9 load instructions per pixel instead of 27, which is what bounds these kernels (64 lanes x 4 B scattered over
+// 512 B per instruction).  The load window is clamped into the row, the taps are picked from it by position.
+struct __attribute__((packed, aligned(4))) F4u { float x, y, z, w; };
+template <typename TX>
+__device__ __forceinline__ void stem_taps(const TX* x, long b, int oy, int ox, bool in, int Cin, int Hin, int Win,
+                                          int stride, long plane, float v[27]) {
+  if (sizeof(TX) == 4 && stride == 2 && Win >= 4) {
+    const int ix0 = 2 * ox - 1;
+    const int base = ix0 < 0 ? 0 : (ix0 > Win - 4 ? Win - 4 : ix0);
+    const int sh = ix0 - base;                      // -1 (left edge), 0, or +1 (right edge)
 #pragma unroll
-  for (int n = 0; n < N; ++n) { s1[n] = 0.f; s2[n] = 0.f; }
-  const long P = (long)g.B * g.Hout * g.Wout;
-  const long HWo = (long)g.Hout * g.Wout;
-  const long plane = (long)g.Hin * g.Win;
-  for (long p = (long)blockIdx.x * NT + tid; p < P; p += (long)gridDim.x * NT) {
-    const long b = p / HWo; const long rem = p - b * HWo;
-    const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-    // clamped tap offsets inside one plane + validity (shared by the channels)
-    int off[9]; bool ok[9];
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = oy * g.stride + ky - 1;
-      const bool vy = iy >= 0 && iy < g.Hin;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy + ky - 1;
+        const bool vy = in && c < Cin && iy >= 0 && iy < Hin;
+        const float* row = reinterpret_cast<const float*>(x) + (b * Cin + (c < Cin ? c : 0)) * plane + (long)(vy ? iy : 0) * Win + base;
+        const F4u f = *reinterpret_cast<const F4u*>(row);
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox * g.stride + kx - 1;
-        ok[ky * 3 + kx] = vy && ix >= 0 && ix < g.Win;
-        off[ky * 3 + kx] = (vy ? iy : 0) * g.Win + (ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix));
-      }
-    }
-    float acc[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) acc[n] = 0.f;
-    for (int c = 0; c < g.Cin; ++c) {
-      const TX* xp = x + (b * g.Cin + c) * plane;
-      float xin[9];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) { const float v = (float)xp[off[t]]; xin[t] = ok[t] ? v : 0.f; }
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float* wk = wl + (c * 9 + t) * N;
-#pragma unroll
-        for (int n = 0; n < N; n += 4) {
-          const float4 wv = *reinterpret_cast<const float4*>(wk + n);
-          acc[n] += xin[t] * wv.x; acc[n + 1] += xin[t] * wv.y; acc[n + 2] += xin[t] * wv.z; acc[n + 3] += xin[t] * wv.w;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int idx = kx + sh;                  // position of tap kx inside the window; -1 = left padding
+          const float t = idx <= 0 ? f.x : (idx == 1 ? f.y : (idx == 2 ? f.z : f.w));
+          v[c * 9 + ky * 3 + kx] = (vy && idx >= 0 && ix0 + kx < Win) ? t : 0.f;
         }
       }
-    }
+    return;
+  }
 #pragma unroll
-    for (int v = 0; v < NCH8; ++v) {
-      float o[8];
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        o[j] = V8<T>::round(acc[v * 8 + j]);
-        s1[v * 8 + j] += o[j];
-        s2[v * 8 + j] += o[j] * o[j];
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy * stride + ky - 1;
+      const bool vy = iy >= 0 && iy < Hin;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = ox * stride + kx - 1;
+        const bool ok = in && c < Cin && vy && ix >= 0 && ix < Win;
+        const long off = (b * Cin + (c < Cin ? c : 0)) * plane + (vy ? iy : 0) * (long)Win + (ix < 0 ? 0 : (ix >= Win ? Win - 1 : ix));
+        const float t = (float)x[off];
+        v[c * 9 + ky * 3 + kx] = ok ? t : 0.f;
       }
-      V8<T>::store(y + p * g.ldy + v * 8, o);
     }
-  }
-  if (g.stats) {
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const float a = wave_sum(s1[n]), b = wave_sum(s2[n]);
-      if (lane == 0) { red[wave][0][n] = a; red[wave][1][n] = b; }
-    }
-    __syncthreads();
-    for (int i = tid; i < 2 * N; i += NT) {
-      const int which = i / N, n = i - which * N;
-      double s = 0.0;
-      for (int wv = 0; wv < NT / 64; ++wv) s += (double)red[wv][which][n];
-      g.stats[(long)blockIdx.x * 2 * N + i] = s;
-      for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) g.stats[(long)r * 2 * N + i] = 0.0;
-    }
-  }
 }
 
 // MFMA form of the stem forward (the performance path).  The VALU kernel above spends 864 FMAs per pixel (VALU-bound,
@@ -143,22 +104,7 @@ __global__ __launch_bounds__(NT, 2) void stem_fwd_mfma_kernel(const StemArgs g) 
       const long b = pc / HWo; const long rem = pc - b * HWo;
       const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
       float v[32];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = oy * g.stride + ky - 1;
-          const bool vy = iy >= 0 && iy < g.Hin;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * g.stride + kx - 1;
-            const bool ok = in && c < g.Cin && vy && ix >= 0 && ix < g.Win;
-            const long off = (b * g.Cin + (c < g.Cin ? c : 0)) * plane + (vy ? iy : 0) * (long)g.Win +
-                             (ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix));
-            const float t = (float)x[off];
-            v[c * 9 + ky * 3 + kx] = ok ? t : 0.f;
-          }
-        }
+      stem_taps<TX>(x, b, oy, ox, in, g.Cin, g.Hin, g.Win, g.stride, plane, v);
 #pragma unroll
       for (int k = 27; k < 32; ++k) v[k] = 0.f;
       __syncthreads();   // the previous tile's fragment reads are done
@@ -369,22 +315,7 @@ __global__ __launch_bounds__(NT, 2) void stem_wgrad_mfma_kernel(const StemWgradA
       const long b = pc / HWo; const long rem = pc - b * HWo;
       const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
       float v[27];
-#pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = oy * g.stride + ky - 1;
-          const bool vy = iy >= 0 && iy < g.Hin;
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * g.stride + kx - 1;
-            const bool ok = in && c < g.Cin && vy && ix >= 0 && ix < g.Win;
-            const long off = (b * g.Cin + (c < g.Cin ? c : 0)) * plane + (vy ? iy : 0) * (long)g.Win +
-                             (ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix));
-            const float t = (float)x[off];
-            v[c * 9 + ky * 3 + kx] = ok ? t : 0.f;
-          }
-        }
+      stem_taps<TX>(x, b, oy, ox, in, g.Cin, g.Hin, g.Win, g.stride, plane, v);
 #pragma unroll
       for (int k = 0; k < 27; ++k) Xt[k * ROW + tid] = (T)v[k];
     }
