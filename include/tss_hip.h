@@ -73,16 +73,18 @@ const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launc
  * replaces: nn.Conv2d(k=1, bias=False) (+BatchNorm2d, ReLU fused as described above) built by
  *           Conv2dBlock TSS/models/fastscnn.py:164-173, DSConv2dBlock :194, ConvBlock TSS/models/contextnet.py:168-177
  *           and the biased classifier conv TSS/models/fastscnn.py:97, TSS/models/contextnet.py:86.
- * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional) = partial sums of y and y^2. */
+ * y[p][n] = sum_k act(x[p][k]) * w[n][k] (+ bias[n]);  stats (optional) = partial sums of y and y^2.
+ * w_bf16 (optional, bf16 path): a current bf16 copy [N][K] of w written by tss_cast_weights -- staged with plain copies. */
 int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                   const float* w, const float* bias, void* y, long ldy, double* stats,
+                   const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
  * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
+ * wT_bf16 (optional, bf16 path): a current bf16 TRANSPOSE [K][N] of w written by tss_cast_weights.
  * wg_ws / wg_dw (optional): the workspace and dW of a tss_pwconv_bwd_weight(..., defer_reduce = 1) call of the SAME layer
  * (same P, K, N): its slot reduction is carried by the first blocks of this launch instead of a kernel of its own. */
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                         long P, int K, int N, int dtype, void* stream);
@@ -178,6 +180,9 @@ int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot,
 int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float p,
                 const unsigned long long* seed_slot, int dtype, void* stream);
 int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtype, void* stream);
+/* bf16 shadows of 1x1 weights, all layers in one launch.  table: njobs x 5 int64 on the device:
+ * (f32 source [N][K], bf16 copy [N][K], bf16 transpose [K][N], N, K); blocks_per_job x njobs blocks of 256 threads. */
+int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, void* stream);
 int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                    const float* lr, float beta1, float beta2, float eps, float weight_decay,
                    float* state, float grad_scale, void* stream);

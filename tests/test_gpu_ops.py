@@ -255,10 +255,51 @@ def test_pw_weight_gradient_reduce_carried_by_backward_data(K, Nn, P):
         gargs = (N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu))
         xargs = (N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1)
         N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), defer, P, K, Nn, 1, st)
-        N.call('tss_pwconv_bwd_data', *gargs, N.ptr(w), *xargs, N.ptr(ein), K, N.ptr(bst),
+        N.call('tss_pwconv_bwd_data', *gargs, N.ptr(w), None, *xargs, N.ptr(ein), K, N.ptr(bst),
                N.ptr(ws) if defer else None, N.ptr(dw) if defer else None, P, K, Nn, 1, st)
         return dw, ein.float(), bst.sum(0)
 
     a, b = run(0), run(1)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert a[0].abs().max() > 0
+
+
+def test_weight_shadows_give_bit_identical_pointwise_results():
+    """WeightShadows (bf16 copies written by tss_cast_weights) only change HOW the weight tile is staged: forward,
+    input gradient and statistics of a train step are bit-identical with and without them."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    from torch_semantic_segmentation_amd.models.fastscnn import FastSCNN
+    torch.manual_seed(11)
+    model = FastSCNN(3, 19).to(DEV)
+    tssa.set_compute_dtype(model, torch.bfloat16)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    x = torch.randn(2, 3, 64, 128, device=DEV)
+    y = torch.randint(0, 19, (2, 64, 128), device=DEV)
+    loss_fn = tssa.CrossEntropyLoss(ignore_index=255)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def step(shadows):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        model.train()
+        if shadows is not None:
+            shadows.refresh()
+            with shadows:
+                loss = loss_fn(model(x), y)
+                loss.backward()
+        else:
+            loss = loss_fn(model(x), y)
+            loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    sh = ops.WeightShadows(model)
+    assert len(sh.weights) >= 30 and not ops._SHADOWS
+    la, ga = step(None)
+    lb, gb = step(sh)
+    assert not ops._SHADOWS                       # nothing leaks out of the with-block
+    assert la == lb
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n

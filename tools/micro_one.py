@@ -18,8 +18,8 @@ st = N.stream()
 nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1) if which == 'wgrad' else 0
 wsw = torch.empty(nws, device=dev) if nws and os.environ.get('TSS_WG_ATOMIC') != '1' else None
 fns = {
- 'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
- 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st),
+ 'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
+ 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), None, N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st),
  'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), 0, P, K, Nn, 1, st),
 }
 if which in ('dwfwd', 'dwbwd', 'dwwg'):
@@ -47,8 +47,8 @@ if os.environ.get('TSS_TIMING') == '1' and which.startswith('pw'):
     buf = (ctypes.c_ulonglong * 8)()
     N.lib().tss_debug_pw_timing(buf, 1)
     n = max(buf[7], 1)
-    for q, nm in enumerate(['prologue', 'loop', 'tail']):
-        print('%-10s %10.0f cycles/block' % (nm, buf[q] / n))
+    for q, nm in enumerate(['prologue', 'loop', 'tail', ' pro:setup', ' pro:issue', ' pro:weights', ' pro:consts']):
+        print('%-12s %10.0f cycles/block' % (nm, buf[q] / n))
     print('blocks', n // 10)
 elif os.environ.get('TSS_TIMING') == '1' and which.startswith('dw'):
     import ctypes

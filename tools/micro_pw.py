@@ -27,9 +27,9 @@ for (K, Nn) in ((128, 128), (64, 384), (384, 64), (32, 48), (128, 768), (768, 12
         mK = torch.zeros(K, device=dev); sK = torch.ones(K, device=dev)
         mN = torch.zeros(Nn, device=dev); sN = torch.ones(Nn, device=dev)
         st = N.stream()
-        fwd = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st)
-        fwd0 = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, None, None, None, 0, N.ptr(w), None, N.ptr(y), Nn, None, P, K, Nn, 1, st)
-        bwd = lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w),
+        fwd = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st)
+        fwd0 = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, None, None, None, 0, N.ptr(w), None, None, N.ptr(y), Nn, None, P, K, Nn, 1, st)
+        bwd = lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), None,
                              N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st)
         wg = lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN),
                             N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), None, 0, P, K, Nn, 1, st)

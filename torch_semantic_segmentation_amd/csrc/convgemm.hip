@@ -470,10 +470,10 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
 extern int g_tss_disable_fast;   // pwfast.hip
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                    const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
+                    const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream);                                                                    // pwfast.hip
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
-                         const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
+                         const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
                          long P, int K, int N, hipStream_t stream);  // pwfast.hip
@@ -484,7 +484,7 @@ bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void*
 extern "C" {
 
 int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                   const float* w, const float* bias, void* y, long ldy, double* stats,
+                   const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (ldx % 8) == 0 && (ldy % 4) == 0 && ldx >= K && ldy >= (N + 3) / 4 * 4,
@@ -498,14 +498,14 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
   g.y = y; g.ldy = ldy; g.stats = stats;
   if (dtype == TSS_BF16 && !g_tss_disable_fast && K <= 768) {   // lean bf16 kernels (pwfast.hip)
     tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * 2, 2.0 * (double)P * K * N);
-    if (tss_pwfast_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, bias, y, ldy, stats, P, K, N, (hipStream_t)stream))
+    if (tss_pwfast_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, w_bf16, bias, y, ldy, stats, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_fwd");
   }
   return launch(g, dtype, TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * esz(dtype));
 }
 
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                         long P, int K, int N, int dtype, void* stream) {
@@ -527,7 +527,7 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   const double bytes = (double)P * (N * (yraw ? 2 : 1) + K * (xraw ? 2 : 1)) * esz(dtype);
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 768 && (N % 8) == 0 && (K % 4) == 0) {
     tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
-    if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
+    if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, wT_bf16, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
                             e_in, ldei, bstats, wg_ws, wg_dw, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_bwd_data");
   }

@@ -352,6 +352,25 @@ __global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, flo
 
 inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 
+// bf16 shadows of the 1x1 convolution weights, all layers in one launch: job j = (f32 source [N][K], bf16 copy [N][K],
+// bf16 transpose [K][N]).  The pointwise kernels stage their weight tiles from these with plain 16-byte copies
+// (forward reads the copy, backward-data the transpose) instead of converting f32 per block.
+__global__ __launch_bounds__(256) void cast_weights_kernel(const long long* table, int njobs) {
+  const int job = blockIdx.y;
+  if (job >= njobs) return;
+  const long long* t = table + (long)job * 5;
+  const float* src = reinterpret_cast<const float*>(t[0]);
+  bf16_t* dst = reinterpret_cast<bf16_t*>(t[1]);
+  bf16_t* dstT = reinterpret_cast<bf16_t*>(t[2]);
+  const long N = t[3], K = t[4];
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < N * K; e += (long)gridDim.x * 256) {
+    const bf16_t v = (bf16_t)src[e];
+    const long n = e / K, k = e - n * K;
+    dst[e] = v;
+    dstT[k * N + n] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -475,6 +494,13 @@ int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin,
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(permute_w3x3_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, w, w_tnc, w_tcn, N, Cin);
   return tss::check_last("permute_w3x3");
+}
+
+int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, void* stream) {
+  TSS_REQUIRE(njobs >= 0 && blocks_per_job >= 1, TSS_ERR_SHAPE);
+  if (njobs == 0) return TSS_OK;
+  hipLaunchKernelGGL(cast_weights_kernel, dim3(blocks_per_job, njobs), dim3(256), 0, (hipStream_t)stream, table, njobs);
+  return tss::check_last("cast_weights");
 }
 
 int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,

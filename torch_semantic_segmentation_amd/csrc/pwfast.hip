@@ -33,6 +33,7 @@ struct FastArgs {
   const float* c0; const float* c1; const float* c2; const float* c3;   // see convgemm.hip GemmArgs
   int a_relu;
   const float* w; int w_trans;         // 0: w[n*K + k]   1: w[k*N + n]
+  const T* wb; long ldwb;              // optional bf16 shadow laid out [output channel][contraction] (tss_cast_weights)
   const float* bias;
   T* y; long ldy; double* stats;
   const T* xm; long ldxm; const float* mm; const float* ms; const float* mb; int m_relu;
@@ -94,6 +95,27 @@ __device__ __forceinline__ void stage_weights(T* Ws, const float* w, int w_trans
         }
       }
     }
+  }
+}
+
+// Weight chunk from a bf16 shadow wb[(n0+n)*ldwb + kb + j] (already [output][contraction]): plain 16-byte copies,
+// one round trip (<= 8 loads per thread for a 128 x 128 chunk), zero outside [0, ncw) x [0, kw).
+__device__ __forceinline__ void stage_weights_bf16(T* Ws, const T* wb, long ldwb, int n0, int ncw, int nrows,
+                                                   int kb, int kw, int kwp, int tid) {
+  const int tx = tid & 15, ty = tid >> 4;     // 16-byte vector within the row, row within a pass of 16
+  const bool cok = tx * 8 < kw;               // kw % 8 == 0 (host-checked)
+  uint4 wv[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int n = u * 16 + ty;
+    const bool ok = cok && n < ncw;
+    wv[u] = *reinterpret_cast<const uint4*>(wb + (ok ? (long)(n0 + n) * ldwb + kb + tx * 8 : 0));
+    if (!ok) wv[u] = make_uint4(0u, 0u, 0u, 0u);
+  }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int n = u * 16 + ty;
+    if (n < nrows && tx * 8 < kwp) *reinterpret_cast<uint4*>(Ws + n * RS + tx * 8) = wv[u];
   }
 }
 
@@ -193,11 +215,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
       }
     }
   };
+  TSS_T(tqa);
   if (t_begin < t_end) issue_loads(t_begin);
+  TSS_T(tqb);
 
   // block set-up under the first tile's loads
   // ---- weights -> LDS once per block (resident): Ws[n][k], zero beyond ncw / K
-  stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, 0, K, kwp, tid);
+  if (g.wb) stage_weights_bf16(Ws, g.wb, g.ldwb, n0, ncw, nrows, 0, K, kwp, tid);
+  else stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, 0, K, kwp, tid);
+  TSS_T(tqc);
 
   // ---- this lane's prologue coefficients (registers), mean folded into the additive term.  Unconditional 16-byte
   // loads through null-safe pointers: a `ptr ? ptr[i] : c` per element is a branch + wait per load.
@@ -397,7 +423,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 #ifdef TSS_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSS_T(tq3);
-  if (threadIdx.x == 0) { atomicAdd(&g_pw_timing[0], tq1 - tq0); atomicAdd(&g_pw_timing[1], tq2 - tq1); atomicAdd(&g_pw_timing[2], tq3 - tq2); atomicAdd(&g_pw_timing[7], 1ull); }
+  if (threadIdx.x == 0) { atomicAdd(&g_pw_timing[0], tq1 - tq0); atomicAdd(&g_pw_timing[1], tq2 - tq1); atomicAdd(&g_pw_timing[2], tq3 - tq2); atomicAdd(&g_pw_timing[3], tqa - tq0); atomicAdd(&g_pw_timing[4], tqb - tqa); atomicAdd(&g_pw_timing[5], tqc - tqb); atomicAdd(&g_pw_timing[6], tq1 - tqc); atomicAdd(&g_pw_timing[7], 1ull); }
 #endif
 }
 
@@ -510,7 +536,8 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
           }
         }
       }
-      stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, kb, kw, kwp, tid);
+      if (g.wb) stage_weights_bf16(Ws, g.wb, g.ldwb, n0, ncw, nrows, kb, kw, kwp, tid);
+      else stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, kb, kw, kwp, tid);
       if (lane_on) {
         float k0[8], k1[8], kadd[8];
         const int cb = kb + (cv_real ? cv * 8 : 0);
@@ -699,7 +726,7 @@ int g_tss_disable_fast = 0;   // tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1): 
 
 // forward: y = act(x) W^T (+bias).  Returns false when the shape is not covered (caller uses convgemm_kernel).
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                    const float* w, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
+                    const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream) {
   // a ragged N (the 19-class classifier) is fine when there are no statistics and the row pitch has room for the
   // zero the last 4-channel group writes into the padding
@@ -709,13 +736,14 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.P = P; g.K = K; g.N = N;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
+  if (w_bf16 && (K % 8) == 0 && tss::aligned16(w_bf16)) { g.wb = (const T*)w_bf16; g.ldwb = K; }   // rows of K contraction channels
   if (K <= KMAX) launch_fast<false, 128>(g, stream); else launch_fast_mc<false>(g, stream);
   return true;
 }
 
 // backward-data: e_in = relu'(act(x)) * (g W), g = ga*(e-gce) + gb*(yraw-gmu); contraction over N (must be <= 128)
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
-                         const float* gce, const float* gmu, const float* w, const void* xraw, long ldx,
+                         const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
                          long P, int K, int N, hipStream_t stream) {
@@ -728,6 +756,7 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   g.P = P; g.K = N; g.N = K;
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr; g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
+  if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wb = (const T*)wT_bf16; g.ldwb = N; }   // transpose [conv K][conv N]: rows of N contraction channels
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   if (N <= KMAX) launch_fast<true, 64>(g, stream); else launch_fast_mc<true>(g, stream);
   return true;

@@ -126,6 +126,7 @@ class Trainer:
             and hasattr(model, 'forward_lowres') and hasattr(model, 'logit_scale')
         if self.flat:
             optimizer.grad_scale = 1.0 / world_size
+        self.shadows = None
         self._graph = None
         self._static = None
         self.iteration = 0
@@ -135,7 +136,10 @@ class Trainer:
     def _forward_backward(self, x, y):
         self.model.train()
         self.optimizer.zero_grad()
-        with ops.direct_grads(self.flat):
+        if self.shadows is None:
+            self.shadows = ops.WeightShadows(self.model)
+        self.shadows.refresh()                       # the optimizer step of the previous iteration changed the weights
+        with ops.direct_grads(self.flat), self.shadows:
             if self.fuse_head_loss and not (self.model._forward_hooks or self.model._forward_pre_hooks):
                 low = self.model.forward_lowres(x)
                 loss = ops.upsample_cross_entropy(low, y, scale_factor=self.model.logit_scale,

@@ -57,6 +57,65 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+# bf16 shadows of the 1x1 convolution weights (WeightShadows below): {weight.data_ptr(): (copy [N][K], transpose [K][N])},
+# only populated while a `with shadows:` block is active, i.e. while somebody guarantees they are current.
+_SHADOWS = {}
+
+
+class WeightShadows:
+    """bf16 copies (and transposes) of every 1x1 convolution weight of a model, refreshed by ONE kernel launch
+    (`tss_cast_weights`).  The pointwise kernels then stage their weight tiles with plain 16-byte copies instead of
+    converting f32 in every block.  Opt-in and explicit: the owner calls refresh() whenever the weights changed
+    (Trainer: at the top of every step, inside the captured graph) and wraps the pass in `with shadows:`; outside such
+    a block the kernels read the f32 weights as before, so a stale shadow can never be used."""
+
+    def __init__(self, module):
+        ws = [p for p in module.parameters() if p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1
+              and p.dtype == torch.float32 and p.is_cuda and p.shape[1] % 8 == 0]
+        self.weights = ws
+        self.table = None
+        self.entries = {}
+        if not ws:
+            return
+        dev = ws[0].device
+        rows, off = [], 0
+        for p in ws:
+            n, k = p.shape[0], p.shape[1]
+            rows.append((p, off, n, k))
+            off += (n * k + 7) // 8 * 8                                # 16-byte aligned segments
+        self.flat = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        self.flat_t = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        table = []
+        for p, o, n, k in rows:
+            c, t = self.flat[o:o + n * k], self.flat_t[o:o + n * k]
+            self.entries[p.data_ptr()] = (c, t)
+            table.append([p.data_ptr(), c.data_ptr(), t.data_ptr(), n, k])
+        self.table = torch.tensor(table, dtype=torch.int64, device=dev)
+        self.blocks = max(1, min(64, (max(n * k for _, _, n, k in rows) + 255) // 256))
+
+    def refresh(self):
+        if self.table is not None:
+            for p in self.weights:                                        # parameters re-pointed since construction?
+                if p.data_ptr() not in self.entries:
+                    raise RuntimeError('WeightShadows: a parameter was reallocated; rebuild the shadows')
+            call('tss_cast_weights', ptr(self.table), self.table.shape[0], self.blocks, stream())
+
+    def __enter__(self):
+        self.prev = dict(_SHADOWS)
+        _SHADOWS.update(self.entries)
+        return self
+
+    def __exit__(self, *exc):
+        _SHADOWS.clear()
+        _SHADOWS.update(self.prev)
+        return False
+
+
+def _shadow(weight, which):
+    ent = _SHADOWS.get(weight.data_ptr()) if _SHADOWS else None
+    return ptr(ent[which]) if ent is not None else None
+
+
 def _aff(link):
     """(mean, scale, bias) device pointers of a pending BatchNorm: a = (x - mean) * scale + bias."""
     if link is None:
@@ -267,7 +326,7 @@ class ConvUnitFn(Function):
         aff = _aff(cfg.in_link)
         st = stream()
         if cfg.kind == 'pw':
-            call('tss_pwconv_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), ptr(bias),
+            call('tss_pwconv_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), _shadow(weight, 0), ptr(bias),
                  ptr(y), ld(y), stats, P, cfg.cin, Cout, dt, st)
         elif cfg.kind == 'dw':
             if bias is not None:
@@ -383,7 +442,7 @@ class ConvUnitFn(Function):
                 margs = xargs if deferred_in else (None, 0, None, None, None, 0)
                 bst = ptr(il.bstats) if il is not None else None
                 if cfg.kind == 'pw':
-                    call('tss_pwconv_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
+                    call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
                 elif cfg.kind == 'dw':
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
