@@ -28,11 +28,12 @@ def _deps_mtime():
 
 def _compile(src, force):
     path = os.path.join(CSRC, src)
-    obj = os.path.join(CSRC, os.path.splitext(src)[0] + '.o')
+    timing = os.environ.get('TSS_TIMING') == '1'     # debug variant (phase timers): its own object files, never mixed
+    obj = os.path.join(CSRC, os.path.splitext(src)[0] + ('.timing.o' if timing else '.o'))
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
         return obj, False
-    extra = ['-DTSS_TIMING'] if os.environ.get('TSS_TIMING') == '1' else []   # debug: phase timers in wgfast_kernel
+    extra = ['-DTSS_TIMING'] if timing else []
     cmd = [HIPCC] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.cpp') else []) + ['-c', path, '-o', obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -46,13 +47,17 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as pool:
         results = list(pool.map(lambda s: _compile(s, force), SOURCES))
     objs = [o for o, _ in results]
-    if any(changed for _, changed in results) or not os.path.exists(LIB):
+    variant = 'timing' if os.environ.get('TSS_TIMING') == '1' else 'release'
+    stamp = os.path.join(CSRC, '.variant')
+    same = os.path.exists(stamp) and open(stamp).read().strip() == variant
+    if any(changed for _, changed in results) or not os.path.exists(LIB) or not same:
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (res.stdout, res.stderr))
+        open(stamp, 'w').write(variant)
         if verbose:
-            print('built', LIB)
+            print('built', LIB, '(%s)' % variant)
     elif verbose:
         print('up to date', LIB)
     return LIB
