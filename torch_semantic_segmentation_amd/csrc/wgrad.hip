@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
 
   TSS_T(tkl);
   if (g.ws) {
-    // partial tile -> this block's workspace slot, row-major [n_local][k_local] (plain stores; blocks without stages
+    // partial tile -> this block's workspace slot, one 16x16 MFMA fragment after the other (plain stores; blocks without stages
     // write their zeros); wg_reduce_kernel sums the slots.  Measured on the 128x128 layer at 1/8 resolution: the f32
     // atomics of 512 blocks onto one 64 KB tile cost 42 us of an 86 us kernel whose streaming loop already runs at
     // HBM speed.  Waves that split the pixels of a stage (same fragment window, other k-steps) first meet in LDS.
@@ -541,10 +541,10 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (i < cn && j < ck) {
-            const int kl = (jb + j) * 16 + fr;
+          if (i < cn && j < ck) {   // fragment-major slot layout (wgreduce.h): every store instruction writes 256 contiguous bytes
+            float* wf = wt + ((ib + i) * (TKe >> 4) + (jb + j)) * 256 + fq * 16 + fr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) wt[((ib + i) * 16 + fq * 4 + r) * TKe + kl] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r) wf[r * 64] = acc[i][j][r];
           }
         }
     }

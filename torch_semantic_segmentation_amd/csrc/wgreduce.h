@@ -20,7 +20,7 @@ inline Split split_for(long P, int K, int N) {
   s.pt = ((wn > wk ? wn : wk) <= 64) ? 128 : 64;      // 128-pixel stages when both chunk widths are <= 64 channels
   s.tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
   const long nstage = (P + s.pt - 1) / s.pt;
-  const long min_stages = 512 / s.pt;                 // a block amortises its set-up + partial tile over >= 512 pixels
+  const long min_stages = 512 / s.pt;                 // a block amortises its set-up + partial tile over >= 512 pixels (256 and 1024 measured: worse)
   long ns = 1024 / s.tiles;
   if (ns < 1) ns = 1;
   if (ns > (nstage + min_stages - 1) / min_stages) ns = (nstage + min_stages - 1) / min_stages;
@@ -47,8 +47,14 @@ __device__ __forceinline__ void reduce_block(const ReduceArgs& r, int bid, float
   const int TNe = ws_dim(r.ND), TKe = ws_dim(r.KD);
   const int slot_n = TNe * TKe, segs = slot_n >> 8;               // slot_n is a multiple of 256
   const int tile = bid / segs, seg = bid - tile * segs;
-  const int idx = seg * 256 + lane * 4;                           // 4 consecutive k of one row (TKe % 16 == 0)
-  const int nl = idx / TKe, kl = idx - nl * TKe;
+  // slot layout = the MFMA accumulator layout, fragment after fragment: element (n, k) of the tile sits at
+  //   ((n / 16) * (TKe / 16) + k / 16) * 256 + (n % 4) * 64 + ((n % 16) / 4) * 16 + k % 16
+  // so a wgfast store instruction (one accumulator register of 64 lanes) writes 256 contiguous bytes, and 4 consecutive
+  // elements here are 4 consecutive k of one row
+  const int idx = seg * 256 + lane * 4;
+  const int frag = seg, off = lane * 4;                           // one fragment per 256-element segment
+  const int fi = frag / (TKe >> 4), fj = frag - fi * (TKe >> 4);
+  const int nl = fi * 16 + ((off & 63) >> 4) * 4 + (off >> 6), kl = fj * 16 + (off & 15);
   const int nc = tile % r.nchn, kc = tile / r.nchn;
   const int ncw = (r.ND - nc * TN < TN) ? (r.ND - nc * TN) : TN, kcw = (r.KD - kc * TK < TK) ? (r.KD - kc * TK) : TK;
   const int FN = (ncw + 15) >> 4, FK = (kcw + 15) >> 4;
