@@ -95,14 +95,12 @@ def pmc_traffic(symbol, args):
     if not files:
         return None
     table = json.load(open(files[-1]))
-    tot = n = 0.0
+    tot = n = 0.0       # launch-weighted mean over every kernel the entry point dispatched to
     for alt in symbol.split('|'):
         for k, v in table.items():
             if k.startswith(alt.split('<')[0]) and (('<' not in alt) or k.startswith(alt.rstrip('>'))):
                 tot += v['hbm_bytes_per_launch'] * v['launches_sampled']
                 n += v['launches_sampled']
-        if n:
-            break       # the first alternative is the kernel the bf16 path actually runs
     return round(tot / n) if n else None
 
 
