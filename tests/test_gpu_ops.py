@@ -303,3 +303,37 @@ def test_weight_shadows_give_bit_identical_pointwise_results():
     assert la == lb
     for n in ga:
         assert torch.equal(ga[n], gb[n]), n
+
+
+@pytest.mark.parametrize('B,H,W', [(2, 16, 32), (1, 9, 11), (3, 10, 6), (2, 7, 4), (1, 33, 70), (4, 64, 128)])
+def test_stem_mfma_kernels_match_torch_at_odd_sizes(B, H, W):
+    """bf16 stem through the C ABI (MFMA forward + weight gradient, 16-byte tap gathers clamped into the row) vs torch
+    conv2d on the same operands, including odd widths / heights where the window leaves the image on the right and at
+    the bottom.  The operands are given (no BatchNorm statistics in the loop), so the bounds are bf16-tight."""
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(4)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    P = B * Ho * Wo
+    x = torch.randn(B, 3, H, W, device=DEV)
+    w = torch.randn(32, 3, 3, 3, device=DEV) * 0.2
+    st, S = N.stream(), N.stat_slabs()
+    y = torch.empty(P, 32, device=DEV, dtype=torch.bfloat16)
+    stats = torch.empty(S, 64, dtype=torch.float64, device=DEV)
+    N.call('tss_stem3x3_fwd', N.ptr(x), 1, N.ptr(w), N.ptr(y), 32, N.ptr(stats), B, 3, H, W, 32, 2, 1, st)
+    ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, 2, 1)              # the kernel's operand rounding
+    got = y.float().view(B, Ho, Wo, 32).permute(0, 3, 1, 2)
+    assert rel(got, ref) < 6e-3
+    tot = stats.sum(0)
+    assert rel(tot[:32].float(), got.sum((0, 2, 3))) < 1e-4 and rel(tot[32:].float(), (got * got).sum((0, 2, 3))) < 1e-4
+    # weight gradient: dW = conv_backward_weight(x, g), g = ga*(e - gce) + gb*(yraw - gmu)
+    e = torch.randn(P, 32, device=DEV).bfloat16()
+    ga, gb = torch.rand(32, device=DEV) + 0.5, torch.randn(32, device=DEV) * 0.3
+    gce, gmu = torch.randn(32, device=DEV) * 0.1, torch.randn(32, device=DEV) * 0.2
+    dw = torch.zeros(32, 3, 3, 3, device=DEV)
+    ws = torch.full((S, 32 * 28), float('nan'), device=DEV)
+    N.call('tss_stem3x3_bwd_weight', N.ptr(e), 32, N.ptr(y), 32, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+           N.ptr(x), 1, N.ptr(dw), N.ptr(ws), B, 3, H, W, 32, 2, 1, st)
+    g = (ga * (e.float() - gce) + gb * (y.float() - gmu)).bfloat16().float().view(B, Ho, Wo, 32).permute(0, 3, 1, 2)
+    wr = w.clone().requires_grad_(True)
+    (F.conv2d(x.bfloat16().float(), wr, None, 2, 1) * g).sum().backward()
+    assert rel(dw, wr.grad) < 6e-3
