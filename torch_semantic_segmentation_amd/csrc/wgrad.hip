@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
 
-  const int nchn = (g.ND + TN - 1) / TN, nchk = (g.KD + TK - 1) / TK;
+  const int nchn = (g.ND + TN - 1) / TN;
   int bid = blockIdx.x;
   const int split = bid % g.nsplit; bid /= g.nsplit;
   const int nc = bid % nchn; bid /= nchn;
