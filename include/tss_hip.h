@@ -135,13 +135,15 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float
 int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                           void* e_in, long ldei, double* bstats,
+                           void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu,
                              const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                             float* dw, float* ws /* [tss_stat_slabs()][C*9] f32 workspace */,
+                             float* dw, float* ws /* [tss_stat_slabs()][C*9] f32 workspace */, int defer_reduce,
                              int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+/* defer_reduce = 1: the workspace rows are summed into dw by the tss_dwconv3x3_bwd_data call of the SAME layer that
+ * follows (its wg_ws / wg_dw arguments) instead of a kernel of its own. */
 
 /* Per-channel statistics buffers (`stats`, `bstats`, `stats_a/b` everywhere in this header) are
  * [tss_stat_slabs()][2*C] f64: every producing kernel writes one partial row per block and zeroes the rest, so

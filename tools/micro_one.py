@@ -30,8 +30,8 @@ if which in ('dwfwd', 'dwbwd', 'dwwg'):
     fns['dwfwd'] = lambda: N.call('tss_dwconv3x3_fwd', N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(wd), N.ptr(yo), C, N.ptr(sd), B, H, W, C, 1, 1, 1, st)
     ei = ops.new_nhwc(B, C, H, W, torch.bfloat16, dev); ei.normal_(); eo = ops.new_nhwc(B, C, H, W, torch.bfloat16, dev)
     dwd = torch.zeros(C, 1, 3, 3, device=dev); ws = torch.empty(S, C * 9, device=dev)
-    fns['dwbwd'] = lambda: N.call('tss_dwconv3x3_bwd_data', N.ptr(ei), C, N.ptr(yo), C, N.ptr(s1), N.ptr(s1), N.ptr(m), N.ptr(m), N.ptr(wd), N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(eo), C, N.ptr(sd), B, H, W, C, 1, 1, 1, st)
-    fns['dwwg'] = lambda: N.call('tss_dwconv3x3_bwd_weight', N.ptr(ei), C, N.ptr(yo), C, N.ptr(s1), N.ptr(s1), N.ptr(m), N.ptr(m), N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(dwd), N.ptr(ws), B, H, W, C, 1, 1, 1, st)
+    fns['dwbwd'] = lambda: N.call('tss_dwconv3x3_bwd_data', N.ptr(ei), C, N.ptr(yo), C, N.ptr(s1), N.ptr(s1), N.ptr(m), N.ptr(m), N.ptr(wd), N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(eo), C, N.ptr(sd), None, None, B, H, W, C, 1, 1, 1, st)
+    fns['dwwg'] = lambda: N.call('tss_dwconv3x3_bwd_weight', N.ptr(ei), C, N.ptr(yo), C, N.ptr(s1), N.ptr(s1), N.ptr(m), N.ptr(m), N.ptr(xi), C, N.ptr(m), N.ptr(s1), N.ptr(m), 1, N.ptr(dwd), N.ptr(ws), 0, B, H, W, C, 1, 1, 1, st)
 if which == 'ceup':
     B, C, h, w, sc = 8, K, Nn, P, 8
     low = ops.new_nhwc(B, C, h, w, torch.bfloat16, dev); low.normal_()

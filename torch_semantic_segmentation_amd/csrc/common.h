@@ -120,10 +120,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // in flight on the same 4 MiB L2 at about the same time.  Placement changes speed only, never
 // results.  The grid must be a multiple of 8 blocks (tss::persistent_blocks guarantees it).
 struct TileRange { int begin, end, step; };
-__device__ __forceinline__ TileRange xcd_tiles(int ntiles) {
-  const int xcd = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int slots = gridDim.x >> 3;
+// `lead` blocks (a multiple of 8) in front of the grid do something else (carried reductions): the sweep is over the
+// remaining gridDim.x - lead blocks, and blockIdx.x - lead keeps its XCD.
+__device__ __forceinline__ TileRange xcd_tiles(int ntiles, int lead = 0) {
+  const int bid = (int)blockIdx.x - lead;
+  const int xcd = bid & 7;
+  const int slot = bid >> 3;
+  const int slots = ((int)gridDim.x - lead) >> 3;
   const int per = (ntiles + 7) >> 3;
   const int b0 = xcd * per;
   int b1 = b0 + per;

@@ -30,6 +30,9 @@ struct DwArgs {
   float* dw; float* ws;
   int B, Hin, Win, C, stride, dil, Hout, Wout;
   int CV, NPL;
+  // backward-data only: the first `lead` blocks (a multiple of 8, `nred` of them working) sum the workspace rows of the
+  // same layer's weight gradient (dw_reduce_block)
+  const float* red_ws; float* red_dw; int red_rows, nred, lead;
 };
 
 template <typename T> struct StatAcc { typedef float type; };
@@ -39,7 +42,8 @@ template <> struct StatAcc<float> { typedef double type; };
 // slab row (plain stores), rows no block owns are zeroed here so the caller never has to clear the buffer.
 template <typename A>
 __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double* stats, int C, int CV, int NPL,
-                                            int cg, int pl, bool active, unsigned char* smem) {
+                                            int cg, int pl, bool active, unsigned char* smem, int lead = 0) {
+  const int grid = (int)gridDim.x - lead, bid = (int)blockIdx.x - lead;   // slab row = index among the sweeping blocks
   A* red = reinterpret_cast<A*>(smem);  // [NPL][2][C]
   __syncthreads();
   if (active) {
@@ -54,8 +58,8 @@ __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double
     const int which = i / C, c = i - which * C;
     double a = 0.0;
     for (int q = 0; q < NPL; ++q) a += (double)red[(q * 2 + which) * C + c];
-    stats[(long)blockIdx.x * 2 * C + i] = a;
-    for (int r = blockIdx.x + gridDim.x; r < TSS_STAT_SLABS; r += gridDim.x) stats[(long)r * 2 * C + i] = 0.0;
+    stats[(long)bid * 2 * C + i] = a;
+    for (int r = bid + grid; r < TSS_STAT_SLABS; r += grid) stats[(long)r * 2 * C + i] = 0.0;
   }
 }
 
@@ -367,30 +371,34 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_weight_kernel(const DwArgs g) {
 }
 
 // dw[i] += sum over the workspace rows.  64 columns per block with the lanes along the columns (every load
-// instruction reads one contiguous 256-byte piece of a row), 16 waves taking rows w, w+16, ... with up to 32 loads in
-// flight per lane: one memory round trip for 512 rows, then a 16-way LDS reduction.
-constexpr int RED_WAVES = 16;
-__global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
-  __shared__ float part[RED_WAVES][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+// instruction reads one contiguous 256-byte piece of a row), the block's waves taking rows w, w+nw, ... with up to 32
+// loads in flight per lane, then an LDS reduction over the waves.  Runs as its own kernel (16 waves) or as extra blocks
+// behind the same layer's backward-data grid (3-4 waves: one launch less, hidden behind the streaming blocks).
+__device__ __forceinline__ void dw_reduce_block(const float* ws, float* dw, int n, int rows, int bid, float* part /*[nw][64]*/) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int col = bid * 64 + lane;
   const int cc = col < n ? col : 0;
   float s = 0.f;
-  for (int r0 = wave; r0 < rows; r0 += RED_WAVES * 32) {
+  for (int r0 = wave; r0 < rows; r0 += nw * 32) {
     float v[32];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) { const int r = r0 + RED_WAVES * u; v[u] = ws[(long)(r < rows ? r : 0) * n + cc]; }
+    for (int u = 0; u < 32; ++u) { const int r = r0 + nw * u; v[u] = ws[(long)(r < rows ? r : 0) * n + cc]; }
 #pragma unroll
-    for (int u = 0; u < 32; ++u) s += (r0 + RED_WAVES * u < rows) ? v[u] : 0.f;
+    for (int u = 0; u < 32; ++u) s += (r0 + nw * u < rows) ? v[u] : 0.f;
   }
-  part[wave][lane] = s;
+  part[wave * 64 + lane] = s;
   __syncthreads();
   if (threadIdx.x < 64 && col < n) {
     float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < RED_WAVES; ++q) t += part[q][threadIdx.x];
+    for (int q = 0; q < nw; ++q) t += part[q * 64 + threadIdx.x];
     dw[col] += t;
   }
+}
+
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* ws, float* dw, int n, int rows) {
+  __shared__ float part[RED_WAVES * 64];
+  dw_reduce_block(ws, dw, n, rows, blockIdx.x, part);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -625,6 +633,10 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   __shared__ __align__(16) float wl[9 * 768];
   TSS_T(tq0);
   const int tid = threadIdx.x;
+  if ((int)blockIdx.x < g.lead) {   // carried weight-gradient row reduction (dw_reduce_block)
+    if ((int)blockIdx.x < g.nred) dw_reduce_block(g.red_ws, g.red_dw, g.C * 9, g.red_rows, blockIdx.x, reinterpret_cast<float*>(smem));
+    return;
+  }
   const int cg = tid % g.CV, pl = tid / g.CV;
   const bool active = pl < g.NPL;
   const int c0 = cg * 8;
@@ -653,7 +665,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   const int nstrip = (g.Win + SW - 1) / SW;
   const long U = (long)g.B * g.Hin * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
-  const TileRange tr = xcd_tiles((int)ntiles);
+  const TileRange tr = xcd_tiles((int)ntiles, g.lead);
   TSS_T(tq1);
   for (int tile = tr.begin; tile < tr.end; tile += tr.step) {
     const long u = (long)tile * g.NPL + pl;
@@ -760,7 +772,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   TSS_T(tq2);
-  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem);
+  if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem, g.lead);
 #ifdef TSS_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSS_T(tq3);
@@ -794,6 +806,16 @@ int geometry(DwArgs& g, int* threads) {
 }
 
 inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
+
+inline bool strip_supported(int stride, int dil) { return (stride == 1 && dil == 1) || (stride == 2 && dil == 1) || (stride == 1 && dil == 4); }
+
+// workspace rows the weight-gradient kernels of this layer write (= their grid); g.NPL / Hout / Wout must be set
+inline int weight_rows(const DwArgs& g) {
+  const long P = (long)g.B * g.Hout * g.Wout;
+  const long U = (long)g.B * g.Hout * ((g.Wout + SW - 1) / SW);
+  return strip_supported(g.stride, g.dil) ? tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS)
+                                          : tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+}
 
 }  // namespace
 
@@ -832,7 +854,7 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float
 int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                           void* e_in, long ldei, double* bstats,
+                           void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldei % 8) == 0 && ldei >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
@@ -856,8 +878,15 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                       ((double)Po * (yraw ? 2 : 1) + (double)P * (xraw ? 2 : 1)) * C * esz(dtype), 18.0 * Po * C);
   const long U = (long)B * Hin * ((Win + SW - 1) / SW);
   const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
-  const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(1, g, sgrid, threads, (hipStream_t)stream)
-                                       : launch_strip<float>(1, g, sgrid, threads, (hipStream_t)stream);
+  const bool carry = wg_ws && wg_dw && strip_supported(stride, dil);
+  if (carry) {   // the row reduction of this layer's weight gradient rides in front of the sweeping blocks
+    g.red_ws = wg_ws; g.red_dw = wg_dw; g.red_rows = weight_rows(g);
+    g.nred = (C * 9 + 63) / 64; g.lead = (g.nred + 7) & ~7;
+  } else if (wg_ws && wg_dw) {
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, wg_ws, wg_dw, C * 9, weight_rows(g));
+  }
+  const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(1, g, sgrid + g.lead, threads, (hipStream_t)stream)
+                                       : launch_strip<float>(1, g, sgrid + g.lead, threads, (hipStream_t)stream);
   if (!strip) {
     const int grid = tss::persistent_blocks((P + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
     if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_data_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
@@ -869,7 +898,7 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu,
                              const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                             float* dw, float* ws, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+                             float* dw, float* ws, int defer_reduce, int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldx % 8) == 0 && ldx >= C && stride >= 1 && dil >= 1, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
@@ -897,7 +926,8 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
     if (dtype == TSS_BF16) hipLaunchKernelGGL(dw_bwd_weight_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
     else hipLaunchKernelGGL(dw_bwd_weight_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   }
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
+  if (!defer_reduce)
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
   return tss::check_last("dwconv_bwd_weight");
 }
 

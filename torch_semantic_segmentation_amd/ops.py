@@ -434,7 +434,8 @@ class ConvUnitFn(Function):
                 call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, P, Cin, Cout, dt, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
-                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), B, Hin, Win, Cout, s, d, dt, wst)
+                defer = 1 if (need_dx and side is None) else 0      # backward-data carries the row reduction
+                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
             if need_dx:
@@ -446,7 +447,7 @@ class ConvUnitFn(Function):
                          ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
                 elif cfg.kind == 'dw':
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
-                         B, Hin, Win, Cout, s, d, dt, st)
+                         ptr(ws) if defer else None, ptr(dw) if defer else None, B, Hin, Win, Cout, s, d, dt, st)
                 else:
                     if s != 1:
                         raise NotImplementedError('HIP path: input gradient of a strided dense 3x3 convolution')
