@@ -512,7 +512,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
 template <typename T, int S, int D>
 __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_kernel(const DwArgs g) {
   constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
-  __shared__ float sdw[768 * 9];
+  __shared__ __align__(16) float sdw[768 * 9];
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
   const bool active = pl < g.NPL;
@@ -603,22 +603,27 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
       }
     }
   }
-  // block reduction over the pixel lanes, one tap at a time through a [threads][8] LDS slab: no atomics (with 32
-  // channels 64 lanes would add to the same 8 LDS words 9 times over), deterministic
-  float* red = sdw;  // [blockDim][8] floats <= 8 KB, reuses the (still unused) sdw storage
+  // block reduction over the pixel lanes, three taps at a time through a [threads][24] LDS slab (24 KB of sdw): no
+  // atomics (with 32 channels 64 lanes would add to the same 8 LDS words 9 times over), deterministic, 6 barriers
+  float* red = sdw;  // [blockDim][24] floats <= 24.6 KB, reuses the (still unused) sdw storage
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
+  for (int t0 = 0; t0 < 9; t0 += 3) {
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) red[tid * 8 + j] = accw[t][j];
+      for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+        for (int j = 0; j < 8; j += 4)
+          *reinterpret_cast<float4*>(red + tid * 24 + tt * 8 + j) =
+              make_float4(accw[t0 + tt][j], accw[t0 + tt][j + 1], accw[t0 + tt][j + 2], accw[t0 + tt][j + 3]);
     }
     __syncthreads();
-    for (int c = tid; c < g.C; c += blockDim.x) {
+    for (int i = tid; i < g.C * 3; i += blockDim.x) {
+      const int c = i / 3, tt = i - c * 3;
       const int cgc = c >> 3, j = c & 7;
       float sum = 0.f;
-      for (int q = 0; q < g.NPL; ++q) sum += red[(q * g.CV + cgc) * 8 + j];
-      g.ws[(long)blockIdx.x * g.C * 9 + c * 9 + t] = sum;
+      for (int q = 0; q < g.NPL; ++q) sum += red[(q * g.CV + cgc) * 24 + tt * 8 + j];
+      g.ws[(long)blockIdx.x * g.C * 9 + c * 9 + t0 + tt] = sum;
     }
   }
 }
