@@ -402,17 +402,20 @@ __global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Strip kernels: one lane owns 8 channels of FOUR consecutive pixels of a row.  The 3 x NCOL input window of a
-// strip is loaded once (NCOL = 3*S + 2*D + 1 columns: 6 / 9 / 12 for the hot path's (stride, dilation) pairs)
+// Strip kernels: one lane owns 8 channels of FOUR pixels of a row (consecutive for stride 2, D apart for stride 1).  The
+// 3 x NCOL input window of a strip is loaded once (NCOL = 6 for stride 1 at any dilation, 9 for stride 2)
 // and every loaded vector is normalised once, instead of 9 loads + 9 normalisations per pixel: 2-2.4x fewer load
 // instructions and 6-12 independent 16-byte loads in flight per lane.  (S, D) are template parameters so the
 // window -> (pixel, tap) scatter is resolved at compile time.
 constexpr int SW = 4;
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void dw_fwd_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, (sizeof(T) == 2 ? 3 : 2)) void dw_fwd_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
-  constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
+  // stride 1: a strip is 4 pixels D apart (x0, x0+D, ...): the taps of neighbouring strip pixels coincide, so the window
+  // is 6 columns for any dilation (with consecutive pixels a dilation-4 strip needs 12 columns and shares nothing)
+  constexpr int XS = (S == 1) ? D : 1;                               // pixel step inside a strip
+  constexpr int NCOL = (S == 1) ? (SW + 2) : ((SW - 1) * S + 2 * D + 1);
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];  // [tap][C]
   const int tid = threadIdx.x;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
   }
   __syncthreads();
   const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
-  const int nstrip = (g.Wout + SW - 1) / SW;
+  const int nstrip = ((g.Wout + SW * XS - 1) / (SW * XS)) * XS;   // groups of SW*XS columns, XS interleaved strips each
   const long U = (long)g.B * g.Hout * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles);
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
     const long t2 = u / nstrip;
     const int oy = (int)(t2 % g.Hout);
     const long b = t2 / g.Hout;
-    const int x0 = xs * SW;
+    const int x0 = (xs / XS) * (SW * XS) + (xs % XS);   // consecutive units -> consecutive pixels (coalesced lanes)
     float acc[SW][8];
 #pragma unroll
     for (int i = 0; i < SW; ++i)
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
       bool ok[NCOL];
 #pragma unroll
       for (int c = 0; c < NCOL; ++c) {
-        const int ix = x0 * S - D + c;
+        const int ix = (S == 1) ? x0 + (c - 1) * XS : x0 * S - D + c;
         ok[c] = vy && ix >= 0 && ix < g.Win;
         raw[c] = V8<T>::load_raw(row + (long)(ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix)) * g.ldx);
       }
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
         for (int i = 0; i < SW; ++i)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
-            if (i * S + kx * D == c) {
+            if ((S == 1) ? (i + kx == c) : (i * S + kx * D == c)) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[i][j] += v[j] * wv[kx][j];
             }
@@ -495,14 +498,14 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
     }
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
-      if (x0 + i < g.Wout) {
+      if (x0 + i * XS < g.Wout) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           acc[i][j] = V8<T>::round(acc[i][j]);
           s1[j] += (A)acc[i][j];
           s2[j] += (A)acc[i][j] * (A)acc[i][j];
         }
-        V8<T>::store(y + ((b * g.Hout + oy) * (long)g.Wout + x0 + i) * g.ldy + c0, acc[i]);
+        V8<T>::store(y + ((b * g.Hout + oy) * (long)g.Wout + x0 + i * XS) * g.ldy + c0, acc[i]);
       }
     }
   }
@@ -510,8 +513,11 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
 }
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_kernel(const DwArgs g) {
-  constexpr int NCOL = (SW - 1) * S + 2 * D + 1;
+__global__ __launch_bounds__(NT_MAX, 2) void dw_bwd_weight_strip_kernel(const DwArgs g) {
+  // stride 1: a strip is 4 pixels D apart (x0, x0+D, ...): the taps of neighbouring strip pixels coincide, so the window
+  // is 6 columns for any dilation (with consecutive pixels a dilation-4 strip needs 12 columns and shares nothing)
+  constexpr int XS = (S == 1) ? D : 1;                               // pixel step inside a strip
+  constexpr int NCOL = (S == 1) ? (SW + 2) : ((SW - 1) * S + 2 * D + 1);
   __shared__ __align__(16) float sdw[768 * 9];
   const int tid = threadIdx.x;
   const int cg = tid % g.CV, pl = tid / g.CV;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
 #pragma unroll
   for (int j = 0; j < 8; ++j) { kd[j] = -(ca[j] * ce[j]) - cb[j] * cm[j]; if (FOLD) sh[j] -= mu[j] * sc[j]; }
   const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
-  const int nstrip = (g.Wout + SW - 1) / SW;
+  const int nstrip = ((g.Wout + SW * XS - 1) / (SW * XS)) * XS;   // groups of SW*XS columns, XS interleaved strips each
   const long U = (long)g.B * g.Hout * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles);
@@ -551,12 +557,12 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
     const long t2 = u / nstrip;
     const int oy = (int)(t2 % g.Hout);
     const long b = t2 / g.Hout;
-    const int x0 = xs * SW;
+    const int x0 = (xs / XS) * (SW * XS) + (xs % XS);   // consecutive units -> consecutive pixels (coalesced lanes)
     float gv[SW][8];
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
-      const bool in = x0 + i < g.Wout;
-      const long q = (b * g.Hout + oy) * (long)g.Wout + (in ? x0 + i : x0);
+      const bool in = x0 + i * XS < g.Wout;
+      const long q = (b * g.Hout + oy) * (long)g.Wout + (in ? x0 + i * XS : x0);
       float ev[8];
       V8<T>::load(e + q * g.lde + c0, ev);
       if (yr) {
@@ -581,7 +587,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
       bool ok[NCOL];
 #pragma unroll
       for (int c = 0; c < NCOL; ++c) {
-        const int ix = x0 * S - D + c;
+        const int ix = (S == 1) ? x0 + (c - 1) * XS : x0 * S - D + c;
         ok[c] = vy && ix >= 0 && ix < g.Win;
         raw[c] = V8<T>::load_raw(row + (long)(ix < 0 ? 0 : (ix >= g.Win ? g.Win - 1 : ix)) * g.ldx);
       }
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
         for (int i = 0; i < SW; ++i)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx)
-            if (i * S + kx * D == c) {
+            if ((S == 1) ? (i + kx == c) : (i * S + kx * D == c)) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) accw[ky * 3 + kx][j] += gv[i][j] * v[j];
             }
@@ -631,9 +637,10 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
 // backward-data on strips of 4 INPUT pixels.  Stride 1: the flipped-tap window of g = BN'(e, y), 2*D + 4 columns.
 // Stride 2 (D = 1): only output rows/columns of matching parity contribute: <= 2 rows x 3 columns.
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, 2) void dw_bwd_data_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
-  constexpr int NCOL = (S == 1) ? (SW + 2 * D) : 3;
+  constexpr int XS = (S == 1) ? D : 1;                  // stride 1: strip pixels D apart, window of 6 output columns
+  constexpr int NCOL = (S == 1) ? (SW + 2) : 3;
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];
   TSS_T(tq0);
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
 #pragma unroll
   for (int j = 0; j < 8; ++j) kd[j] = -(ca[j] * ce[j]) - cb[j] * cm[j];
   __syncthreads();
-  const int nstrip = (g.Win + SW - 1) / SW;
+  const int nstrip = ((g.Win + SW * XS - 1) / (SW * XS)) * XS;
   const long U = (long)g.B * g.Hin * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles, g.lead);
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
     const long t2 = u / nstrip;
     const int iy = (int)(t2 % g.Hin);
     const long b = t2 / g.Hin;
-    const int x0 = xs * SW;
+    const int x0 = (xs / XS) * (SW * XS) + (xs % XS);   // consecutive units -> consecutive pixels (coalesced lanes)
     float acc[SW][8];
 #pragma unroll
     for (int i = 0; i < SW; ++i)
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
     typename V8<T>::Raw rx[SW];
     if (g.x) {
 #pragma unroll
-      for (int i = 0; i < SW; ++i) rx[i] = V8<T>::load_raw(x + (pbase + (x0 + i < g.Win ? i : 0)) * g.ldx + c0);
+      for (int i = 0; i < SW; ++i) rx[i] = V8<T>::load_raw(x + (pbase + (x0 + i * XS < g.Win ? i * XS : 0)) * g.ldx + c0);
     }
 #pragma unroll 1
     for (int ky = 0; ky < 3; ++ky) {
@@ -702,13 +709,13 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
       const bool vy = ny >= 0 && oyr * S == ny && oyr < g.Hout;
       const int oy = vy ? oyr : 0;
       const long rowq = (b * g.Hout + oy) * (long)g.Wout;
-      // first output column of the window: stride 1: x0 - D; stride 2: x0 / 2 (x0 is a multiple of 4)
+      // first output column of the window: stride 1: x0 - D, then every D-th column; stride 2: x0 / 2 (x0 is a multiple of 4)
       const int oc0 = (S == 1) ? (x0 - D) : (x0 / 2);
       typename V8<T>::Raw re[NCOL], ry[NCOL];
       bool ok[NCOL];
 #pragma unroll
       for (int c = 0; c < NCOL; ++c) {
-        const int ox = oc0 + c;
+        const int ox = oc0 + c * XS;
         ok[c] = vy && ox >= 0 && ox < g.Wout;
         const long q = rowq + (ox < 0 ? 0 : (ox >= g.Wout ? g.Wout - 1 : ox));
         re[c] = V8<T>::load_raw(e + q * g.lde + c0);
@@ -739,13 +746,13 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
           for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * gvv[j] : 0.f;
         }
         // input pixel i of the strip sees output column (oc0 + c) through tap kx when
-        //   stride 1:  x0 + i - (kx-1)*D == x0 - D + c      <=>  i + (2 - kx) * D == c   (kx counted from the flip)
+        //   stride 1:  x0 + i*D - (kx-1)*D == x0 - D + c*D  <=>  i + (2 - kx) == c       (kx counted from the flip)
         //   stride 2:  x0 + i - (kx-1)   == 2 * (x0/2 + c)  <=>  kx == i + 1 - 2c
 #pragma unroll
         for (int i = 0; i < SW; ++i)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
-            const bool hit = (S == 1) ? (i + (2 - kx) * D == c) : (kx == i + 1 - 2 * c);
+            const bool hit = (S == 1) ? (i + (2 - kx) == c) : (kx == i + 1 - 2 * c);
             if (hit) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[i][j] += gvv[j] * wv[kx][j];
@@ -755,8 +762,8 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
     }
 #pragma unroll
     for (int i = 0; i < SW; ++i) {
-      if (x0 + i < g.Win) {
-        const long p = pbase + i;
+      if (x0 + i * XS < g.Win) {
+        const long p = pbase + i * XS;
         if (g.x) {
           float xv[8];
           V8<T>::unpack(rx[i], xv);
