@@ -410,7 +410,7 @@ __global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* 
 constexpr int SW = 4;
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, (sizeof(T) == 2 ? 3 : 2)) void dw_fwd_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void dw_fwd_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   // stride 1: a strip is 4 pixels D apart (x0, x0+D, ...): the taps of neighbouring strip pixels coincide, so the window
   // is 6 columns for any dilation (with consecutive pixels a dilation-4 strip needs 12 columns and shares nothing)
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NT_MAX, (sizeof(T) == 2 ? 3 : 2)) void dw_fwd_strip
 }
 
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, 2) void dw_bwd_weight_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_kernel(const DwArgs g) {
   // stride 1: a strip is 4 pixels D apart (x0, x0+D, ...): the taps of neighbouring strip pixels coincide, so the window
   // is 6 columns for any dilation (with consecutive pixels a dilation-4 strip needs 12 columns and shares nothing)
   constexpr int XS = (S == 1) ? D : 1;                               // pixel step inside a strip
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(NT_MAX, 2) void dw_bwd_weight_strip_kernel(const Dw
 // backward-data on strips of 4 INPUT pixels.  Stride 1: the flipped-tap window of g = BN'(e, y), 2*D + 4 columns.
 // Stride 2 (D = 1): only output rows/columns of matching parity contribute: <= 2 rows x 3 columns.
 template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, 2) void dw_bwd_data_strip_kernel(const DwArgs g) {
+__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   constexpr int XS = (S == 1) ? D : 1;                  // stride 1: strip pixels D apart, window of 6 output columns
   constexpr int NCOL = (S == 1) ? (SW + 2) : 3;
