@@ -170,7 +170,15 @@ def main():
     args = parse()
     from torch_semantic_segmentation_amd import engine as E
     from torch_semantic_segmentation_amd import _native as N
-    world, rank, local_rank = E.setup_distributed(enable=True)
+    # TSS_BENCH_REHEARSE=1: multi-rank dry run on a box with fewer GPUs than ranks (gloo collectives, ranks share the
+    # visible devices round-robin) -- checks the N > 1 control flow, says nothing about speed
+    rehearse = os.environ.get('TSS_BENCH_REHEARSE') == '1'
+    if rehearse:
+        ndev = max(torch.cuda.device_count(), 1)
+        world, rank, local_rank = E.setup_distributed(enable=True, local_rank=int(os.environ.get('LOCAL_RANK', '0')) % ndev,
+                                                      backend='gloo')
+    else:
+        world, rank, local_rank = E.setup_distributed(enable=True)
     if world != args.gpus and rank == 0:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -228,7 +236,7 @@ def main():
         elapsed = t.item()
     final_loss = float(loss)
 
-    if args.host_batch and rank == 0:
+    if args.host_batch:          # all ranks: the steps contain the gradient all-reduce
         hx, hy = x.cpu().pin_memory(), y.cpu().pin_memory()
         for _ in range(2):
             trainer.step_async(hx, hy)
@@ -238,13 +246,14 @@ def main():
             trainer.step_async(hx, hy)       # H2D straight into the captured step's buffers, same stream: no overlap
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / args.steps
-        print('host-batch (PCIe-inclusive, un-overlapped): %.3f ms/step, %.1f images/s, %.1f GB/s H2D-equivalent' % (
-            1e3 * dt, args.batch / dt, (hx.numel() * hx.element_size() + hy.numel() * hy.element_size()) / dt / 1e9),
-            file=sys.stderr)
+        if rank == 0:
+            print('host-batch (PCIe-inclusive, un-overlapped): %.3f ms/step, %.1f images/s, %.1f GB/s H2D-equivalent' % (
+                1e3 * dt, args.batch / dt, (hx.numel() * hx.element_size() + hy.numel() * hy.element_size()) / dt / 1e9),
+                file=sys.stderr)
 
     roofline = None
     breakdown = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline:     # every rank takes part (the un-captured steps all-reduce like the timed ones); rank 0 reports
         from torch_semantic_segmentation_amd import ops as _ops
         _ops.overlap_wgrad = False      # one kernel at a time, so that an event pair times exactly one kernel
         eager = make_trainer(False)

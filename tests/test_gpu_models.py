@@ -199,3 +199,27 @@ def test_bf16_training_tracks_f32():
     a, b = np.array(curves[torch.float32]), np.array(curves[torch.bfloat16])
     assert a[-1] < a[0] and b[-1] < b[0]
     assert np.abs(a - b).max() < 0.05 * a[0]
+
+
+def test_bench_two_rank_rehearsal_runs_to_completion():
+    """bench.py under torch.distributed.run with 2 ranks (gloo collectives, both ranks on this GPU): the whole flow --
+    capture, timed steps with the gradient all-reduce, the un-captured roofline pass on EVERY rank, the final barrier --
+    ends with one JSON line from rank 0 (a rank-0-only collective anywhere would hang here)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSS_BENCH_REHEARSE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29547', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '2',
+           '--batch', '2', '--height', '128', '--width', '256', '--no-cpu-baseline']
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
+    assert out['roofline'] is not None and out['value'] > 0
