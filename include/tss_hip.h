@@ -162,6 +162,19 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,
                         float* ga, float* gb, float* gce, int C, void* stream);
 
+/* ---- cross-replica (Sync) BatchNorm: apex.parallel.convert_syncbn_model TSS scripts/train_fastscnn.py:144-145 -------
+ * tss_slab_reduce sums a replica's slab rows into out[0..2C) and stores `count` at out[2C]; the caller all-reduces the
+ * [2C+1] f64 vector over the ranks (one RCCL collective per BatchNorm layer and direction) and hands it to the *_sync
+ * finalize kernels: forward = global batch statistics (also into the running statistics), backward = global sums for
+ * the input gradient, this replica's slab sums (bstats) for d(gamma), d(beta). */
+int tss_slab_reduce(const double* slabs, double count, double* out, int C, void* stream);
+int tss_bn_finalize_sync(const double* gsums, const float* gamma, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                         float* scale, int C, void* stream);
+int tss_bn_bwd_finalize_sync(const double* bstats, const double* gsums, const float* invstd, const float* gamma,
+                             int accumulate, float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C,
+                             void* stream);
+
 /* ---- join: out = relu?(affA(a) + affB(b)) ------------------------------------------------------------
  * replaces: the trailing BatchNorm2d(+ReLU) of a block, `x + input` / F.relu of BottleneckBlock
  *           TSS/models/fastscnn.py:158-161, TSS/models/contextnet.py:145-147 and F.relu(lowres + highres)

@@ -155,3 +155,21 @@ def test_deep_supervision_wrapper_contract():
     out, aux = w.train()(x)
     assert out.shape == (2, 2, 4, 4) and aux[0].shape == (2, 5, 4, 4) and not toy.a._forward_hooks
     assert w.eval()(x).shape == (2, 2, 4, 4)
+
+
+def test_convert_syncbn_model_keeps_modules_parameters_and_state_dict():
+    """apex.parallel.convert_syncbn_model stand-in (scripts/train_fastscnn.py:144-145): same module objects, same
+    parameters/buffers, same state_dict keys; the layers are still _BatchNorm instances; without an initialised process
+    group (or in eval mode) they behave as ordinary BatchNorm."""
+    import importlib
+    import torch
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    model = F.FastSCNN(3, 19)
+    keys, params = list(model.state_dict().keys()), [id(p) for p in model.parameters()]
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    assert tssa.convert_syncbn_model(model) is model
+    assert list(model.state_dict().keys()) == keys and [id(p) for p in model.parameters()] == params
+    assert len(bns) == 44 and all(isinstance(m, tssa.SyncBatchNorm) and isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in bns)
+    assert all(ops._sync_group(m) is None for m in bns)        # no process group here: local statistics

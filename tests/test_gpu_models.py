@@ -223,3 +223,34 @@ def test_bench_two_rank_rehearsal_runs_to_completion():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 4 and out['scaling'] == 'weak'
     assert out['roofline'] is not None and out['value'] > 0
+
+
+def test_syncbn_two_ranks_equal_one_big_batch(tmp_path):
+    """convert_syncbn_model (apex SyncBN in the reference's distributed scripts): two ranks with
+    two images each give the outputs, running statistics and (rank-summed) gradients of ONE process on all four images."""
+    import subprocess
+    import sys
+    from tests import syncbn_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_path = str(tmp_path / 'sync.pt')
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29561', os.path.join(root, 'tests', 'syncbn_worker.py'), out_path]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = torch.load(out_path)
+    model = W.build().to(DEV)                       # same weights, ordinary (local) BatchNorm, the whole batch at once
+    x, cot = W.batch()
+    ref_out = W.run(model, x.to(DEV), cot.to(DEV)).cpu()
+    assert cases.rel_err(got['out'].numpy(), ref_out[:2].numpy()) < 2e-5
+    for n, b in model.named_buffers():
+        if b.dtype.is_floating_point:
+            assert cases.rel_err(got['buffers'][n].numpy(), b.detach().cpu().numpy()) < 2e-5, n
+        else:
+            assert int(got['buffers'][n]) == int(b), n
+    for n, p in model.named_parameters():
+        a, b = got['grads'][n].double(), p.grad.detach().cpu().double()
+        # BatchNorm biases in front of another BatchNorm have analytically zero gradients: absolute floor
+        assert float((a - b).abs().max() / max(float(b.abs().max()), 1e-2)) < 5e-4, n

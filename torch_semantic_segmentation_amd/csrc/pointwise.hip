@@ -66,6 +66,62 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums,
   }
 }
 
+// ---- cross-replica (Sync) BatchNorm: the slab rows of a replica are summed to one [2C + 1] f64 vector (sums, sums of
+// squares / centred products, element count), the caller all-reduces it over the ranks (RCCL), and the finalize
+// kernels below read the global vector.  apex.parallel.SyncBatchNorm semantics: forward normalises with the global
+// batch statistics and updates the running statistics with them; backward uses the global sums for the input
+// gradient and the LOCAL sums for d(gamma), d(beta) (the gradient all-reduce of the data-parallel step adds those).
+__global__ __launch_bounds__(FIN_NT) void slab_reduce_kernel(const double* slabs, double count, double* out, int C) {
+  double s0, s1;
+  int c;
+  slab_sum(slabs, C, &s0, &s1, &c);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * C] = count;
+  if (threadIdx.x >= FIN_CH || c >= C) return;
+  out[c] = s0;
+  out[C + c] = s1;
+}
+
+__global__ void bn_finalize_sync_kernel(const double* gsums, const float* gamma, float eps, float momentum,
+                                        float* running_mean, float* running_var, long long* num_batches,
+                                        float* mean_out, float* invstd_out, float* scale, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && num_batches) *num_batches += 1;
+  if (c >= C) return;
+  const double count = gsums[2 * C];
+  const double mean = gsums[c] / count;
+  double var = gsums[C + c] / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float m = (float)mean;
+  mean_out[c] = m;
+  invstd_out[c] = invstd;
+  scale[c] = (gamma ? gamma[c] : 1.f) * invstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_var) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_sync_kernel(const double* bstats, const double* gsums,
+                                                                      const float* invstd, const float* gamma, int accumulate,
+                                                                      float* dgamma, float* dbeta, float* ga, float* gb,
+                                                                      float* gce, int C) {
+  double se, sey;
+  int c;
+  slab_sum(bstats, C, &se, &sey, &c);           // this replica's sums: parameter gradients
+  if (threadIdx.x >= FIN_CH || c >= C) return;
+  const double r = invstd[c];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(r * sey);
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)se;
+  const double count = gsums[2 * C];
+  const double k = (gamma ? (double)gamma[c] : 1.0) * r;
+  const double c1 = gsums[c] / count, c2 = r * gsums[C + c] / count;   // global means of e and e * xhat
+  ga[c] = (float)k;
+  gb[c] = (float)(-k * c2 * r);
+  gce[c] = (float)c1;
+}
+
 __global__ void bn_eval_affine_kernel(const float* gamma, const float* running_mean,
                                       const float* running_var, float eps, float* mean_out, float* invstd_out,
                                       float* scale, int C) {
@@ -384,6 +440,30 @@ int tss_bn_finalize(const double* sums, double count, const float* gamma, float 
                      gamma, eps, momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out,
                      scale, C);
   return tss::check_last("bn_finalize");
+}
+
+int tss_slab_reduce(const double* slabs, double count, double* out, int C, void* stream) {
+  TSS_REQUIRE(C > 0 && count >= 0.0, TSS_ERR_SHAPE);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, slabs, count, out, C);
+  return tss::check_last("slab_reduce");
+}
+
+int tss_bn_finalize_sync(const double* gsums, const float* gamma, float eps, float momentum, float* running_mean,
+                         float* running_var, long long* num_batches_tracked, float* mean_out, float* invstd_out,
+                         float* scale, int C, void* stream) {
+  TSS_REQUIRE(C > 0, TSS_ERR_SHAPE);
+  hipLaunchKernelGGL(bn_finalize_sync_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gsums, gamma, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, mean_out, invstd_out, scale, C);
+  return tss::check_last("bn_finalize_sync");
+}
+
+int tss_bn_bwd_finalize_sync(const double* bstats, const double* gsums, const float* invstd, const float* gamma,
+                             int accumulate, float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C,
+                             void* stream) {
+  TSS_REQUIRE(C > 0, TSS_ERR_SHAPE);
+  hipLaunchKernelGGL(bn_bwd_finalize_sync_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream,
+                     bstats, gsums, invstd, gamma, accumulate, dgamma, dbeta, ga, gb, gce, C);
+  return tss::check_last("bn_bwd_finalize_sync");
 }
 
 int tss_bn_eval_affine(const float* gamma, const float* running_mean, const float* running_var,

@@ -183,7 +183,7 @@ def npix(t):
 class BNLink:
     """State shared by the producer and the consumer of one deferred BatchNorm."""
     __slots__ = ('C', 'count', 'training', 'gamma', 'beta', 'vec', 'scale', 'mean', 'invstd',
-                 'ga', 'gb', 'gce', 'stats', 'bstats', 'consumed')
+                 'ga', 'gb', 'gce', 'stats', 'bstats', 'consumed', 'sync')
 
     def __init__(self, C, count, training, gamma, beta, device):
         self.C, self.count, self.training, self.gamma, self.beta = C, count, training, gamma, beta
@@ -193,6 +193,7 @@ class BNLink:
         both = torch.empty((2, N.stat_slabs(), 2 * C), dtype=torch.float64, device=device)
         self.stats, self.bstats = both[0], both[1]
         self.consumed = False
+        self.sync = None          # process group of a cross-replica (Sync) BatchNorm, see SyncBatchNorm below
 
 
 class Deferred:
@@ -214,6 +215,45 @@ class Deferred:
                 raise RuntimeError('a deferred BatchNorm output may feed exactly one consumer; materialize it first')
             self.link.consumed = True
         return self
+
+
+class SyncBatchNorm(torch.nn.BatchNorm2d):
+    """Cross-replica BatchNorm for the data-parallel path (apex.parallel.SyncBatchNorm as the reference's scripts use it,
+    scripts/train_fastscnn.py:144-145): in training mode the batch statistics are those of the GLOBAL batch.  Same
+    parameters, buffers and state_dict keys as nn.BatchNorm2d.  The HIP path implements it as one all-reduce of a
+    [2C+1] f64 vector per layer and direction between the producing kernel and the finalize kernel."""
+    process_group = None
+
+
+def convert_syncbn_model(module, process_group=None):
+    """apex.parallel.convert_syncbn_model: every BatchNorm2d of `module` becomes a SyncBatchNorm, in place (the
+    module objects, parameters and buffers stay the same, so optimizers and state_dicts are unaffected)."""
+    for m in module.modules():
+        if isinstance(m, torch.nn.BatchNorm2d) and not isinstance(m, SyncBatchNorm):
+            m.__class__ = SyncBatchNorm
+            m.process_group = process_group
+    return module
+
+
+def _sync_group(bn, any_mode=False):
+    """The process group over which this BatchNorm's statistics are reduced, or None (local statistics: not a Sync
+    layer, eval mode unless `any_mode`, no process group, or a single rank)."""
+    import torch.distributed as dist
+    if not isinstance(bn, (SyncBatchNorm, torch.nn.SyncBatchNorm)) or not (bn.training or any_mode):
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    group = getattr(bn, 'process_group', None) or dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
+def _allreduce_stats(slabs, count, C, group, st):
+    """slab rows of this replica -> [2C+1] f64 (sums, second moments, count), summed over the ranks."""
+    import torch.distributed as dist
+    vec = torch.empty(2 * C + 1, dtype=torch.float64, device=slabs.device)
+    call('tss_slab_reduce', ptr(slabs), float(count), ptr(vec), C, st)
+    dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=group)
+    return vec
 
 
 def as_deferred(x):
@@ -349,11 +389,16 @@ class ConvUnitFn(Function):
             bn = cfg.bn
             if cfg.training:
                 track = bn.track_running_stats and bn.running_mean is not None
-                call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
-                     float(bn.momentum), ptr(bn.running_mean) if track else None,
-                     ptr(bn.running_var) if track else None,
-                     ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None,
-                     ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+                run_args = (ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                            ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None)
+                link.sync = _sync_group(bn)
+                if link.sync is not None:
+                    gs = _allreduce_stats(link.stats, P, Cout, link.sync, st)
+                    call('tss_bn_finalize_sync', ptr(gs), ptr(gamma), float(bn.eps), float(bn.momentum), *run_args,
+                         ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+                else:
+                    call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
+                         float(bn.momentum), *run_args, ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
             else:
                 call('tss_bn_eval_affine', ptr(gamma), ptr(bn.running_mean), ptr(bn.running_var),
                      float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
@@ -388,9 +433,14 @@ class ConvUnitFn(Function):
                 else:
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
-            call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd),
-                 ptr(link.gamma), int(link.training), acc, ptr(dgamma), ptr(dbeta),
-                 ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
+            if link.sync is not None:
+                gs = _allreduce_stats(link.bstats, link.count, Cout, link.sync, st)
+                call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), acc,
+                     ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
+            else:
+                call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd),
+                     ptr(link.gamma), int(link.training), acc, ptr(dgamma), ptr(dbeta),
+                     ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
             if acc:
                 dgamma = dbeta = None
             ga, gb, gce, gmu = link.ga, link.gb, link.gce, link.mean
