@@ -244,6 +244,11 @@ int tss_upsample_ce_bwd(const float* dlow_acc, const float* inv_count, const flo
                         long n, int dtype, void* stream);
 int tss_upsample_head_bwd_cols(const float* tmp, void* dlow, long ldl, int B, int N, int h, int w, int W,
                                int dtype, void* stream);
+/* Fused evaluation head: argmax of the bilinearly upsampled logits (+ confusion matrix, rows = truth) from the low-res
+ * NHWC logits; the full-resolution logits are never materialised (model(x).argmax(1) of the evaluator TSS/engine.py:65-77). */
+int tss_upsample_argmax_confusion(const void* low, long ldl, const long long* target, unsigned char* pred,
+                                  unsigned long long* confusion, int B, int C, int h, int w, int H, int W,
+                                  int ignore_index, int dtype, void* stream);
 int tss_argmax_confusion(const void* logits, const long long* target, unsigned char* pred,
                          unsigned long long* confusion, long B, int C, long HW, int ignore_index,
                          int dtype, void* stream);

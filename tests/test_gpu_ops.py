@@ -337,3 +337,29 @@ def test_stem_mfma_kernels_match_torch_at_odd_sizes(B, H, W):
     wr = w.clone().requires_grad_(True)
     (F.conv2d(x.bfloat16().float(), wr, None, 2, 1) * g).sum().backward()
     assert rel(dw, wr.grad) < 6e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 5, 6, 4), 4), ((1, 21, 9, 33), 8)])
+def test_fused_upsample_argmax_confusion_matches_unfused(shape, scale, dtype):
+    """Evaluator head as one operator == argmax / confusion matrix of the materialised upsampled logits (f32: exact;
+    bf16: the unfused path rounds the upsampled logits to bf16 first, so near-ties may flip -- bounded fraction)."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(13)
+    B, C, h, w = shape
+    low = ops.to_nhwc((2 * torch.randn(*shape, device=DEV)).to(dtype))
+    target = torch.randint(0, C, (B, h * scale, w * scale), device=DEV)
+    target[torch.rand(B, h * scale, w * scale, device=DEV) < 0.1] = 255
+    pred, cm = tssa.upsample_argmax_confusion(low, target, scale_factor=scale, ignore_index=255)
+    ref = F.interpolate(low.float(), scale_factor=scale, mode='bilinear', align_corners=True)
+    rp = ref.argmax(1)
+    mism = (pred.long() != rp).float().mean().item()
+    assert mism <= (1e-4 if dtype == torch.float32 else 5e-3)
+    valid = target != 255
+    rc = torch.zeros(C, C, dtype=torch.int64, device=DEV)
+    rc.index_put_((target[valid], pred.long()[valid]), torch.ones_like(target[valid]), accumulate=True)
+    assert torch.equal(cm, rc)
+    # accumulation into an existing matrix, no prediction output
+    _, cm2 = tssa.upsample_argmax_confusion(low, target, scale_factor=scale, ignore_index=255, confusion=cm.clone(), want_pred=False)
+    assert torch.equal(cm2, 2 * rc)

@@ -292,6 +292,78 @@ __global__ __launch_bounds__(NT) void argmax_confusion_kernel(const T* logits, c
       if (scm[i]) atomicAdd(cm + i, (unsigned long long)scm[i]);
 }
 
+// Fused evaluation head (eval half): argmax over the classes of the bilinearly upsampled logits
+// + confusion-matrix update, straight from the low-res NHWC logits.  Same lane / register layout as
+// upsample_ce_onepass_kernel (lane = output column, the two horizontally interpolated low-res rows in registers, one
+// FMA per logit); lowest class index wins ties like torch.argmax; rows = truth.
+template <typename T, int CP>
+__global__ __launch_bounds__(NT, 3) void upsample_argmax_kernel(const T* low, long ldl, const long long* target,
+                                                                unsigned char* pred_out, unsigned long long* cm, int B,
+                                                                int C, int h, int w, int H, int W, int ignore_index,
+                                                                int band_rows) {
+  extern __shared__ unsigned int scm[];  // [C*C]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * C; i += NT) scm[i] = 0u;
+  __syncthreads();
+  const int nstrip = (W + NT - 1) / NT, nband = (H + band_rows - 1) / band_rows;
+  int bid = blockIdx.x;
+  const int strip = bid % nstrip; bid /= nstrip;
+  const int band = bid % nband;
+  const long b = bid / nband;
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int x = strip * NT + tid;
+  const bool xin = x < W;
+  const Tap tx = ac_tap(sx, xin ? x : W - 1, w);
+  const int ya = band * band_rows;
+  const int yb = ya + band_rows < H ? ya + band_rows : H;
+  float aA[CP], aB[CP];
+  auto load_row = [&](int r, float* a) {
+    const T* p0 = low + ((b * h + r) * (long)w + tx.i0) * ldl;
+    const T* p1 = low + ((b * h + r) * (long)w + tx.i1) * ldl;
+#pragma unroll
+    for (int c4 = 0; c4 < CP; c4 += 4) {
+      float u[4], v[4];
+      V4<T>::load(p0 + c4, u);
+      V4<T>::load(p1 + c4, v);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? tx.l0 * u[q] + tx.l1 * v[q] : -TSS_INF;
+    }
+  };
+  int rA = ac_tap(sy, ya, h).i0;
+  int rB = rA + (rA < h - 1 ? 1 : 0);
+  load_row(rA, aA);
+  load_row(rB, aB);
+  for (int y = ya; y < yb; ++y) {
+    const Tap ty = ac_tap(sy, y, h);
+    if (ty.i0 != rA) {
+      rA = rB;
+      rB = rA + (rA < h - 1 ? 1 : 0);
+#pragma unroll
+      for (int c = 0; c < CP; ++c) aA[c] = aB[c];
+      load_row(rB, aB);
+    }
+    float best = -TSS_INF;
+    int arg = 0;
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      const float z = ty.l0 * aA[c] + ty.l1 * aB[c];
+      if (c < C && (z > best || c == 0)) { best = z; arg = c; }
+    }
+    if (xin) {
+      const long p = (b * H + y) * (long)W + x;
+      if (pred_out) pred_out[p] = (unsigned char)arg;
+      if (cm && target) {
+        const long long t = target[p];
+        if (t != ignore_index && t >= 0 && t < C) atomicAdd(&scm[(int)t * C + arg], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (cm)
+    for (int i = tid; i < C * C; i += NT)
+      if (scm[i]) atomicAdd(cm + i, (unsigned long long)scm[i]);
+}
+
 inline int grid_for(long total) {
   long g = (total + NT - 1) / NT;
   if (g > 4096) g = 4096;
@@ -362,6 +434,28 @@ int tss_argmax_confusion(const void* logits, const long long* target, unsigned c
     hipLaunchKernelGGL(argmax_confusion_kernel<float>, dim3((int)grid), dim3(NT), sh, (hipStream_t)stream,
                        (const float*)logits, target, pred, confusion, B, C, HW, ignore_index);
   return tss::check_last("argmax_confusion");
+}
+
+int tss_upsample_argmax_confusion(const void* low, long ldl, const long long* target, unsigned char* pred,
+                                  unsigned long long* confusion /*[C*C] accumulated*/, int B, int C, int h, int w,
+                                  int H, int W, int ignore_index, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(low), TSS_ERR_ALIGN);
+  if ((long)B * H * W == 0) return TSS_OK;
+  const int nstrip = (W + NT - 1) / NT;
+  int band_rows = 64;
+  while (band_rows > 16 && (long)B * nstrip * ((H + band_rows - 1) / band_rows) < 2048) band_rows /= 2;
+  const long grid = (long)B * nstrip * ((H + band_rows - 1) / band_rows);
+  tss::ProfScope prof(TSS_K_ARGMAX, (hipStream_t)stream, (double)B * h * w * C * esz(dtype) + (double)B * H * W * 9.0, 0);
+  const size_t sh = (size_t)C * C * sizeof(unsigned int);
+#define TSS_AM_LAUNCH(TT, CPV)                                                                                 \
+  hipLaunchKernelGGL((upsample_argmax_kernel<TT, CPV>), dim3((int)grid), dim3(NT), sh, (hipStream_t)stream,      \
+                     (const TT*)low, ldl, target, pred, confusion, B, C, h, w, H, W, ignore_index, band_rows)
+  if (dtype == TSS_BF16) { if (C <= 20) TSS_AM_LAUNCH(bf16_t, 20); else TSS_AM_LAUNCH(bf16_t, 24); }
+  else { if (C <= 20) TSS_AM_LAUNCH(float, 20); else TSS_AM_LAUNCH(float, 24); }
+#undef TSS_AM_LAUNCH
+  return tss::check_last("upsample_argmax_confusion");
 }
 
 int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* dlow_acc /*[B][h][w][ldl] f32, zeroed*/,

@@ -266,6 +266,13 @@ class Evaluator:
             if self.device is not None:
                 x = x.to(self.device, non_blocking=self.non_blocking)
                 y = y.to(self.device, non_blocking=self.non_blocking)
+            fused = (self.loss_fn is None and hasattr(self.model, 'forward_lowres') and hasattr(self.model, 'logit_scale')
+                     and not (self.model._forward_hooks or self.model._forward_pre_hooks))
+            if fused:   # decoder upsample + argmax + confusion matrix as one operator: no full-resolution logits
+                low = self.model.forward_lowres(x)
+                _, cm = ops.upsample_argmax_confusion(low, y, scale_factor=self.model.logit_scale,
+                                                      ignore_index=self.ignore_index, confusion=cm, want_pred=False)
+                continue
             logits = self.model(x)
             _, cm = ops.argmax_confusion(logits, y, ignore_index=self.ignore_index, confusion=cm, want_pred=False)
             if self.loss_fn is not None:

@@ -862,6 +862,28 @@ def upsample_cross_entropy(low, target, scale_factor=None, size=None, ignore_ind
     return UpsampleCrossEntropyFn.apply(low, target, ho, wo, ignore_index)
 
 
+def upsample_argmax_confusion(low, target=None, scale_factor=None, size=None, ignore_index=255, confusion=None,
+                              want_pred=True):
+    """argmax_confusion(F.interpolate(low, scale, bilinear, align_corners=True), ...) without the full-resolution logits
+    (the evaluator's decoder head + metric update as one operator).  Returns (pred uint8 or None, confusion)."""
+    low = to_nhwc(materialize(low))
+    ho, wo = _out_size(low, size, scale_factor)
+    B, C, h, w = low.shape
+    if C > 24 or ho < h or wo < w:
+        return argmax_confusion(upsample_logits(low, size=(ho, wo)), target, ignore_index=ignore_index,
+                                confusion=confusion, want_pred=want_pred)
+    pred = torch.empty((B, ho, wo), dtype=torch.uint8, device=low.device) if want_pred else None
+    if target is not None:
+        if target.dtype != torch.int64 or tuple(target.shape) != (B, ho, wo):
+            raise RuntimeError('target must be int64 of shape (B,H,W) = %s' % ((B, ho, wo),))
+        _check_device(target)
+        if confusion is None:
+            confusion = torch.zeros((C, C), dtype=torch.int64, device=low.device)
+    call('tss_upsample_argmax_confusion', ptr(low), ld(low), ptr(target.contiguous()) if target is not None else None,
+         ptr(pred), ptr(confusion), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
+    return pred, confusion
+
+
 def argmax_confusion(logits, target=None, num_classes=None, ignore_index=255, confusion=None, want_pred=True):
     """argmax over dim 1 (lowest index wins ties) and, with a target, the confusion-matrix update
     (rows = truth, cols = prediction) that create_segmentation_evaluator's metrics need (TSS/engine.py:65-72)."""
