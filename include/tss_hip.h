@@ -232,6 +232,17 @@ int tss_cross_entropy_fwd(const void* logits, const long long* target, float* ls
 int tss_cross_entropy_bwd(const void* logits, const long long* target, const float* lse, const float* inv_count,
                           const float* grad_out, void* dlogits, long B, int C, long HW, int ignore_index,
                           int dtype, void* stream);
+/* Online hard example mining cross-entropy: OHEMLoss(ignore_index, thresh_loss = -log 0.7, numel_frac = 0.01) of the
+ * reference's training recipe (TSS/losses/ohem_loss.py:10-21, scripts/train_fastscnn.py:133-137).  n_top = int(B*HW *
+ * numel_frac).  The (n_top+1)-th largest per-pixel loss is found by a device-side radix select (no sort, no host read-back);
+ * workspace = tss_ohem_workspace_bytes() bytes, zeroed once by the caller (left zeroed by every call). */
+long tss_ohem_workspace_bytes(void);
+int tss_ohem_fwd(const void* logits, const long long* target, float* lse, float* pixel_loss, void* workspace,
+                 float* loss, float* params, long B, int C, long HW, int ignore_index, float thresh_loss,
+                 long n_top, int dtype, void* stream);
+int tss_ohem_bwd(const void* logits, const long long* target, const float* lse, const float* pixel_loss,
+                 const float* params, const float* grad_out, void* dlogits, long B, int C, long HW, int ignore_index,
+                 int dtype, void* stream);
 /* Fused decoder head + loss: cross-entropy (mean over the non-ignored pixels) of the bilinearly upsampled logits,
  * straight from the low-res NHWC logits (replaces F.interpolate TSS/models/fastscnn.py:63-64 + the loss call
  * TSS/engine.py:30 as one operator; the full-resolution logits and their gradient are never materialised).

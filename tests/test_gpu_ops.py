@@ -363,3 +363,35 @@ def test_fused_upsample_argmax_confusion_matches_unfused(shape, scale, dtype):
     # accumulation into an existing matrix, no prediction output
     _, cm2 = tssa.upsample_argmax_confusion(low, target, scale_factor=scale, ignore_index=255, confusion=cm.clone(), want_pred=False)
     assert torch.equal(cm2, 2 * rc)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', ['threshold', 'top_n', 'many_ignored'])
+def test_ohem_loss_matches_reference_formula(case, dtype):
+    """tssa.OHEMLoss == ohem_loss of the reference (TSS/losses/ohem_loss.py:10-21, restated in oracle/recipe.py) in value
+    and gradient, on both branches: the (n+1)-th largest loss above the threshold (mean of everything above it) and
+    below it (mean of the n largest); also when most pixels are ignored."""
+    import torch_semantic_segmentation_amd as tssa
+    from oracle.recipe import ohem
+    torch.manual_seed(21)
+    B, C, H, W = 2, 19, 32, 64
+    gain, frac = (3.0, 0.05) if case == 'threshold' else (0.05, 0.01)     # confident-wrong logits vs nearly uniform ones
+    logits = (gain * torch.randn(B, C, H, W, device=DEV)).to(dtype)
+    target = torch.randint(0, C, (B, H, W), device=DEV)
+    thresh = 0.35667494393873245 if case == 'threshold' else 3.5               # uniform 19-class CE is ~2.94 < 3.5
+    if case == 'many_ignored':
+        target[torch.rand(B, H, W, device=DEV) < 0.995] = 255
+    else:
+        target[torch.rand(B, H, W, device=DEV) < 0.1] = 255
+    a = logits.clone().requires_grad_(True)
+    la = tssa.OHEMLoss(ignore_index=255, thresh_loss=thresh, numel_frac=frac)(a, target)
+    (0.7 * la).backward()
+    b = logits.float().clone().requires_grad_(True)
+    lb = ohem(b, target, ignore_index=255, thresh_loss=thresh, numel_frac=frac)
+    (0.7 * lb).backward()
+    per = F.cross_entropy(logits.float(), target, ignore_index=255, reduction='none').flatten()
+    nth = torch.sort(per, descending=True)[0][int(per.numel() * frac)].item()
+    assert (nth > thresh) == (case == 'threshold')                              # the intended branch is exercised
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert abs(la.item() / lb.item() - 1) < tol
+    assert rel(a.grad, b.grad) < tol

@@ -818,6 +818,62 @@ class CrossEntropyLoss(torch.nn.Module):
         return cross_entropy(input, target, self.ignore_index)
 
 
+class OHEMFn(Function):
+    """ohem_loss (TSS/losses/ohem_loss.py:10-21): per-pixel CE, the (n+1)-th largest found by a device-side radix select."""
+    _ws = {}
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index, thresh_loss, numel_frac):
+        _check_device(logits)
+        logits = logits.contiguous()
+        B, C, H, W = logits.shape
+        if (H * W) % 8:
+            raise NotImplementedError('HIP path: H*W must be a multiple of 8')
+        if target.dtype != torch.int64 or target.shape != (B, H, W):
+            raise RuntimeError('target must be int64 of shape (B,H,W)')
+        target = target.contiguous()
+        dev = logits.device
+        key = (dev.type, dev.index)
+        if key not in OHEMFn._ws:          # zeroed once; every call leaves it zeroed
+            OHEMFn._ws[key] = torch.zeros(N.lib().tss_ohem_workspace_bytes(), dtype=torch.uint8, device=dev)
+        lse = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        pix = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        out = torch.empty(5, dtype=torch.float32, device=dev)              # loss, then the 4 selection parameters
+        n_top = int(B * H * W * float(numel_frac))
+        call('tss_ohem_fwd', ptr(logits), ptr(target), ptr(lse), ptr(pix), ptr(OHEMFn._ws[key]), ptr(out[0:1]),
+             ptr(out[1:5]), B, C, H * W, int(ignore_index), float(thresh_loss), n_top, N.dtype_code(logits.dtype),
+             stream())
+        ctx.ignore_index = int(ignore_index)
+        ctx.save_for_backward(logits, target, lse, pix, out)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        logits, target, lse, pix, out = ctx.saved_tensors
+        B, C, H, W = logits.shape
+        gout = gout.to(torch.float32).contiguous()
+        d = torch.empty_like(logits)
+        call('tss_ohem_bwd', ptr(logits), ptr(target), ptr(lse), ptr(pix), ptr(out[1:5]), ptr(gout), ptr(d),
+             B, C, H * W, ctx.ignore_index, N.dtype_code(logits.dtype), stream())
+        return d, None, None, None, None
+
+
+def ohem_loss(input, target, ignore_index=-100, thresh_loss=0.35667494393873245, numel_frac=0.01):
+    """TSS/losses/ohem_loss.py:10-21 (thresh_loss default = -log(0.7))."""
+    return OHEMFn.apply(input, target, ignore_index, thresh_loss, numel_frac)
+
+
+class OHEMLoss(torch.nn.Module):
+    """Drop-in for TSS.losses.OHEMLoss (TSS/losses/ohem_loss.py:24-37), the loss of scripts/train_fastscnn.py."""
+
+    def __init__(self, ignore_index=-100, thresh_loss=0.35667494393873245, numel_frac=0.01):
+        super().__init__()
+        self.ignore_index, self.thresh_loss, self.numel_frac = ignore_index, thresh_loss, numel_frac
+
+    def forward(self, input, target):
+        return ohem_loss(input, target, self.ignore_index, self.thresh_loss, self.numel_frac)
+
+
 class UpsampleCrossEntropyFn(Function):
     """cross_entropy(F.interpolate(low, scale, bilinear, align_corners=True), target) without the full-res logits:
     one pass yields the loss and the unscaled low-res gradient, backward scales it by grad_out / #valid."""
