@@ -254,3 +254,54 @@ def test_syncbn_two_ranks_equal_one_big_batch(tmp_path):
         a, b = got['grads'][n].double(), p.grad.detach().cpu().double()
         # BatchNorm biases in front of another BatchNorm have analytically zero gradients: absolute floor
         assert float((a - b).abs().max() / max(float(b.abs().max()), 1e-2)) < 5e-4, n
+
+
+def test_reference_training_recipe_runs_on_the_hip_path():
+    """scripts/train_fastscnn.py:107-137 as a whole: FastSCNN in a DeepSupervisionWrapper with two auxiliary Classifier
+    heads (hooks on model.downsample / model.features, x8 and x32 bilinear upsample), loss = OHEM(main, frac 0.1) +
+    0.4 CE(aux1) + 0.4 CE(aux2).  Same state_dict as the oracle's restatement of that recipe -> same training loss in
+    f32 (forward is well conditioned), finite gradients for every parameter, and the loss falls under AdamW."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from oracle.recipe import DeepSupervision, ohem
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    torch.manual_seed(5)
+    ref = O.build('fastscnn')
+    ref = DeepSupervision(ref, [
+        (ref.downsample, nn.Sequential(O.fast_head(64, 19), nn.Upsample(scale_factor=8, mode='bilinear', align_corners=True))),
+        (ref.features, nn.Sequential(O.fast_head(128, 19), nn.Upsample(scale_factor=32, mode='bilinear', align_corners=True)))])
+    cases.zero_dropout(ref)
+    model = F_.FastSCNN(3, 19)
+    model = E.DeepSupervisionWrapper(model, [
+        (model.downsample, nn.Sequential(F_.Classifier(64, 19), nn.Upsample(scale_factor=8, mode='bilinear', align_corners=True))),
+        (model.features, nn.Sequential(F_.Classifier(128, 19), nn.Upsample(scale_factor=32, mode='bilinear', align_corners=True)))])
+    model.load_state_dict(ref.state_dict(), strict=True)
+    cases.zero_dropout(model)
+    model.to(DEV)
+    tssa.set_compute_dtype(model, torch.float32)
+    x, y = synthetic_batch(2, 64, 128, seed=3)
+    ohem_fn, ce_fn = tssa.OHEMLoss(ignore_index=255, numel_frac=0.1), tssa.CrossEntropyLoss(ignore_index=255)
+
+    def loss_fn(outputs, target):
+        main, (aux1, aux2) = outputs
+        return ohem_fn(main, target) + 0.4 * ce_fn(aux1.contiguous(), target) + 0.4 * ce_fn(aux2.contiguous(), target)
+
+    ref.train()
+    out_r, (a1, a2) = ref(x)
+    loss_r = ohem(out_r, y, ignore_index=255, numel_frac=0.1) + 0.4 * nn.functional.cross_entropy(a1, y, ignore_index=255) \
+        + 0.4 * nn.functional.cross_entropy(a2, y, ignore_index=255)
+    opt = torch.optim.AdamW(model.parameters(), lr=2e-3)
+    xd, yd = x.to(DEV), y.to(DEV)
+    losses = []
+    for _ in range(6):
+        model.train()
+        opt.zero_grad()
+        loss = loss_fn(model(xd), yd)
+        loss.backward()
+        if not losses:
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert abs(losses[0] / loss_r.item() - 1) < 2e-3
+    assert losses[-1] < losses[0]
