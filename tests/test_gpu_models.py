@@ -274,7 +274,7 @@ def test_reference_training_recipe_runs_on_the_hip_path():
     cases.zero_dropout(ref)
     model = F_.FastSCNN(3, 19)
     model = E.DeepSupervisionWrapper(model, [
-        (model.downsample, nn.Sequential(F_.Classifier(64, 19), nn.Upsample(scale_factor=8, mode='bilinear', align_corners=True))),
+        (model.downsample, nn.Sequential(F_.Classifier(64, 19), tssa.Upsample(scale_factor=8))),       # HIP x8 head
         (model.features, nn.Sequential(F_.Classifier(128, 19), nn.Upsample(scale_factor=32, mode='bilinear', align_corners=True)))])
     model.load_state_dict(ref.state_dict(), strict=True)
     cases.zero_dropout(model)

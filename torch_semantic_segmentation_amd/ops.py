@@ -678,6 +678,24 @@ def upsample_logits(low, scale_factor=None, size=None):
     return UpsampleHeadFn.apply(low, ho, wo)
 
 
+class Upsample(torch.nn.Module):
+    """nn.Upsample(scale_factor=k, mode='bilinear', align_corners=True) on the HIP path: the auxiliary heads of the
+    reference's deep-supervision recipe (scripts/train_fastscnn.py:108-117) end in one.  NHWC logits in, NCHW-contiguous
+    full-resolution logits out (what the losses consume), through tss_upsample_head_{fwd,bwd}."""
+
+    def __init__(self, size=None, scale_factor=None, mode='bilinear', align_corners=True):
+        super().__init__()
+        if mode != 'bilinear' or not align_corners:
+            raise NotImplementedError("HIP path: Upsample(mode='bilinear', align_corners=True) only")
+        self.size, self.scale_factor = size, scale_factor
+
+    def forward(self, input):
+        return upsample_logits(input, scale_factor=self.scale_factor, size=self.size)
+
+    def extra_repr(self):
+        return 'size=%r, scale_factor=%r, mode=bilinear, align_corners=True' % (self.size, self.scale_factor)
+
+
 class UpsampleHeadFn(Function):
     @staticmethod
     def forward(ctx, low, ho, wo):
