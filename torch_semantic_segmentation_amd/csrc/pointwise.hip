@@ -170,6 +170,17 @@ struct JoinArgs {
   long P; int C, CV, NPL;
 };
 
+// 8 per-channel constants of a lane: two unconditional 16-byte loads through a null-safe pointer, then a select
+__device__ __forceinline__ void coef8(const float* p, const float* safe, int c0, bool active, float dflt, float out[8]) {
+  const bool has = p != nullptr;
+  const float* q = has ? p + (active ? c0 : 0) : safe;
+  float v[8];
+  V4<float>::load(q, v);
+  V4<float>::load(q + 4, v + 4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = (has && active) ? v[j] : dflt;
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
   const int tid = threadIdx.x;
@@ -179,27 +190,33 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
   const T* a = reinterpret_cast<const T*>(g.a);
   const T* b = reinterpret_cast<const T*>(g.b);
   T* out = reinterpret_cast<T*>(g.out);
+  // constants and both operands are loaded without branches (a `ptr ? load : c` is a branch + wait per load; an `if (b)`
+  // around the second operand makes it a second dependent round trip): the small joins were pure latency chains
   float ma[8], sa[8], ba[8], mb[8], sb[8], bb[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sa[j] = g.sa ? g.sa[c0 + j] : 1.f; ma[j] = (g.sa && g.ma) ? g.ma[c0 + j] : 0.f; ba[j] = (g.sa && g.ba) ? g.ba[c0 + j] : 0.f;
-    sb[j] = g.sb ? g.sb[c0 + j] : 1.f; mb[j] = (g.sb && g.mb) ? g.mb[c0 + j] : 0.f; bb[j] = (g.sb && g.bb) ? g.bb[c0 + j] : 0.f;
-  }
+  const float* safe = reinterpret_cast<const float*>(g.a);     // any readable, 16-byte aligned address
+  coef8(g.sa, safe, c0, true, 1.f, sa);
+  coef8(g.sa ? g.ma : nullptr, safe, c0, true, 0.f, ma);
+  coef8(g.sa ? g.ba : nullptr, safe, c0, true, 0.f, ba);
+  coef8(g.sb, safe, c0, true, 1.f, sb);
+  coef8(g.sb ? g.mb : nullptr, safe, c0, true, 0.f, mb);
+  coef8(g.sb ? g.bb : nullptr, safe, c0, true, 0.f, bb);
   const long stride = (long)gridDim.x * g.NPL;
   const float relu_lo = g.relu ? 0.f : -__builtin_inff();
+  const bool hb = b != nullptr;
+  const T* b2 = hb ? b : a;                                      // dummy second stream when there is none
+  const long ldb2 = hb ? g.ldb : g.lda;
   for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
-    float v[8];
-    V8<T>::load(a + p * g.lda + c0, v);
+    const typename V8<T>::Raw ra = V8<T>::load_raw(a + p * g.lda + c0);
+    const typename V8<T>::Raw rb = V8<T>::load_raw(b2 + p * ldb2 + c0);
+    float v[8], u[8];
+    V8<T>::unpack(ra, v);
+    V8<T>::unpack(rb, u);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (v[j] - ma[j]) * sa[j] + ba[j];
-    if (b) {
-      float u[8];
-      V8<T>::load(b + p * g.ldb + c0, u);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += (u[j] - mb[j]) * sb[j] + bb[j];
+    for (int j = 0; j < 8; ++j) {
+      v[j] = (v[j] - ma[j]) * sa[j] + ba[j];
+      if (hb) v[j] += (u[j] - mb[j]) * sb[j] + bb[j];
+      v[j] = fmaxf(v[j], relu_lo);
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
     V8<T>::store(out + p * g.ldo + c0, v);
   }
 }
@@ -223,36 +240,33 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
   A s0[8], sA[8], sB[8];
   float ma[8], mb[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    s0[j] = 0; sA[j] = 0; sB[j] = 0;
-    ma[j] = (active && g.ma) ? g.ma[c0 + j] : 0.f;
-    mb[j] = (active && g.mb) ? g.mb[c0 + j] : 0.f;
-  }
+  for (int j = 0; j < 8; ++j) { s0[j] = 0; sA[j] = 0; sB[j] = 0; }
+  const float* safe = reinterpret_cast<const float*>(g.dout);
+  coef8(g.ma, safe, c0, active, 0.f, ma);
+  coef8(g.mb, safe, c0, active, 0.f, mb);
   const long stride = (long)gridDim.x * g.NPL;
   if (active) {
+    // up to four streams per pixel (dout, out for the ReLU mask, the two raw branch outputs for the statistics): all
+    // issued together -- absent ones re-read dout -- instead of four dependent round trips
+    const bool hr = g.relu != 0, ha = g.stats_a != nullptr, hbb = g.stats_b != nullptr;
+    const T* po = hr ? out : dout; const long ldo = hr ? g.ldo : g.lddo;
+    const T* pa = ha ? a : dout;   const long lda = ha ? g.lda : g.lddo;
+    const T* pb = hbb ? b : dout;  const long ldb = hbb ? g.ldb : g.lddo;
     for (long p = (long)blockIdx.x * g.NPL + pl; p < g.P; p += stride) {
-      float v[8];
-      V8<T>::load(dout + p * g.lddo + c0, v);
-      if (g.relu) {
-        float o[8];
-        V8<T>::load(out + p * g.ldo + c0, o);
+      const typename V8<T>::Raw rd = V8<T>::load_raw(dout + p * g.lddo + c0);
+      const typename V8<T>::Raw ro = V8<T>::load_raw(po + p * ldo + c0);
+      const typename V8<T>::Raw rA = V8<T>::load_raw(pa + p * lda + c0);
+      const typename V8<T>::Raw rB = V8<T>::load_raw(pb + p * ldb + c0);
+      float v[8], o[8], ua[8], ub[8];
+      V8<T>::unpack(rd, v); V8<T>::unpack(ro, o); V8<T>::unpack(rA, ua); V8<T>::unpack(rB, ub);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (!(o[j] > 0.f)) v[j] = 0.f;
-      }
+      for (int j = 0; j < 8; ++j) if (hr && !(o[j] > 0.f)) v[j] = 0.f;
       if (e) V8<T>::store(e + p * g.lde + c0, v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s0[j] += (A)v[j];
-      if (g.stats_a) {
-        float u[8];
-        V8<T>::load(a + p * g.lda + c0, u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sA[j] += (A)v[j] * (A)(u[j] - ma[j]);
-      }
-      if (g.stats_b) {
-        float u[8];
-        V8<T>::load(b + p * g.ldb + c0, u);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sB[j] += (A)v[j] * (A)(u[j] - mb[j]);
+      for (int j = 0; j < 8; ++j) {
+        s0[j] += (A)v[j];
+        if (ha) sA[j] += (A)v[j] * (A)(ua[j] - ma[j]);
+        if (hbb) sB[j] += (A)v[j] * (A)(ub[j] - mb[j]);
       }
     }
   }
