@@ -46,6 +46,12 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums,
                                    long long* num_batches, float* mean_out, float* invstd_out,
                                    float* scale, int C) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;
+  // the per-channel operands of the tail are requested before the slab rows (independent of them): their round trip
+  // hides under the slab reduction instead of following it.  Null pointers read a valid dummy and are selected away.
+  const int cp = min(blockIdx.x * FIN_CH + (int)(threadIdx.x & (FIN_CH - 1)), C - 1);
+  const float g_in = (gamma ? gamma : mean_out)[cp];
+  const float rm_in = (running_mean ? running_mean : mean_out)[cp];
+  const float rv_in = (running_var ? running_var : mean_out)[cp];
   double ssum, ssq;
   int c;
   slab_sum(sums, C, &ssum, &ssq, &c);
@@ -54,15 +60,15 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums,
   double var = ssq / count - mean * mean;
   if (var < 0.0) var = 0.0;
   const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float g = gamma ? gamma[c] : 1.f;
+  const float g = gamma ? g_in : 1.f;
   const float m = (float)mean;
   mean_out[c] = m;
   invstd_out[c] = invstd;
   scale[c] = g * invstd;
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_mean) running_mean[c] = (1.f - momentum) * rm_in + momentum * m;
   if (running_var) {
     const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_var[c] = (1.f - momentum) * rv_in + momentum * (float)unbiased;
   }
 }
 
@@ -140,16 +146,21 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* running_m
 __global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
                                        const float* gamma, int training, int accumulate,
                                        float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C) {
+  const int cp = min(blockIdx.x * FIN_CH + (int)(threadIdx.x & (FIN_CH - 1)), C - 1);
+  const float r_in = invstd[cp];                       // requested ahead of the slab rows, as in bn_finalize_kernel
+  const float g_in = (gamma ? gamma : invstd)[cp];
+  const float dg_in = (dgamma ? dgamma : invstd)[cp];
+  const float db_in = (dbeta ? dbeta : invstd)[cp];
   double se, sey;
   int c;
   slab_sum(bstats, C, &se, &sey, &c);
   if (threadIdx.x >= FIN_CH || c >= C) return;
-  const double r = invstd[c];
+  const double r = r_in;
   const double dg = r * sey;
   const double db = se;
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
-  const double k = (gamma ? (double)gamma[c] : 1.0) * r;
+  if (dgamma) dgamma[c] = (accumulate ? dg_in : 0.f) + (float)dg;
+  if (dbeta) dbeta[c] = (accumulate ? db_in : 0.f) + (float)db;
+  const double k = (gamma ? (double)g_in : 1.0) * r;
   if (training) {
     const double c1 = db / count, c2 = dg / count;
     ga[c] = (float)k;
