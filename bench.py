@@ -35,9 +35,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
-    ap.add_argument('--batch', type=int, default=8, help='images per GPU')
-    ap.add_argument('--height', type=int, default=1024)
-    ap.add_argument('--width', type=int, default=2048)
+    ap.add_argument('--mode', default='train', choices=['train', 'eval'],
+                    help='eval = SURVEY config C5: eval-mode no-grad forward, default 1 x 3 x 2048 x 4096 (never the headline line)')
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (default 8; 1 in eval mode)')
+    ap.add_argument('--height', type=int, default=None)
+    ap.add_argument('--width', type=int, default=None)
     ap.add_argument('--graph', default='auto', choices=['auto', 'on', 'off'])
     ap.add_argument('--fuse-head', default='on', choices=['on', 'off'],
                     help='decoder upsample + cross-entropy as one operator (same value and gradients)')
@@ -48,7 +50,10 @@ def parse():
                     help='also report the PCIe-inclusive rate: the batch is copied from pinned host memory every step '
                          '(never the headline value; printed to stderr)')
     ap.add_argument('--stock', action='store_true', help='also time the stock PyTorch-ROCm (MIOpen) path of the oracle modules')
-    return ap.parse_args()
+    args = ap.parse_args()
+    dflt = (8, 1024, 2048) if args.mode == 'train' else (1, 2048, 4096)
+    args.batch, args.height, args.width = (args.batch or dflt[0], args.height or dflt[1], args.width or dflt[2])
+    return args
 
 
 def build_model(name):
@@ -166,8 +171,51 @@ def stock_gpu(model_name, batch, h, w, device, steps=5):
     return batch * steps / (time.time() - t0)
 
 
+def main_eval(args):
+    """SURVEY config C5 / TSS/utils/benchmark.py: eval-mode forward (running BatchNorm statistics, no dropout, no grad)
+    through the x8 decoder head, HIP-graph replay, input resident in HBM."""
+    from torch_semantic_segmentation_amd import engine as E
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    device = torch.device('cuda', 0)
+    model, tssa = build_model(args.model)
+    model.to(device).eval()
+    dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    tssa.set_compute_dtype(model, dtype)
+    x, _ = synthetic(args.batch, args.height, args.width, 1234, device)
+    fwd = E.GraphedInference(model) if args.graph != 'off' else model
+    if args.graph != 'off':
+        x = fwd.static_input(x)      # the input is resident in the buffer the captured forward reads
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = fwd(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = fwd(x)
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    esz = 2 if dtype == torch.bfloat16 else 4
+    ms = 1e3 * elapsed / args.steps
+    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}.get(args.model)
+    res = {'metric': 'images/sec (eval forward) %s %dx%d bs=%d' % (args.model, args.height, args.width, args.batch),
+           'value': round(args.batch * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': args.dtype, 'data': 'synthetic',
+           'config': {'workload': '%s eval-mode forward incl. x8 bilinear head, %d x 3 x %d x %d, 19 classes, random-init weights'
+                                  % (args.model, args.batch, args.height, args.width), 'hip_graph': args.graph != 'off',
+                      'logits': list(out.shape)}}
+    if S_ref:   # SURVEY section 8d: A = (sum over blocks of in + out elements + full-resolution logits) * b
+        a = (S_ref * args.batch * args.height * args.width / (8.0 * 1024 * 2048) + args.batch * 19.0 * args.height * args.width) * esz
+        res['step_roofline'] = {'alg_bytes_per_step': round(a), 'achieved_GBps': round(a / (ms * 1e-3) / 1e9, 1),
+                                'frac_of_8TBps': round(a / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
+    if args.mode == 'eval':
+        return main_eval(args)
     from torch_semantic_segmentation_amd import engine as E
     from torch_semantic_segmentation_amd import _native as N
     # TSS_BENCH_REHEARSE=1: multi-rank dry run on a box with fewer GPUs than ranks (gloo collectives, ranks share the

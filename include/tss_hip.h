@@ -157,6 +157,9 @@ int tss_bn_finalize(const double* sums, double count, const float* gamma, float 
                     float* mean_out, float* invstd_out, float* scale, int C, void* stream);
 int tss_bn_eval_affine(const float* gamma, const float* running_mean, const float* running_var,
                        float eps, float* mean_out, float* invstd_out, float* scale, int C, void* stream);
+/* all eval-mode BatchNorm layers of a model in one launch.  table: njobs x 6 int64 on the device: (gamma or 0, running_mean,
+ * running_var, out [3][C] = mean | invstd | scale, C, eps as f32 bits); max_channels = the largest C of the table. */
+int tss_bn_eval_affine_batched(const long long* table, int njobs, int max_channels, void* stream);
 /* bstats = [sum(e), sum(e*(y-mean))]; writes d(gamma), d(beta) (+= when accumulate) and ga, gb, gce */
 int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         const float* gamma, int training, int accumulate, float* dgamma, float* dbeta,

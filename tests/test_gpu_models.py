@@ -305,3 +305,28 @@ def test_reference_training_recipe_runs_on_the_hip_path():
         losses.append(loss.item())
     assert abs(losses[0] / loss_r.item() - 1) < 2e-3
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_graphed_inference_and_benchmark_model_match_eager_eval():
+    """TSS/utils/benchmark.py counterpart: the captured eval forward returns the eager eval logits bit for bit, and
+    benchmark_model reports the reference's keys."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd.models.fastscnn import fastscnn
+    torch.manual_seed(3)
+    m = fastscnn(3, 19).cuda().eval()
+    tssa.set_compute_dtype(m, torch.bfloat16)
+    x = torch.randn(2, 3, 128, 256, device='cuda')
+    with torch.no_grad():
+        want = m(x).clone()
+    g = tssa.GraphedInference(m)
+    got = g(x).clone()
+    assert torch.equal(got, want)
+    x2 = torch.randn(2, 3, 128, 256, device='cuda')
+    with torch.no_grad():
+        want2 = m(x2)
+    assert torch.equal(g(x2), want2)          # replay reads the new input
+    with pytest.raises(ValueError):
+        g(torch.randn(1, 3, 128, 256, device='cuda'))
+    r = tssa.benchmark_model(m, x, iterations=3, warmup=1, use_graph=True)
+    assert set(r) == {'fps', 'min', 'max', 'mean', 'std'} and r['fps'] > 0 and r['min'] <= r['mean'] <= r['max']

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
-"""Per-step timeline summary from a rocprofv3 --kernel-trace CSV: for the last full step (delimited by adamw_kernel),
+"""Per-step timeline summary from a rocprofv3 --kernel-trace CSV: for the last full step (delimited by adamw_kernel, or the kernel named in $TRACE_MARK),
 wall time, sum of kernel durations, idle gaps and per-kernel totals.  usage: trace_gaps.py <kernel_trace.csv>"""
 import collections
 import csv
+import os
 import re
 import sys
 
@@ -10,7 +11,8 @@ rows = []
 for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'adamw_kernel' in r[2]]
+mark = os.environ.get('TRACE_MARK', 'adamw_kernel')   # the kernel that ends a step (eval traces: the x8 head)
+marks = [i for i, r in enumerate(rows) if mark in r[2]]
 if len(marks) < 3:
     sys.exit('need at least 3 steps in the trace')
 lo, hi = marks[-2] + 1, marks[-1] + 1   # one full step: after the previous AdamW up to and including this one

@@ -5,5 +5,6 @@ from .models import set_compute_dtype                        # noqa: F401
 from .ops import CrossEntropyLoss, cross_entropy, argmax_confusion, upsample_cross_entropy  # noqa: F401
 from .ops import SyncBatchNorm, convert_syncbn_model, upsample_argmax_confusion  # noqa: F401
 from .ops import OHEMLoss, ohem_loss, Upsample  # noqa: F401
+from .engine import benchmark_model, GraphedInference  # noqa: F401
 
 __version__ = '0.1.0'

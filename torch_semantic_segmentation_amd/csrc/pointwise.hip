@@ -139,6 +139,25 @@ __global__ void bn_eval_affine_kernel(const float* gamma, const float* running_m
   scale[c] = (gamma ? gamma[c] : 1.f) * invstd;
 }
 
+// every eval-mode BatchNorm of a model in one launch.  table: njobs x 6 int64 -- gamma (or 0), running_mean, running_var,
+// out (mean at out[0..C), invstd at out[C..2C), scale at out[2C..3C)), C, eps (f32 bits in the low word).
+__global__ __launch_bounds__(128) void bn_eval_affine_batched_kernel(const long long* table, int njobs) {
+  const long long* job = table + (long)blockIdx.y * 6;
+  const int C = (int)job[4];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float* gamma = (const float*)job[0];
+  const float* rm = (const float*)job[1];
+  const float* rv = (const float*)job[2];
+  float* out = (float*)job[3];
+  const float eps = __int_as_float((int)job[5]);
+  const float g = (gamma ? gamma : rm)[c];
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  out[c] = rm[c];
+  out[C + c] = invstd;
+  out[2 * C + c] = (gamma ? g : 1.f) * invstd;
+}
+
 // bstats = [sum(e), sum(e*(y-mean))] over the N = count elements of each channel (centred: no cancellation).
 // training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
 //           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
@@ -498,6 +517,14 @@ int tss_bn_eval_affine(const float* gamma, const float* running_mean, const floa
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma,
                      running_mean, running_var, eps, mean_out, invstd_out, scale, C);
   return tss::check_last("bn_eval_affine");
+}
+
+int tss_bn_eval_affine_batched(const long long* table, int njobs, int max_channels, void* stream) {
+  TSS_REQUIRE(table && njobs > 0 && max_channels > 0, TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_BN_FINALIZE, (hipStream_t)stream, 24.0 * max_channels * njobs, 0);
+  hipLaunchKernelGGL(bn_eval_affine_batched_kernel, dim3((max_channels + 127) / 128, njobs), dim3(128), 0,
+                     (hipStream_t)stream, table, njobs);
+  return tss::check_last("bn_eval_affine_batched");
 }
 
 int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,

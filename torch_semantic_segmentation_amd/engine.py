@@ -249,6 +249,27 @@ def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False
 
 # ----------------------------------------------------------------------------- evaluator
 
+class EvalPrep:
+    """Model-wide preparation of an eval-mode forward as two launches: bf16 shadows of the 1x1 weights
+    (ops.WeightShadows) and the affines of every BatchNorm that runs on its running statistics (ops.EvalAffines).
+    `with prep:` refreshes both from the live parameters / buffers and makes them visible to the layers inside."""
+
+    def __init__(self, model):
+        self.shadows, self.affines = ops.WeightShadows(model), ops.EvalAffines(model)
+
+    def __enter__(self):
+        self.shadows.refresh()
+        self.affines.refresh()
+        self.shadows.__enter__()
+        self.affines.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.affines.__exit__(*exc)
+        self.shadows.__exit__(*exc)
+        return False
+
+
 class Evaluator:
     """model.eval() + no_grad forward, argmax, confusion matrix -> IoU / mIoU / accuracy / Dice
     (the metrics of create_segmentation_evaluator, TSS/engine.py:59-82; confusion rows = truth)."""
@@ -262,26 +283,34 @@ class Evaluator:
         self.model.eval()
         cm = None
         loss_sum, n = 0.0, 0
+        prep = None
         for x, y in data:
             if self.device is not None:
                 x = x.to(self.device, non_blocking=self.non_blocking)
                 y = y.to(self.device, non_blocking=self.non_blocking)
-            fused = (self.loss_fn is None and hasattr(self.model, 'forward_lowres') and hasattr(self.model, 'logit_scale')
-                     and not (self.model._forward_hooks or self.model._forward_pre_hooks))
-            if fused:   # decoder upsample + argmax + confusion matrix as one operator: no full-resolution logits
-                low = self.model.forward_lowres(x)
-                _, cm = ops.upsample_argmax_confusion(low, y, scale_factor=self.model.logit_scale,
-                                                      ignore_index=self.ignore_index, confusion=cm, want_pred=False)
-                continue
-            logits = self.model(x)
-            _, cm = ops.argmax_confusion(logits, y, ignore_index=self.ignore_index, confusion=cm, want_pred=False)
-            if self.loss_fn is not None:
-                loss_sum += float(self.loss_fn(logits, y)) * x.shape[0]
-                n += x.shape[0]
+            if prep is None:
+                prep = EvalPrep(self.model)
+            with prep:
+                cm, loss_sum, n = self._batch(x, y, cm, loss_sum, n)
         metrics = confusion_metrics(cm.cpu().double())
         if self.loss_fn is not None and n:
             metrics['loss'] = loss_sum / n
         return metrics
+
+    def _batch(self, x, y, cm, loss_sum, n):
+        fused = (self.loss_fn is None and hasattr(self.model, 'forward_lowres') and hasattr(self.model, 'logit_scale')
+                 and not (self.model._forward_hooks or self.model._forward_pre_hooks))
+        if fused:   # decoder upsample + argmax + confusion matrix as one operator: no full-resolution logits
+            low = self.model.forward_lowres(x)
+            _, cm = ops.upsample_argmax_confusion(low, y, scale_factor=self.model.logit_scale,
+                                                  ignore_index=self.ignore_index, confusion=cm, want_pred=False)
+            return cm, loss_sum, n
+        logits = self.model(x)
+        _, cm = ops.argmax_confusion(logits, y, ignore_index=self.ignore_index, confusion=cm, want_pred=False)
+        if self.loss_fn is not None:
+            loss_sum += float(self.loss_fn(logits, y)) * x.shape[0]
+            n += x.shape[0]
+        return cm, loss_sum, n
 
 
 def confusion_metrics(cm):
@@ -323,3 +352,77 @@ class DeepSupervisionWrapper(nn.Module):
             for h in handles:
                 h.remove()
         return output, aux_outputs
+
+
+# ----------------------------------------------------------------------------- inference (TSS/utils/benchmark.py)
+
+class GraphedInference:
+    """eval-mode, no-grad forward of `model` captured once in a HIP graph and replayed: the input is copied into a fixed
+    device buffer, the returned logits live in a fixed output buffer (overwritten by the next call).  Shapes are fixed
+    at the first call.  `lowres=True` returns the 1/8-resolution logits of `model.forward_lowres` (what the fused
+    evaluation head consumes) instead of the x8-upsampled ones."""
+
+    def __init__(self, model, lowres=False):
+        self.model, self.lowres = model, lowres
+        self._graph = self._x = self._out = self._prep = None
+
+    def _forward(self, x):
+        if self._prep is None:
+            self._prep = EvalPrep(self.model)
+        with self._prep:      # two model-wide launches (captured with the rest): weights and statistics are read live
+            return self.model.forward_lowres(x) if self.lowres else self.model(x)
+
+    def static_input(self, x):
+        """The device buffer the captured forward reads: fill it in place (H2D copy straight into it) and pass it to
+        __call__, which then skips its own device-to-device copy."""
+        if self._x is None:
+            self._x = torch.empty_like(x)
+        if x.data_ptr() != self._x.data_ptr():
+            self._x.copy_(x, non_blocking=True)
+        return self._x
+
+    @torch.no_grad()
+    def __call__(self, x):
+        if self._graph is None:
+            self.model.eval()
+            self.static_input(x)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._forward(self._x)
+            torch.cuda.current_stream().wait_stream(side)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._out = self._forward(self._x)
+        elif tuple(x.shape) != tuple(self._x.shape) or x.dtype != self._x.dtype:
+            raise ValueError(f'GraphedInference: input fixed at {tuple(self._x.shape)} {self._x.dtype}, got {tuple(x.shape)} {x.dtype}')
+        if x.data_ptr() != self._x.data_ptr():
+            self._x.copy_(x, non_blocking=True)
+        self._graph.replay()
+        return self._out
+
+
+def benchmark_model(model, batch, iterations, warmup, use_graph=False):
+    """Same arguments and result keys as TSS/utils/benchmark.py:6-33 (fps / min / max / mean / std of the forward time
+    in seconds, gradients disabled).  Each iteration is bracketed by a device synchronisation -- kernels are
+    asynchronous, the reference's host-side `time()` pair only measures a GPU model if something blocks.  The caller
+    chooses train/eval mode as in the reference; `use_graph` replays a captured eval forward (GraphedInference)."""
+    import time
+    import numpy as np
+    fwd = GraphedInference(model) if use_graph else model
+    cuda = batch.is_cuda
+    record = np.zeros(iterations)
+    with torch.set_grad_enabled(False):
+        for _ in range(warmup):
+            fwd(batch)
+        for it in range(iterations):
+            if cuda:
+                torch.cuda.synchronize()
+            start = time.perf_counter()
+            fwd(batch)
+            if cuda:
+                torch.cuda.synchronize()
+            record[it] = time.perf_counter() - start
+    return {'fps': 1 / np.mean(record), 'min': np.min(record), 'max': np.max(record), 'mean': np.mean(record),
+            'std': np.std(record)}
