@@ -59,6 +59,7 @@ const char* tss_last_error(void);      /* text of the last HIP error seen by thi
 const char* tss_arch(void);            /* "gfx950" */
 #define TSS_OPT_DISABLE_FAST_PATHS 1   /* value 1: bf16 calls use the general kernels only (A/B checks of the lean ones) */
 int tss_set_option(int key, int value);
+int tss_get_option(int key);   /* current value, -1 for an unknown key */
 
 /* ---- profiler: HIP events around every launch, on the launch stream --------------------------------- */
 int tss_prof_enable(int on);           /* 1: record events for every launch from now on; 0: stop */
@@ -102,11 +103,16 @@ long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype);
  * fwd takes the weight re-laid out as [9][N][Cin], bwd_data as [9][Cin][N] (tss_permute_w3x3); bwd_weight
  * accumulates straight into the torch layout [N][Cin][3][3]. */
 int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, void* stream);
+/* the same two layouts as bf16 (either may be NULL).  With a bf16 copy and stride 1, dilation 1, contraction in {32, 64, 128},
+ * outputs % 16 == 0 and <= 128, bf16 activations, fwd / bwd_data run the LDS-halo kernel of conv3x3.hip (one 64-pixel
+ * row segment per tile, nine shifted LDS views, double-buffered weight taps); the f32 layout may then be NULL. */
+int tss_permute_w3x3_bf16(const float* w, void* w_tnc_bf16, void* w_tcn_bf16, int N, int Cin, void* stream);
 int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                    const float* w_tnc, void* y, long ldy, double* stats,
+                    const float* w_tnc, const void* w_tnc_bf16, void* y, long ldy, double* stats,
                     int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream);
 int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                          const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* w_tcn_bf16,
                          const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats,
                          int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream);  /* stride 1 */

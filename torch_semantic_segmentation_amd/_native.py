@@ -88,6 +88,11 @@ def call(name, *args):
         raise RuntimeError('%s failed: %s %s' % (name, ERRORS.get(rc, rc), detail))
 
 
+def fast_paths_disabled():
+    """tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1) is in force (parity tests of the generic kernels)."""
+    return lib().tss_get_option(1) == 1
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()

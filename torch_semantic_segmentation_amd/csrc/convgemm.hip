@@ -113,6 +113,27 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
     for (int i = tid; i < NCH * 2; i += NT) Sacc[i] = 0.0;  // first use is after the tile loop's barriers
   }
 
+  // epilogue constants of the 16 channels this lane owns, loaded once (null-safe pointers, clamped channel, selects):
+  // fetched inside the epilogue each was a predicated load in front of the stores (a branch and a wait apiece)
+  float e_bias[4][4], e_mm[4][4], e_ms[4][4], e_mb[4][4];
+  {
+    const float* pb = g.bias ? g.bias : g.w; const float* pm = g.mm ? g.mm : g.w;
+    const float* ps = g.ms ? g.ms : g.w; const float* pq = g.mb ? g.mb : g.w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + fq * 4 + r;
+        const bool in = n < g.ND;
+        const int nb = (in && g.bias) ? n : 0, nm = (in && g.mm) ? n : 0, ns = (in && g.ms) ? n : 0, nq = (in && g.mb) ? n : 0;
+        const float vb = pb[nb], vm = pm[nm], vs = ps[ns], vq = pq[nq];
+        e_bias[i][r] = (in && g.bias) ? vb : 0.f;
+        e_mm[i][r] = (in && g.mm) ? vm : 0.f;
+        e_ms[i][r] = (in && g.ms) ? vs : 1.f;
+        e_mb[i][r] = (in && g.mb) ? vq : 0.f;
+      }
+  }
+
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * BM;
     f32x4 acc[4][4];
@@ -171,11 +192,13 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
 
       // ---- 2. coefficients and (when not resident) weights
       if (MODE != A_STEM) {
-        for (int j = tid; j < kw; j += NT) {
-          Cs[j] = g.c0 ? g.c0[k0 + j] : 1.f;
-          Cs[KC + j] = g.c1 ? g.c1[k0 + j] : 0.f;
-          Cs[2 * KC + j] = g.c2 ? g.c2[k0 + j] : 0.f;
-          Cs[3 * KC + j] = g.c3 ? g.c3[k0 + j] : 0.f;
+        for (int j = tid; j < kw; j += NT) {   // four independent loads through null-safe pointers, then selects
+          const float v0 = (g.c0 ? g.c0 + k0 + j : g.w)[0], v1 = (g.c1 ? g.c1 + k0 + j : g.w)[0];
+          const float v2 = (g.c2 ? g.c2 + k0 + j : g.w)[0], v3 = (g.c3 ? g.c3 + k0 + j : g.w)[0];
+          Cs[j] = g.c0 ? v0 : 1.f;
+          Cs[KC + j] = g.c1 ? v1 : 0.f;
+          Cs[2 * KC + j] = g.c2 ? v2 : 0.f;
+          Cs[3 * KC + j] = g.c3 ? v3 : 0.f;
         }
       }
       if (!w_resident || !w_loaded) {
@@ -189,9 +212,10 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
             for (int u = 0; u < 8; ++u) {
               const int idx = base + tid + u * NT;
               const int n = idx / vpr, jv = idx - n * vpr;
-              wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (idx < total && n < ncw && jv * 4 < kw)
-                wv[u] = *reinterpret_cast<const float4*>(wt + (long)(n0 + n) * g.wrs + k0 + jv * 4);
+              // clamp + select, not a predicated load (a branch with its own wait per load: 16 serial L2 round trips)
+              const bool ok = idx < total && n < ncw && jv * 4 < kw;
+              wv[u] = *reinterpret_cast<const float4*>(wt + (ok ? (long)(n0 + n) * g.wrs + k0 + jv * 4 : 0));
+              if (!ok) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -216,9 +240,9 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
             for (int u = 0; u < 8; ++u) {
               const int idx = base + tid + u * NT;
               const int nv = idx / kwp, j = idx - nv * kwp;
-              wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (idx < total && j < kw && nv * 4 < ncw)
-                wv[u] = *reinterpret_cast<const float4*>(wt + (long)(k0 + j) * g.wcs + n0 + nv * 4);
+              const bool ok = idx < total && j < kw && nv * 4 < ncw;
+              wv[u] = *reinterpret_cast<const float4*>(wt + (ok ? (long)(k0 + j) * g.wcs + n0 + nv * 4 : 0));
+              if (!ok) wv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -335,18 +359,16 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[m][i][r];
-            if (g.bias) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] += (n + r < g.ND) ? g.bias[n + r] : 0.f;
-            }
+            for (int r = 0; r < 4; ++r) v[r] += e_bias[i][r];
             if (xm) {
               float xr[4];
               V4<T>::load(xm + p * g.ldxm + n, xr);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const float xc = xr[r] - (g.mm ? g.mm[n + r] : 0.f);
+                const float xc = xr[r] - e_mm[i][r];
                 if (g.m_relu) {
-                  const float a = g.ms ? (xc * g.ms[n + r] + (g.mb ? g.mb[n + r] : 0.f)) : xc;
+                  const float a = g.ms ? (xc * e_ms[i][r] + e_mb[i][r]) : xc;
                   if (!(a > 0.f)) v[r] = 0.f;
                 }
                 v[r] = V8<T>::round(v[r]);
@@ -469,6 +491,15 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 }  // namespace
 
 extern int g_tss_disable_fast;   // pwfast.hip
+// conv3x3.hip
+bool tss_conv3x3_lean_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                          const void* w9, void* y, long ldy, double* stats, int B, int H, int W, int Cin, int N,
+                          int stride, int dil, hipStream_t stream);
+bool tss_conv3x3_lean_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
+                               const float* gce, const float* gmu, const void* w9t, const void* xraw, long ldx,
+                               const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                               void* e_in, long ldei, double* bstats, int B, int H, int W, int Cin, int N, int dil,
+                               hipStream_t stream);
 bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                     const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats, long P, int K, int N,
                     hipStream_t stream);                                                                    // pwfast.hip
@@ -536,7 +567,7 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 }
 
 int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                    const float* w_tnc, void* y, long ldy, double* stats,
+                    const float* w_tnc, const void* w_tnc_bf16, void* y, long ldy, double* stats,
                     int B, int Hin, int Win, int Cin, int N, int stride, int dil, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && stride >= 1 && dil >= 1,
@@ -550,11 +581,19 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin;  // [tap][n][c]
   g.y = y; g.ldy = ldy; g.stats = stats;
   const double bytes = ((double)B * Hin * Win * Cin + (double)g.P * N) * esz(dtype);
+  if (dtype == TSS_BF16 && w_tnc_bf16 && !g_tss_disable_fast && tss::aligned16(w_tnc_bf16)) {
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes, 18.0 * (double)g.P * Cin * N);
+    if (tss_conv3x3_lean_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc_bf16, y, ldy, stats, B, Hin, Win, Cin, N,
+                             stride, dil, (hipStream_t)stream))
+      return tss::check_last("conv3x3_lean_fwd");
+  }
+  TSS_REQUIRE(w_tnc, TSS_ERR_SHAPE);
   return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes);
 }
 
 int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                          const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* w_tcn_bf16,
                          const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats,
                          int B, int H, int W, int Cin, int N, int dil, int dtype, void* stream) {
@@ -573,8 +612,18 @@ int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   const double bytes = (double)g.P * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * esz(dtype);
+  if (dtype == TSS_BF16 && w_tcn_bf16 && !g_tss_disable_fast && tss::aligned16(w_tcn_bf16) && tss::aligned16(e) &&
+      tss::aligned16(e_in)) {
+    tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes, 18.0 * (double)g.P * Cin * N);
+    if (tss_conv3x3_lean_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn_bf16, xraw, ldx, in_mean, in_scale, in_bias,
+                                  in_relu, e_in, ldei, bstats, B, H, W, Cin, N, dil, (hipStream_t)stream))
+      return tss::check_last("conv3x3_lean_bwd_data");
+  }
+  TSS_REQUIRE(w_tcn, TSS_ERR_SHAPE);
   return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes);
 }
+
+int tss_get_option(int key) { return key == TSS_OPT_DISABLE_FAST_PATHS ? g_tss_disable_fast : -1; }
 
 int tss_set_option(int key, int value) {
   if (key == TSS_OPT_DISABLE_FAST_PATHS) { g_tss_disable_fast = value; return TSS_OK; }

@@ -403,8 +403,19 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const T* e, long lde, long P
   __shared__ float red[NT];
   const int nl = threadIdx.x % 64, pl = threadIdx.x / 64;
   float s = 0.f;
-  if (nl < N)
-    for (long p = (long)blockIdx.x * 4 + pl; p < P; p += (long)gridDim.x * 4) s += (float)e[p * lde + nl];
+  if (nl < N) {
+    const long stride = (long)gridDim.x * 4;
+    for (long p = (long)blockIdx.x * 4 + pl; p < P; p += stride * 8) {
+      T v[8];   // 8 rows in flight per lane (clamped row + select: no predicated loads)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long q = p + u * stride;
+        v[u] = e[(q < P ? q : p) * lde + nl];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (p + u * stride < P) ? (float)v[u] : 0.f;
+    }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (threadIdx.x < 64 && nl < N) atomicAdd(out + nl, red[nl] + red[64 + nl] + red[128 + nl] + red[192 + nl]);

@@ -166,6 +166,12 @@ class EvalAffines:
         return False
 
 
+def _conv3x3_lean(dtype, k, n, stride, dil):
+    """Domain of the LDS-halo dense 3x3 kernel (conv3x3.hip): contraction k, outputs n."""
+    return (dtype == torch.bfloat16 and stride == 1 and dil == 1 and k in (32, 64, 128) and n % 16 == 0 and 16 <= n <= 128
+            and not N.fast_paths_disabled())
+
+
 def _shadow(weight, which):
     ent = _SHADOWS.get(weight.data_ptr()) if _SHADOWS else None
     return ptr(ent[which]) if ent is not None else None
@@ -431,9 +437,14 @@ class ConvUnitFn(Function):
         elif cfg.kind == 'dense':
             if bias is not None:
                 raise NotImplementedError('HIP path: dense 3x3 convolution with bias')
-            w_tnc = torch.empty((9, Cout, cfg.cin), dtype=torch.float32, device=dev)
-            call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
-            call('tss_conv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc),
+            w_tnc = w_tnc16 = None
+            if _conv3x3_lean(x.dtype, cfg.cin, Cout, s, d):      # bf16 tap-major copy: the LDS-halo kernel (conv3x3.hip)
+                w_tnc16 = torch.empty((9, Cout, cfg.cin), dtype=torch.bfloat16, device=dev)
+                call('tss_permute_w3x3_bf16', ptr(weight), ptr(w_tnc16), None, Cout, cfg.cin, st)
+            else:
+                w_tnc = torch.empty((9, Cout, cfg.cin), dtype=torch.float32, device=dev)
+                call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
+            call('tss_conv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(w_tnc16),
                  ptr(y), ld(y), stats, B, Hin, Win, cfg.cin, Cout, s, d, dt, st)
         else:  # stem
             if bias is not None:
@@ -560,9 +571,14 @@ class ConvUnitFn(Function):
                 else:
                     if s != 1:
                         raise NotImplementedError('HIP path: input gradient of a strided dense 3x3 convolution')
-                    w_tcn = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
-                    call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
-                    call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
+                    w_tcn = w_tcn16 = None
+                    if _conv3x3_lean(e.dtype, Cout, Cin, 1, d):       # contraction over Cout, outputs = Cin
+                        w_tcn16 = torch.empty((9, Cin, Cout), dtype=torch.bfloat16, device=dev)
+                        call('tss_permute_w3x3_bf16', ptr(weight), None, ptr(w_tcn16), Cout, Cin, st)
+                    else:
+                        w_tcn = torch.empty((9, Cin, Cout), dtype=torch.float32, device=dev)
+                        call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
+                    call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), ptr(w_tcn16), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cin, Cout, d, dt, st)
         dbias_ret = None
         if ctx.has_bias:
