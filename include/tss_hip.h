@@ -143,6 +143,18 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+/* backward-data AND weight gradient of one layer in a single sweep (bf16; stride/dilation of the strip kernels): e, yraw
+ * and x are read once.  x is the layer's input (always given: the weight gradient needs it); x_pending = 1 when it is a
+ * producer's raw output whose BatchNorm(+ReLU) is still pending (in_* describe it): e_in is then masked and bstats
+ * written, exactly as tss_dwconv3x3_bwd_data does with xraw.  ws: [TSS_STAT_SLABS][C*9] f32 rows of per-block partial
+ * sums, added to dw ([C][1][3][3]) by a second small launch.  tss_dwconv3x3_bwd_fused_supported: 1 when this entry
+ * covers the shape. */
+int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype);
+int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr,
+                            const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                            const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                            int x_pending, void* e_in, long ldei, double* bstats, float* ws, float* dw,
+                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu,
                              const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

@@ -66,6 +66,41 @@ def test_adaptive_pool_fwd_bwd(bins, h, w):
     assert rel(ya, yb) < 1e-5 and rel(a.grad, b.grad) < 1e-5
 
 
+@pytest.mark.parametrize('stride,dil,c,h,w', [(1, 1, 48, 9, 21), (2, 1, 32, 10, 22), (1, 4, 128, 12, 19)])
+@pytest.mark.parametrize('pending', [True, False])
+def test_depthwise_fused_backward_matches_two_launches(stride, dil, c, h, w, pending):
+    """tss_dwconv3x3_bwd_fused (input gradient + weight gradient in one sweep, opt-in) against the default pair of
+    launches on the same bf16 operands: pw+BN+ReLU -> dw+BN -> pw (input BatchNorm pending) or dw first (materialised)."""
+    import importlib
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+
+    def run(fused):
+        torch.manual_seed(21)
+        layers = [F_.Conv2dBlock(c, c, 1)] if pending else []
+        layers += [F_.DWConv2dBlock(c, c, kernel_size=3, padding=dil, stride=stride, dilation=dil), F_.Conv2dBlock(c, c, 1)]
+        m = nn.Sequential(*layers).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = torch.randn(2, c, h, w, device=DEV).requires_grad_(True)
+        old = ops.fuse_dw_backward
+        ops.fuse_dw_backward = fused
+        try:
+            out = m(x)
+            out.float().backward(torch.randn_like(out, dtype=torch.float32))
+        finally:
+            ops.fuse_dw_backward = old
+        return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+    dx1, g1 = run(True)
+    dx0, g0 = run(False)
+    assert rel(dx1, dx0) < 2e-2
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert rel(g1[k], g0[k]) < 2e-2, k
+
+
 def test_resize_image_matches_interpolate():
     from torch_semantic_segmentation_amd import ops
     x = torch.randn(2, 3, 64, 128, device=DEV)

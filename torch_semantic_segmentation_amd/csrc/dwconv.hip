@@ -24,6 +24,7 @@ __device__ unsigned long long g_dw_timing[8];   // debug builds: [prologue, loop
 
 struct DwArgs {
   const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu;
+  int x_mask;      // backward-data: x is the producer's raw output -> ReLU mask + statistics in the epilogue
   const float* w;  // [C][9]
   void* y; long ldy; double* stats;
   const void* e; long lde; const void* yraw; long ldyr; const float* ga; const float* gb; const float* gce; const float* gmu;
@@ -636,11 +637,24 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_weight_strip_
 
 // backward-data on strips of 4 INPUT pixels.  Stride 1: the flipped-tap window of g = BN'(e, y), 2*D + 4 columns.
 // Stride 2 (D = 1): only output rows/columns of matching parity contribute: <= 2 rows x 3 columns.
-template <typename T, int S, int D>
-__global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_kernel(const DwArgs g) {
+//
+// WG = true additionally produces this layer's WEIGHT gradient in the same sweep: dw[t] = sum_p g[p] a[p + off_t] =
+// sum_q g[q - off_t] a[q], and (q, q - off_t) are exactly the (input pixel, window column) pairs the input gradient
+// e_in[q] = sum_t w[t] g[q - off_t] already visits -- stride 2 included, where only parity-matching pairs exist for both.
+// So every g value in the window is multiplied once more, by the ACTIVATED input under the strip (already loaded for
+// the ReLU mask), into 72 per-lane accumulators: e, y and x are read once per layer instead of twice, and the separate
+// weight-gradient launch disappears.  Rows of per-block partial sums go to g.ws as in dw_bwd_weight_strip_kernel.
+// Measured (FastSCNN step, 14 layers): 1.88 ms fused vs 0.95 + 0.70 ms as two launches.  The 72 accumulators put the
+// kernel at 256 VGPRs + 198 AGPRs and 1 wave/SIMD, where memory latency and VALU no longer overlap (2.8 TB/s on the
+// stride-1 layers, on par with the pair; stride 2 loses).  2-pixel strips: 106 AGPRs, slower still (7.65 vs 7.28 ms/step);
+// 2 waves/SIMD spills 500 B/lane.  Kept as an opt-in (TSS_FUSE_DW_BWD=1) until the per-channel constants move to LDS.
+constexpr int WG_SW = 4, WG_WAVES = 1;
+template <typename T, int S, int D, bool WG>
+__global__ __launch_bounds__(NT_MAX, (WG ? WG_WAVES : (D == 1 ? 2 : 1))) void dw_bwd_data_strip_kernel(const DwArgs g) {
   typedef typename StatAcc<T>::type A;
   constexpr int XS = (S == 1) ? D : 1;                  // stride 1: strip pixels D apart, window of 6 output columns
-  constexpr int NCOL = (S == 1) ? (SW + 2) : 3;
+  constexpr int SWW = WG ? WG_SW : SW;                   // pixels per strip
+  constexpr int NCOL = (S == 1) ? (SWW + 2) : (SWW / 2 + 1);
   __shared__ __align__(16) unsigned char smem[NT_MAX * 16 * sizeof(typename StatAcc<T>::type)];
   __shared__ __align__(16) float wl[9 * 768];
   TSS_T(tq0);
@@ -662,6 +676,12 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
   A s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s1[j] = 0; s2[j] = 0; }
+  float accw[WG ? 9 : 1][8];
+#pragma unroll
+  for (int t = 0; t < (WG ? 9 : 1); ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) accw[t][j] = 0.f;
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
   coef8(g.ga, g.w, c0, active, 1.f, ca);
   coef8(g.yraw ? g.gb : nullptr, g.w, c0, active, 0.f, cb);
   coef8(g.yraw ? g.gce : nullptr, g.w, c0, active, 0.f, ce);
@@ -674,7 +694,7 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
 #pragma unroll
   for (int j = 0; j < 8; ++j) kd[j] = -(ca[j] * ce[j]) - cb[j] * cm[j];
   __syncthreads();
-  const int nstrip = ((g.Win + SW * XS - 1) / (SW * XS)) * XS;
+  const int nstrip = ((g.Win + SWW * XS - 1) / (SWW * XS)) * XS;
   const long U = (long)g.B * g.Hin * nstrip;
   const long ntiles = (U + g.NPL - 1) / g.NPL;
   const TileRange tr = xcd_tiles((int)ntiles, g.lead);
@@ -686,22 +706,22 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
     const long t2 = u / nstrip;
     const int iy = (int)(t2 % g.Hin);
     const long b = t2 / g.Hin;
-    const int x0 = (xs / XS) * (SW * XS) + (xs % XS);   // consecutive units -> consecutive pixels (coalesced lanes)
-    float acc[SW][8];
+    const int x0 = (xs / XS) * (SWW * XS) + (xs % XS);   // consecutive units -> consecutive pixels (coalesced lanes)
+    float acc[SWW][8];
 #pragma unroll
-    for (int i = 0; i < SW; ++i)
+    for (int i = 0; i < SWW; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
     // the producer's raw output under the strip (ReLU mask + statistics in the epilogue): issued first, so the round
     // trip runs under the three window rows instead of being exposed at the end of every strip
     const long pbase = (b * g.Hin + iy) * (long)g.Win + x0;
-    typename V8<T>::Raw rx[SW];
+    typename V8<T>::Raw rx[SWW];
     if (g.x) {
 #pragma unroll
-      for (int i = 0; i < SW; ++i) rx[i] = V8<T>::load_raw(x + (pbase + (x0 + i * XS < g.Win ? i * XS : 0)) * g.ldx + c0);
+      for (int i = 0; i < SWW; ++i) rx[i] = V8<T>::load_raw(x + (pbase + (x0 + i * XS < g.Win ? i * XS : 0)) * g.ldx + c0);
     }
-#pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
+    float av[WG ? SWW : 1][8];   // WG: activated input under the strip (zero beyond the row end)
+    auto window_row = [&](const int ky) {
       const int ny = iy - (ky - 1) * D;  // = oy * S
       const int oyr = ny / S;
       // parity / border rows contribute nothing: their loads are clamped to row 0 and masked (no branch around the
@@ -720,6 +740,16 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
         const long q = rowq + (ox < 0 ? 0 : (ox >= g.Wout ? g.Wout - 1 : ox));
         re[c] = V8<T>::load_raw(e + q * g.lde + c0);
         if (yr) ry[c] = V8<T>::load_raw(yr + q * g.ldyr + c0);
+      }
+      if (WG && ky == 0) {   // rx was requested before this row: it arrives first, the row's loads stay in flight
+#pragma unroll
+        for (int i = 0; i < SWW; ++i) {
+          float xv[8];
+          V8<T>::unpack(rx[i], xv);
+          const bool in = x0 + i * XS < g.Win;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) av[i][j] = in ? fmaxf((xv[j] - mu[j]) * sc[j] + sh[j], relu_lo) : 0.f;
+        }
       }
       float wv[3][8];
 #pragma unroll
@@ -749,22 +779,33 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
         //   stride 1:  x0 + i*D - (kx-1)*D == x0 - D + c*D  <=>  i + (2 - kx) == c       (kx counted from the flip)
         //   stride 2:  x0 + i - (kx-1)   == 2 * (x0/2 + c)  <=>  kx == i + 1 - 2c
 #pragma unroll
-        for (int i = 0; i < SW; ++i)
+        for (int i = 0; i < SWW; ++i)
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             const bool hit = (S == 1) ? (i + (2 - kx) == c) : (kx == i + 1 - 2 * c);
             if (hit) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[i][j] += gvv[j] * wv[kx][j];
+              if (WG) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) accw[WG ? ky * 3 + kx : 0][j] += gvv[j] * av[WG ? i : 0][j];
+              }
             }
           }
       }
+    };
+    if constexpr (WG) {      // unrolled: the accumulator index must be static
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) window_row(ky);
+    } else {
+#pragma unroll 1
+      for (int ky = 0; ky < 3; ++ky) window_row(ky);
     }
 #pragma unroll
-    for (int i = 0; i < SW; ++i) {
+    for (int i = 0; i < SWW; ++i) {
       if (x0 + i * XS < g.Win) {
         const long p = pbase + i * XS;
-        if (g.x) {
+        if (g.x_mask) {
           float xv[8];
           V8<T>::unpack(rx[i], xv);
 #pragma unroll
@@ -785,6 +826,33 @@ __global__ __launch_bounds__(NT_MAX, (D == 1 ? 2 : 1)) void dw_bwd_data_strip_ke
 #endif
   TSS_T(tq2);
   if (g.stats) flush_stats<A>(s1, s2, g.stats, g.C, g.CV, g.NPL, cg, pl, active, smem, g.lead);
+  if (WG) {
+    // block reduction of the weight-gradient accumulators over the pixel lanes, three taps at a time through a
+    // [threads][24] slab that reuses the weight stage (the weights are dead): deterministic, no atomics
+    float* red = wl;
+    float* wrow = g.ws + (long)((int)blockIdx.x - g.lead) * g.C * 9;
+#pragma unroll
+    for (int t0 = 0; t0 < 9; t0 += 3) {
+      __syncthreads();
+      if (active) {
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+          for (int j = 0; j < 8; j += 4)
+            *reinterpret_cast<float4*>(red + tid * 24 + tt * 8 + j) =
+                make_float4(accw[WG ? t0 + tt : 0][j], accw[WG ? t0 + tt : 0][j + 1], accw[WG ? t0 + tt : 0][j + 2],
+                            accw[WG ? t0 + tt : 0][j + 3]);
+      }
+      __syncthreads();
+      for (int i = tid; i < g.C * 3; i += blockDim.x) {
+        const int c = i / 3, tt = i - c * 3;
+        const int cgc = c >> 3, j = c & 7;
+        float sum = 0.f;
+        for (int q = 0; q < g.NPL; ++q) sum += red[(q * g.CV + cgc) * 24 + tt * 8 + j];
+        wrow[c * 9 + t0 + tt] = sum;
+      }
+    }
+  }
 #ifdef TSS_TIMING
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   TSS_T(tq3);
@@ -797,7 +865,7 @@ bool launch_strip(int which, const DwArgs& g, int grid, int threads, hipStream_t
 #define TSS_DW_CASE(SS, DD)                                                                                         \
   if (g.stride == SS && g.dil == DD) {                                                                              \
     if (which == 0) hipLaunchKernelGGL((dw_fwd_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g);        \
-    else if (which == 1) hipLaunchKernelGGL((dw_bwd_data_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g); \
+    else if (which == 1) hipLaunchKernelGGL((dw_bwd_data_strip_kernel<T, SS, DD, false>), dim3(grid), dim3(threads), 0, st, g); \
     else hipLaunchKernelGGL((dw_bwd_weight_strip_kernel<T, SS, DD>), dim3(grid), dim3(threads), 0, st, g);            \
     return true;                                                                                                    \
   }
@@ -815,6 +883,20 @@ int geometry(DwArgs& g, int* threads) {
   if (g.NPL < 1) return TSS_ERR_SHAPE;
   *threads = (g.CV * g.NPL + 63) / 64 * 64;
   return TSS_OK;
+}
+
+// backward-data + weight gradient in one sweep (bf16 only: the f32 parity path keeps the two separate kernels)
+bool launch_strip_fused(const DwArgs& g, int grid, int threads, hipStream_t st) {
+#define TSS_DW_CASE(SS, DD)                                                                                         \
+  if (g.stride == SS && g.dil == DD) {                                                                              \
+    hipLaunchKernelGGL((dw_bwd_data_strip_kernel<bf16_t, SS, DD, true>), dim3(grid), dim3(threads), 0, st, g);       \
+    return true;                                                                                                    \
+  }
+  TSS_DW_CASE(1, 1)
+  TSS_DW_CASE(2, 1)
+  TSS_DW_CASE(1, 4)
+#undef TSS_DW_CASE
+  return false;
 }
 
 inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
@@ -876,7 +958,7 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in), TSS_ERR_ALIGN);
   DwArgs g = {};
   g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu; g.w = w;
-  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_mask = xraw != nullptr;
   g.y = e_in; g.ldy = ldei; g.stats = bstats;
   g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
   g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
@@ -905,6 +987,43 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
     else hipLaunchKernelGGL(dw_bwd_data_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g);
   }
   return tss::check_last("dwconv_bwd_data");
+}
+
+int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype) {
+  return dtype == TSS_BF16 && strip_supported(stride, dil) && C > 0 && (C % 8) == 0 && C <= 768;
+}
+
+int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr,
+                            const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                            const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                            int x_pending, void* e_in, long ldei, double* bstats, float* ws, float* dw,
+                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(tss_dwconv3x3_bwd_fused_supported(C, stride, dil, dtype), TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldei % 8) == 0 && ldei >= C && (ldx % 8) == 0 && ldx >= C, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE(x && ws && dw && (!bstats || x_pending), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(x), TSS_ERR_ALIGN);
+  DwArgs g = {};
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu; g.w = w;
+  g.x = x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_mask = x_pending != 0;
+  g.y = e_in; g.ldy = ldei; g.stats = bstats; g.ws = ws; g.dw = dw;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.C = C; g.stride = stride; g.dil = dil;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  int threads;
+  const int rc = geometry(g, &threads);
+  if (rc) return rc;
+  const long P = (long)B * Hin * Win;
+  if (P == 0) return TSS_OK;
+  const long Po = (long)B * g.Hout * g.Wout;
+  const long U = (long)B * Hin * ((Win + WG_SW - 1) / WG_SW);
+  const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
+  {
+    tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
+                        ((double)Po * (yraw ? 2 : 1) + (double)P * 2) * C * esz(dtype), 36.0 * Po * C);
+    launch_strip_fused(g, sgrid, threads, (hipStream_t)stream);
+  }
+  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, sgrid);
+  return tss::check_last("dwconv_bwd_fused");
 }
 
 int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,

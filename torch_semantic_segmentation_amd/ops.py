@@ -12,6 +12,8 @@ ordinary tensors with ordinary gradients.
 
 There is no torch/ATen fallback here: every operator calls the C ABI and raises if it is unavailable.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.nn.modules.batchnorm import _BatchNorm
@@ -46,6 +48,9 @@ class direct_grads:
 
 # Launch a layer's weight gradient on a side stream, concurrently with its input gradient (ConvUnitFn.backward).
 overlap_wgrad = False   # measured: no gain on MI355X once the kernels are pipelined (9.88 ms off vs 9.84-9.95 ms on)
+# depthwise layers: input gradient and weight gradient from one kernel (tss_dwconv3x3_bwd_fused) instead of two launches.
+# Opt-in: correct, reads e / y / x once, but measured slower on MI355X (1 wave/SIMD, see dwconv.hip): 7.28 vs 7.05 ms/step.
+fuse_dw_backward = os.environ.get('TSS_FUSE_DW_BWD', '0') == '1'
 overlap_max_elems = 48 << 20   # only layers too small to fill the chip on their own (large ones just contend)
 _side_streams = {}
 
@@ -555,7 +560,10 @@ class ConvUnitFn(Function):
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
                 defer = 1 if (need_dx and side is None) else 0      # backward-data carries the row reduction
-                call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
+                # input gradient and weight gradient in ONE sweep when the shape allows (e, y, x read once)
+                fused_dw = bool(defer and fuse_dw_backward and N.lib().tss_dwconv3x3_bwd_fused_supported(Cout, s, d, dt))
+                if not fused_dw:
+                    call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
             if need_dx:
@@ -565,6 +573,9 @@ class ConvUnitFn(Function):
                 if cfg.kind == 'pw':
                     call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
+                elif cfg.kind == 'dw' and fused_dw:
+                    call('tss_dwconv3x3_bwd_fused', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(e_in), ld(e_in),
+                         bst, ptr(ws), ptr(dw), B, Hin, Win, Cout, s, d, dt, st)
                 elif cfg.kind == 'dw':
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, B, Hin, Win, Cout, s, d, dt, st)
