@@ -18,6 +18,11 @@ rocprofv3 --pmc WRITE_SIZE -d $out/write --output-format csv -- python3 $root/be
 python3 $root/tools/pmc_traffic.py $out/fetch $out/write $out/${tag}_pmc_traffic.json > $out/${tag}_pmc_traffic.txt
 rm -rf $out/fetch $out/write
 echo "pmc done"
+# 2b. MFMA utilisation of the matrix kernels (counter-only pass)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/mfma --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --graph off --no-cpu-baseline --no-roofline > /dev/null 2> $out/mfma.err
+python3 $root/tools/pmc_mfma.py $out/mfma > $out/${tag}_pmc_mfma.txt
+rm -rf $out/mfma
+echo "mfma done"
 cd $root
 # 3. the timeline of one captured step
 tools/trace_step.sh
@@ -26,4 +31,7 @@ echo "trace done"
 # 4. the bench lines themselves
 python3 bench.py > $out/${tag}_bench_default.json 2> $out/default.err
 python3 bench.py --model contextnet14 --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_contextnet14.json 2> $out/ctx.err
+python3 bench.py --mode eval --steps 20 --warmup 3 > $out/${tag}_bench_eval_c5_fastscnn.json 2> $out/eval1.err
+python3 bench.py --mode eval --steps 20 --warmup 3 --model contextnet14 > $out/${tag}_bench_eval_c5_contextnet14.json 2> $out/eval2.err
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --host-batch > /dev/null 2> $out/${tag}_host_batch.txt
 echo "bench done"
