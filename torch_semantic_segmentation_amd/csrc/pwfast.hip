@@ -433,11 +433,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 // walked in 128-channel chunks with the accumulators kept in registers, each chunk's weights restaged from L2 and
 // the folded BatchNorm constants of all K channels resident in LDS.
 constexpr int KTOT = 768;
-template <bool BWD>
+// TM = pixels per tile: 128, or 64 when a layer has fewer than 256 tiles of 128 (the 1/32-resolution project / expand
+// layers: 128 blocks of 128 pixels left half the CUs idle behind a five-chunk serial chain).
+template <bool BWD, int TM>
 __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
+  constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
+  constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);
-  T* Ws = Xs + BM * RS;
+  T* Ws = Xs + TM * RS;
   float* Ck = reinterpret_cast<float*>(Ws + NCH * RS);   // [3][KTOT]: k0, k1, kadd
   float* Ec = Ck + 3 * KTOT;                              // [3][NCH] epilogue constants
 
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const int nchunks = (g.N + NCH - 1) / NCH;
   const int xcd = bidx & 7, slot = bidx >> 3;
   const int nc = slot % nchunks, gslot = slot / nchunks;
-  const long ntiles = (g.P + BM - 1) / BM;
+  const long ntiles = (g.P + TM - 1) / TM;
   const long per = (ntiles + 7) >> 3;
   const long t_begin = xcd * per + gslot;
   long t_end = xcd * per + per;
@@ -501,11 +505,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const int nlane = n0 + wn * 64 + fq * 4;
 
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
-    const long p0 = tile * BM;
-    const bool full = p0 + BM <= g.P;
-    f32x4 acc[4][4];
+    const long p0 = tile * TM;
+    const bool full = p0 + TM <= g.P;
+    f32x4 acc[MF][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MF; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -514,22 +518,22 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       const int kw = (K - kb < KMAX) ? (K - kb) : KMAX;
       const int kwp = (kw + 31) & ~31;
       const int nvec = kw >> 3, nvecp = kwp >> 3;
-      const int rpp = NT / nvecp, npass = (BM + rpp - 1) / rpp;
+      const int rpp = NT / nvecp, npass = (TM + rpp - 1) / rpp;
       const int cv = tid % nvecp, r = tid / nvecp;
       const bool lane_on = r < rpp, cv_real = cv < nvec;
       __syncthreads();  // previous chunk's MFMA reads are done (and Ck is visible on the first pass)
 
       // A-tile loads first (the HBM round trip), then the weight chunk from L2, then normalise + store
-      uint4 ra[8], rb[8];
+      uint4 ra[NP], rb[NP];
       if (lane_on) {
         const T* pa = g.a0 + p0 * g.lda0 + kb + (cv_real ? cv * 8 : 0);
         const T* pb = BWD ? g.a1 + p0 * g.lda1 + kb + (cv_real ? cv * 8 : 0) : nullptr;
         const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ps = 0; ps < NP; ++ps) {
           if (ps < npass) {
             const int row = ps * rpp + r;
-            const bool ok = row < BM && (full || p0 + row < g.P);
+            const bool ok = row < TM && (full || p0 + row < g.P);
             const int rr = ok ? row : 0;
             ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
             if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
@@ -544,10 +548,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { k0[j] = Ck[cb + j]; k1[j] = Ck[KTOT + cb + j]; kadd[j] = Ck[2 * KTOT + cb + j]; }
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
+        for (int ps = 0; ps < NP; ++ps) {
           if (ps < npass) {
             const int row = ps * rpp + r;
-            if (row < BM) {
+            if (row < TM) {
               const bool ok = cv_real && (full || p0 + row < g.P);
               const uint32_t* ua = reinterpret_cast<const uint32_t*>(&ra[ps]);
               const uint32_t* ub = reinterpret_cast<const uint32_t*>(&rb[ps]);
@@ -575,19 +579,19 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       __syncthreads();
 
       if (nfr > 0) {
-        const T* xrow = Xs + (wm * 64 + fr) * RS + fq * 8;
+        const T* xrow = Xs + (wm * (TM / 2) + fr) * RS + fq * 8;
         const T* wrow = Ws + (wn * 64 + fr) * RS + fq * 8;
         const int nks = kwp >> 5;
         for (int ks = 0; ks < nks; ++ks) {
-          bf16x8 xf[4];
+          bf16x8 xf[MF];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
+          for (int m = 0; m < MF; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RS + ks * 32);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (i < nfr) {
               const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RS + ks * 32);
 #pragma unroll
-              for (int m = 0; m < 4; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
+              for (int m = 0; m < MF; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
             }
           }
         }
@@ -595,8 +599,8 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     }
 
     // ---- epilogue (identical to pwfast_kernel)
-    T* yrow = g.y + (p0 + wm * 64 + fr) * g.ldy + nlane;
-    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * 64 + fr) * g.ldxm + nlane : nullptr;
+    T* yrow = g.y + (p0 + wm * (TM / 2) + fr) * g.ldy + nlane;
+    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm + nlane : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nfr) {
@@ -612,8 +616,8 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
         const float cmm[4] = {e0.x, e0.y, e0.z, e0.w};                                 // bwd: mean / scale / bias
         const float cms[4] = {e1.x, e1.y, e1.z, e1.w}, cmb[4] = {e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const bool pin = full || (p0 + wm * 64 + m * 16 + fr < g.P);
+        for (int m = 0; m < MF; ++m) {
+          const bool pin = full || (p0 + wm * (TM / 2) + m * 16 + fr < g.P);
           if (pin && nin) {
             float v[4];
 #pragma unroll
@@ -673,12 +677,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   }
 }
 
-constexpr size_t kSmemMc = (size_t)(BM + NCH) * RS * sizeof(T) + 3 * KTOT * sizeof(float) + 3 * NCH * sizeof(float);
-
-template <bool BWD>
-void launch_fast_mc(FastArgs& g, hipStream_t stream) {
+template <bool BWD, int TM>
+void launch_fast_mc_tm(FastArgs& g, hipStream_t stream) {
+  constexpr size_t smem = (size_t)(TM + NCH) * RS * sizeof(T) + 3 * KTOT * sizeof(float) + 3 * NCH * sizeof(float);
   const int nchunks = (g.N + NCH - 1) / NCH;
-  const long ntiles = (g.P + BM - 1) / BM;
+  const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
   long cap = 64 / nchunks;
   if (cap < 1) cap = 1;
@@ -687,10 +690,20 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   const int grid = 8 * nchunks * (int)gs + g.nred8;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSmemMc);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr = true;
   }
-  hipLaunchKernelGGL(pwfast_mc_kernel<BWD>, dim3(grid), dim3(NT), kSmemMc, stream, g);
+  hipLaunchKernelGGL((pwfast_mc_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
+}
+
+template <bool BWD>
+void launch_fast_mc(FastArgs& g, hipStream_t stream) {
+  const int nchunks = (g.N + NCH - 1) / NCH;
+  // fewer than 256 block-tiles of 128 pixels: halve the tile so that every CU gets a block
+  const long t128 = (g.P + BM - 1) / BM * nchunks;
+  if (t128 < 192) launch_fast_mc_tm<BWD, 32>(g, stream);
+  else if (t128 < 256) launch_fast_mc_tm<BWD, 64>(g, stream);
+  else launch_fast_mc_tm<BWD, BM>(g, stream);
 }
 
 template <bool BWD, int TM>
