@@ -11,24 +11,29 @@ namespace {
 constexpr int NT = 256;
 
 // ------------------------------------------------------------------------------------------ BN
-// Column sums over the TSS_STAT_SLABS partial rows for a group of FIN_CH channels per block.  Lanes run along the
-// channels (lanes 0..31: sum column c, lanes 32..63: second column C + c), so every load instruction of a wave reads
-// two contiguous 256-byte segments of one slab row; the 16 waves of the block take rows w, w+16, ... (32 rows each,
-// all loads of a lane in flight at once) and meet in LDS.  The first version gave one wave per channel with lanes along the
-// ROWS: 64 different cache lines per instruction, ~8-10 us per finalize x 88 launches per step.
-constexpr int FIN_CH = 32, FIN_WAVES = 16, FIN_NT = FIN_WAVES * 64;
+// Column sums over the TSS_STAT_SLABS partial rows for a group of FIN_CH channels per block.  A wave's 64 lanes are
+// FIN_RG row groups x 2 columns (sum, second moment) x FIN_CH channels: every load instruction reads 2 x FIN_RG contiguous
+// 64-byte segments; the 16 waves take interleaved rows (8 loads per lane, all in flight at once) and meet in LDS.
+// History: one wave per channel with lanes along the ROWS (64 different cache lines per instruction): 8-10 us per finalize
+// x 88 launches per step; 32 channels per block: 6.4 us -- each block still streamed 262 KB through ONE CU, and a layer
+// has only C/32 = 2..24 such blocks; 8 channels per block: 65 KB per block, four times as many CUs pulling: 5.35 us
+// (4 channels per block, 32-byte segments: 6.5 us).
+constexpr int FIN_CH = 8, FIN_RG = 4, FIN_WAVES = 16, FIN_NT = FIN_WAVES * 64;
+static_assert(2 * FIN_CH * FIN_RG == 64, "one wave = row groups x 2 columns x channels");
 __device__ __forceinline__ void slab_sum(const double* slabs, int C, double* s0, double* s1, int* c_out) {
   __shared__ double red[FIN_WAVES][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cl = lane & 31, hs = lane >> 5;
+  const int cl = lane & (FIN_CH - 1), hs = (lane / FIN_CH) & 1, rg = lane / (2 * FIN_CH);
   const int c = blockIdx.x * FIN_CH + cl;
   const bool in = c < C;
   const double* col = slabs + (long)hs * C + (in ? c : 0);
-  constexpr int R = TSS_STAT_SLABS / FIN_WAVES;   // rows per wave
+  constexpr int RSTEP = FIN_WAVES * FIN_RG;        // rows covered by one load instruction of the block
+  constexpr int R = TSS_STAT_SLABS / RSTEP;        // loads per lane
+  static_assert(TSS_STAT_SLABS % RSTEP == 0, "slab rows must divide evenly");
   double acc = 0.0;
-  double v[R];   // all 32 loads of the lane in flight: one memory round trip per finalize
+  double v[R];   // all loads of the lane in flight: one memory round trip per finalize
 #pragma unroll
-  for (int u = 0; u < R; ++u) v[u] = col[(long)(wave + FIN_WAVES * u) * 2 * C];
+  for (int u = 0; u < R; ++u) v[u] = col[(long)(wave * FIN_RG + rg + RSTEP * u) * 2 * C];
 #pragma unroll
   for (int u = 0; u < R; ++u) acc += v[u];
   red[wave][lane] = in ? acc : 0.0;
@@ -36,7 +41,12 @@ __device__ __forceinline__ void slab_sum(const double* slabs, int C, double* s0,
   double a = 0.0, b = 0.0;
   if (threadIdx.x < FIN_CH) {
 #pragma unroll
-    for (int w = 0; w < FIN_WAVES; ++w) { a += red[w][threadIdx.x]; b += red[w][32 + threadIdx.x]; }
+    for (int w = 0; w < FIN_WAVES; ++w)
+#pragma unroll
+      for (int q = 0; q < FIN_RG; ++q) {
+        a += red[w][q * 2 * FIN_CH + threadIdx.x];
+        b += red[w][q * 2 * FIN_CH + FIN_CH + threadIdx.x];
+      }
   }
   *s0 = a; *s1 = b; *c_out = blockIdx.x * FIN_CH + threadIdx.x;   // valid for threadIdx.x < FIN_CH
 }
