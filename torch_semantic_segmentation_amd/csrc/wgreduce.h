@@ -8,6 +8,9 @@
 namespace tss_wg {
 
 constexpr int TN = 128, TK = 128, NT = 256;
+#ifndef WG_SMALL_PX
+#define WG_SMALL_PX 256
+#endif
 
 // workspace slot extent along one axis: min(dim, 128) rounded up to the 16-wide MFMA fragment
 __host__ __device__ inline int ws_dim(int d) { return ((d < TN ? d : TN) + 15) & ~15; }
@@ -20,7 +23,12 @@ inline Split split_for(long P, int K, int N) {
   s.pt = ((wn > wk ? wn : wk) <= 64) ? 128 : 64;      // 128-pixel stages when both chunk widths are <= 64 channels
   s.tiles = ((N + TN - 1) / TN) * ((K + TK - 1) / TK);
   const long nstage = (P + s.pt - 1) / s.pt;
-  const long min_stages = 512 / s.pt;                 // a block amortises its set-up + partial tile over >= 512 pixels (256 and 1024 measured: worse)
+  // a block amortises its set-up + partial tile over >= 512 pixels (256 and 1024 measured: worse) -- unless that leaves
+  // CUs without a block (the 1/32-resolution layers: 160-192 blocks, each a serial chain of 8 stages at one memory
+  // latency per stage, tools/wg_timing.sh): then 256 pixels per block (784 -> 681 us over the 27 launches; 128: 705 us)
+  const long full = s.tiles * ((P + 511) / 512);
+  const long min_px = full < 256 ? WG_SMALL_PX : 512;
+  const long min_stages = (min_px + s.pt - 1) / s.pt;
   long ns = 1024 / s.tiles;
   if (ns < 1) ns = 1;
   if (ns > (nstage + min_stages - 1) / min_stages) ns = (nstage + min_stages - 1) / min_stages;
