@@ -242,6 +242,25 @@ int tss_adaptive_pool_fwd(const void* x, long ldx, void* y, long ldy, int B, int
                           int dtype, void* stream);
 int tss_adaptive_pool_bwd(const void* dy, long lddy, void* dx, long lddx, int B, int H, int W, int C, int bins,
                           int dtype, void* stream);
+/* PyramidPoolingModule (TSS/models/fastscnn.py:101-123), the element-wise stages of ALL arms per launch (narms <= 4; the
+ * pointer / size arrays are HOST arrays of narms entries):
+ *   pool_fwd   : y[a] = AdaptiveAvgPool2d(bins[a])(x), NHWC [B][bins][bins][C]
+ *   pool_bwd   : dx = sum_a pool_a^T(dy[a])
+ *   concat_fwd : out = cat(x, upsample(relu?(bn_a(raw[a]))) for every arm), align_corners=True, raw[a] = [B][bins][bins][ca];
+ *                mean/scale/beta[a] NULL: raw[a] is already the activation
+ *   concat_bwd : e[a] = relu'(.) * upsample^T(dout[:, C + a*ca : C + (a+1)*ca]) and, when bstats[a] != NULL, the slab rows
+ *                (sum e, sum e*(raw - mean)) of the arm's BatchNorm backward (needs B * bins^2 <= tss_stat_slabs()) */
+int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms,
+                     int B, int H, int W, int C, int dtype, void* stream);
+int tss_ppm_pool_bwd(const void* const* dy, const long* lddy, const int* bins, int narms, void* dx, long lddx,
+                     int B, int H, int W, int C, int dtype, void* stream);
+int tss_ppm_concat_fwd(const void* x, long ldx, const void* const* raw, const long* ldr, const int* bins,
+                       const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
+                       int narms, void* out, long ldo, int B, int H, int W, int C, int ca, int dtype, void* stream);
+int tss_ppm_concat_bwd(const void* dout, long lddo, const void* const* raw, const long* ldr, const int* bins,
+                       const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
+                       double* const* bstats, void* const* e, const long* lde, int narms,
+                       int B, int H, int W, int C, int ca, int dtype, void* stream);
 int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream);
 
 /* ---- caller side: loss and evaluation metrics --------------------------------------------------------

@@ -159,6 +159,44 @@ def test_dense3x3_lean_kernel_agrees_with_general_kernel(cin, cout, h, w):
         assert l2(b1[k], b0[k]) < 1e-2, k
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 64, 16, 32), (3, 128, 12, 20)])
+def test_pyramid_pooling_all_arms_per_launch_matches_per_arm_operators(dtype, shape):
+    """tss_ppm_{pool,concat}_{fwd,bwd} (every arm of the PyramidPoolingModule per launch, BatchNorm + ReLU applied per
+    bilinear tap, slab rows written by the gather) against the generic per-arm operators on the same operands."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    B, C, H, W = shape
+
+    def run(fused):
+        torch.manual_seed(13)
+        m = F_.PyramidPoolingModule(C, C).to(DEV)
+        tssa.set_compute_dtype(m, dtype)
+        m.train()
+        x = torch.randn(B, C, H, W, device=DEV).requires_grad_(True)
+        cot = torch.randn(B, C, H, W, device=DEV)
+        old = ops.ppm_fused
+        ops.ppm_fused = fused
+        try:
+            out = m(x.to(dtype) if dtype != torch.float32 else x)
+            out.float().backward(cot)
+        finally:
+            ops.ppm_fused = old
+        return (out.detach().float().cpu(), x.grad.float().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters()},
+                {k: b.detach().float().cpu() for k, b in m.named_buffers() if b.dtype.is_floating_point})
+    o1, dx1, g1, b1 = run(True)
+    o0, dx0, g0, b0 = run(False)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert cases.rel_err(o1, o0) < tol and cases.rel_err(dx1, dx0) < 4 * tol
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert cases.rel_err(g1[k], g0[k]) < 5 * tol, k
+    for k in b0:
+        assert cases.rel_err(b1[k], b0[k]) < tol, k
+
+
 def test_cpu_tensors_raise():
     m = cases.product_block('fast_pw_act')
     with pytest.raises(RuntimeError, match='HIP path only'):

@@ -356,6 +356,227 @@ __global__ __launch_bounds__(NT) void adaptive_pool_bwd_kernel(const T* dy, long
   }
 }
 
+// ---------------------------------------------------------------------------- pyramid pooling, all arms per launch
+// PyramidPoolingModule (TSS/models/fastscnn.py:101-123) is four arms of pool -> 1x1 conv -> BN -> ReLU -> upsample over a
+// 32 x 64 map: 53 launches of 4-11 us per step when every arm runs the generic operators one by one (~0.4 ms for 0.5 GMAC).
+// These four kernels handle the arms' element-wise stages for ALL arms at once (tables passed by value):
+//   ppm_pool_fwd    : the adaptive average pools of every arm                                   (4 launches -> 1)
+//   ppm_pool_bwd    : dx = sum over arms of the pool gradients                                  (4 + 3 adds -> 1)
+//   ppm_concat_fwd  : out = cat(x, upsample(relu(bn_i(raw_i)))) -- BN + ReLU applied per tap    (4 + 4 + 1 -> 1)
+//   ppm_concat_bwd  : e_i = relu'(.) * upsample^T(dout slice_i) + the BatchNorm-backward sums   (8 + 4 -> 1)
+constexpr int PPM_MAX = 4;
+struct PpmArgs {
+  const void* x; long ldx; void* out; long ldo;           // concat: x -> out[:, :C];  pool: x is the pooled-from map
+  const void* raw[PPM_MAX]; long ldr[PPM_MAX];            // arm tensors [B][bins][bins][ca] (pool outputs / conv raw outputs / grads)
+  void* e[PPM_MAX]; long lde[PPM_MAX];                    // concat bwd: masked gradient per arm
+  const float* mean[PPM_MAX]; const float* scale[PPM_MAX]; const float* beta[PPM_MAX];
+  double* bstats[PPM_MAX];
+  int bins[PPM_MAX], cell0[PPM_MAX + 1];                  // cell0: prefix sums of bins^2
+  int relu[PPM_MAX];
+  int narms, B, H, W, C, ca;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ppm_pool_fwd_kernel(const PpmArgs g, int CV, int NPL) {
+  __shared__ float red[NT * 8];
+  const int cells = g.cell0[g.narms];
+  const int cid = blockIdx.x % cells;
+  const long b = blockIdx.x / cells;
+  int arm = 0;
+#pragma unroll
+  for (int a = 1; a < PPM_MAX; ++a) if (a < g.narms && cid >= g.cell0[a]) arm = a;
+  const int bins = g.bins[arm], cell = cid - g.cell0[arm];
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* y = reinterpret_cast<T*>(g.e[arm]);
+  const int H = g.H, W = g.W, C = g.C;
+  const int bi = cell / bins, bj = cell % bins;
+  const int y0 = pool_start(bi, H, bins), y1 = pool_end(bi, H, bins);
+  const int x0 = pool_start(bj, W, bins), x1 = pool_end(bj, W, bins);
+  const int tid = threadIdx.x, cg = tid % CV, pl = tid / CV;
+  const bool active = pl < NPL;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  if (active) {
+    for (int k0 = pl; k0 < n; k0 += NPL * 8) {
+      typename V8<T>::Raw raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * NPL;
+        const int kk = k < n ? k : pl;
+        const int yy = y0 + kk / ww, xx = x0 + kk % ww;
+        raw[u] = V8<T>::load_raw(x + ((b * H + yy) * (long)W + xx) * g.ldx + cg * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float v[8];
+        V8<T>::unpack(raw[u], v);
+        const bool on = k0 + u * NPL < n;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += on ? v[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pl * C + cg * 8 + j] = acc[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += blockDim.x) {
+    float t = 0.f;
+    for (int q = 0; q < NPL; ++q) t += red[q * C + c];
+    y[(b * bins * bins + cell) * g.lde[arm] + c] = (T)(t / (float)n);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ppm_pool_bwd_kernel(const PpmArgs g) {
+  const int CV = g.C / 8, H = g.H, W = g.W;
+  const long total = (long)g.B * H * W * CV;
+  T* dx = reinterpret_cast<T*>(g.out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const long b = p / H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int a = 0; a < g.narms; ++a) {
+      const int bins = g.bins[a];
+      const T* dy = reinterpret_cast<const T*>(g.raw[a]);
+      for (int bi = 0; bi < bins; ++bi) {
+        const int y0 = pool_start(bi, H, bins), y1 = pool_end(bi, H, bins);
+        if (yy < y0 || yy >= y1) continue;
+        for (int bj = 0; bj < bins; ++bj) {
+          const int x0 = pool_start(bj, W, bins), x1 = pool_end(bj, W, bins);
+          if (xx < x0 || xx >= x1) continue;
+          const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+          float v[8];
+          V8<T>::load(dy + ((b * bins + bi) * (long)bins + bj) * g.ldr[a] + cv * 8, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += v[j] * inv;
+        }
+      }
+    }
+    V8<T>::store(dx + ((b * H + yy) * (long)W + xx) * g.ldo + cv * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void ppm_concat_fwd_kernel(const PpmArgs g) {
+  const int CVx = g.C / 8, CVa = g.ca / 8, CVt = CVx + g.narms * CVa;
+  const int H = g.H, W = g.W;
+  const long total = (long)g.B * H * W * CVt;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  T* out = reinterpret_cast<T*>(g.out);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CVt);
+    long p = i / CVt;
+    const long pix = p;
+    const int ox = (int)(p % W); p /= W;
+    const int oy = (int)(p % H);
+    const long b = p / H;
+    float o[8];
+    if (cv < CVx) {
+      V8<T>::load(x + pix * g.ldx + cv * 8, o);
+    } else {
+      const int arm = (cv - CVx) / CVa, c0 = ((cv - CVx) % CVa) * 8;
+      const int bins = g.bins[arm];
+      const float sy = ac_scale(bins, H), sx = ac_scale(bins, W);
+      const Tap ty = ac_tap(sy, oy, bins), tx = ac_tap(sx, ox, bins);
+      const T* base = reinterpret_cast<const T*>(g.raw[arm]) + (b * bins * (long)bins) * g.ldr[arm] + c0;
+      const long ld = g.ldr[arm];
+      float v00[8], v01[8], v10[8], v11[8], mu[8], sc[8], be[8];
+      V8<T>::load(base + ((long)ty.i0 * bins + tx.i0) * ld, v00);
+      V8<T>::load(base + ((long)ty.i0 * bins + tx.i1) * ld, v01);
+      V8<T>::load(base + ((long)ty.i1 * bins + tx.i0) * ld, v10);
+      V8<T>::load(base + ((long)ty.i1 * bins + tx.i1) * ld, v11);
+      const bool aff = g.scale[arm] != nullptr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        mu[j] = aff ? g.mean[arm][c0 + j] : 0.f; sc[j] = aff ? g.scale[arm][c0 + j] : 1.f; be[j] = aff ? g.beta[arm][c0 + j] : 0.f;
+      }
+      const float lo = g.relu[arm] ? 0.f : -TSS_INF;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // the arm's activation is rounded to T where the unfused path materialised it, then interpolated
+        const float a00 = V8<T>::round(fmaxf((v00[j] - mu[j]) * sc[j] + be[j], lo)), a01 = V8<T>::round(fmaxf((v01[j] - mu[j]) * sc[j] + be[j], lo));
+        const float a10 = V8<T>::round(fmaxf((v10[j] - mu[j]) * sc[j] + be[j], lo)), a11 = V8<T>::round(fmaxf((v11[j] - mu[j]) * sc[j] + be[j], lo));
+        o[j] = ty.l0 * (tx.l0 * a00 + tx.l1 * a01) + ty.l1 * (tx.l0 * a10 + tx.l1 * a11);
+      }
+    }
+    V8<T>::store(out + pix * g.ldo + cv * 8, o);
+  }
+}
+
+// one block per (image, arm, cell): gathers the cell's gradient from the window of output pixels that read it,
+// applies the ReLU mask of the arm's activation and leaves (e, e * (raw - mean)) in the arm's slab row b * bins^2 + cell
+template <typename T>
+__global__ __launch_bounds__(NT) void ppm_concat_bwd_kernel(const PpmArgs g) {
+  __shared__ float red[NT * 8];
+  const int cells = g.cell0[g.narms];
+  const int cid = blockIdx.x % cells;
+  const long b = blockIdx.x / cells;
+  int arm = 0;
+#pragma unroll
+  for (int a = 1; a < PPM_MAX; ++a) if (a < g.narms && cid >= g.cell0[a]) arm = a;
+  const int bins = g.bins[arm], cell = cid - g.cell0[arm];
+  const int ci = cell / bins, cj = cell % bins;
+  const int H = g.H, W = g.W, ca = g.ca, CVa = ca / 8;
+  const int tid = threadIdx.x, cg = tid % CVa, pl = tid / CVa, NPL = NT / CVa;
+  const float sy = ac_scale(bins, H), sx = ac_scale(bins, W);
+  int ylo, yhi, xlo, xhi;
+  ac_window(sy, ci, H, &ylo, &yhi);
+  ac_window(sx, cj, W, &xlo, &xhi);
+  const int ww = xhi - xlo + 1, n = (yhi - ylo + 1) * ww;
+  const T* dout = reinterpret_cast<const T*>(g.x) + g.C + arm * ca + cg * 8;   // x = the gradient of the concat buffer
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int k0 = pl; k0 < n; k0 += NPL * 4) {
+    typename V8<T>::Raw raw[4];
+    float wgt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * NPL;
+      const int kk = k < n ? k : pl;
+      const int oy = ylo + kk / ww, ox = xlo + kk % ww;
+      wgt[u] = k < n ? ac_weight(sy, oy, bins, ci) * ac_weight(sx, ox, bins, cj) : 0.f;
+      raw[u] = V8<T>::load_raw(dout + ((b * H + oy) * (long)W + ox) * g.ldx);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v[8];
+      V8<T>::unpack(raw[u], v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += wgt[u] != 0.f ? wgt[u] * v[j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[pl * ca + cg * 8 + j] = acc[j];
+  __syncthreads();
+  const long q = b * bins * bins + cell;
+  const int rows_used = g.B * bins * bins;
+  for (int c = tid; c < ca; c += blockDim.x) {
+    float t = 0.f;
+    for (int r = 0; r < NPL; ++r) t += red[r * ca + c];
+    const float v = (float)reinterpret_cast<const T*>(g.raw[arm])[q * g.ldr[arm] + c];
+    const bool aff = g.scale[arm] != nullptr;
+    const float xc = v - (aff ? g.mean[arm][c] : 0.f);
+    const float act = aff ? xc * g.scale[arm][c] + g.beta[arm][c] : xc;
+    if (g.relu[arm] && !(act > 0.f)) t = 0.f;
+    t = V8<T>::round(t);
+    reinterpret_cast<T*>(g.e[arm])[q * g.lde[arm] + c] = (T)t;
+    double* st = g.bstats[arm];
+    if (st) {
+      st[q * 2 * ca + c] = (double)t;
+      st[q * 2 * ca + ca + c] = (double)t * (double)xc;
+      for (long rr = q + rows_used; rr < TSS_STAT_SLABS; rr += rows_used) { st[rr * 2 * ca + c] = 0.0; st[rr * 2 * ca + ca + c] = 0.0; }
+    }
+  }
+}
+
 // copy a [P][C] NHWC tensor into a channel slice of another (concat without torch.cat)
 template <typename T>
 __global__ __launch_bounds__(NT) void copy_nhwc_kernel(const T* x, long ldx, T* y, long ldy, long P, int C) {
@@ -551,6 +772,104 @@ int tss_adaptive_pool_bwd(const void* dy, long lddy, void* dx, long lddx, int B,
     hipLaunchKernelGGL(adaptive_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
                        (const float*)dy, lddy, (float*)dx, lddx, B, H, W, C, bins);
   return tss::check_last("adaptive_pool_bwd");
+}
+
+namespace {
+int ppm_fill(PpmArgs& g, int narms, const int* bins, int B, int H, int W, int C, int ca) {
+  if (narms < 1 || narms > PPM_MAX || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C % 8) != 0) return TSS_ERR_SHAPE;
+  g.narms = narms; g.B = B; g.H = H; g.W = W; g.C = C; g.ca = ca;
+  g.cell0[0] = 0;
+  for (int a = 0; a < narms; ++a) {
+    if (bins[a] < 1) return TSS_ERR_SHAPE;   // bins > H or W is legal (one-pixel windows repeat), as in torch
+    g.bins[a] = bins[a];
+    g.cell0[a + 1] = g.cell0[a] + bins[a] * bins[a];
+  }
+  for (int a = narms; a < PPM_MAX; ++a) { g.bins[a] = 1; g.cell0[a + 1] = g.cell0[narms]; }
+  return TSS_OK;
+}
+}  // namespace
+
+int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms,
+                     int B, int H, int W, int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C <= NT * 8 && (ldx % 8) == 0 && ldx >= C && tss::aligned16(x), TSS_ERR_SHAPE);
+  PpmArgs g = {};
+  const int rc = ppm_fill(g, narms, bins, B, H, W, C, C);
+  if (rc) return rc;
+  g.x = x; g.ldx = ldx;
+  for (int a = 0; a < narms; ++a) { TSS_REQUIRE(y[a] && ldy[a] >= C, TSS_ERR_SHAPE); g.e[a] = y[a]; g.lde[a] = ldy[a]; }
+  const int CV = C / 8, NPL = NT / CV;
+  const int threads = (CV * NPL + 63) / 64 * 64;
+  const int grid = B * g.cell0[narms];
+  tss::ProfScope prof(TSS_K_POOL_FWD, (hipStream_t)stream, (double)narms * B * H * W * C * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_pool_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL);
+  else hipLaunchKernelGGL(ppm_pool_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL);
+  return tss::check_last("ppm_pool_fwd");
+}
+
+int tss_ppm_pool_bwd(const void* const* dy, const long* lddy, const int* bins, int narms, void* dx, long lddx,
+                     int B, int H, int W, int C, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE((lddx % 8) == 0 && lddx >= C && tss::aligned16(dx), TSS_ERR_SHAPE);
+  PpmArgs g = {};
+  const int rc = ppm_fill(g, narms, bins, B, H, W, C, C);
+  if (rc) return rc;
+  g.out = dx; g.ldo = lddx;
+  for (int a = 0; a < narms; ++a) {
+    TSS_REQUIRE(dy[a] && (lddy[a] % 8) == 0 && lddy[a] >= C && tss::aligned16(dy[a]), TSS_ERR_SHAPE);
+    g.raw[a] = dy[a]; g.ldr[a] = lddy[a];
+  }
+  const long total = (long)B * H * W * (C / 8);
+  tss::ProfScope prof(TSS_K_POOL_BWD, (hipStream_t)stream, (double)B * H * W * C * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_pool_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(ppm_pool_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g);
+  return tss::check_last("ppm_pool_bwd");
+}
+
+int tss_ppm_concat_fwd(const void* x, long ldx, const void* const* raw, const long* ldr, const int* bins,
+                       const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
+                       int narms, void* out, long ldo, int B, int H, int W, int C, int ca, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(ca > 0 && (ca % 8) == 0 && (ldx % 8) == 0 && ldx >= C && (ldo % 8) == 0 && ldo >= C + narms * ca, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(out), TSS_ERR_ALIGN);
+  PpmArgs g = {};
+  const int rc = ppm_fill(g, narms, bins, B, H, W, C, ca);
+  if (rc) return rc;
+  g.x = x; g.ldx = ldx; g.out = out; g.ldo = ldo;
+  for (int a = 0; a < narms; ++a) {
+    TSS_REQUIRE(raw[a] && (ldr[a] % 8) == 0 && ldr[a] >= ca && tss::aligned16(raw[a]), TSS_ERR_SHAPE);
+    g.raw[a] = raw[a]; g.ldr[a] = ldr[a]; g.mean[a] = mean[a]; g.scale[a] = scale[a]; g.beta[a] = beta[a]; g.relu[a] = relu[a];
+    TSS_REQUIRE((mean[a] != nullptr) == (scale[a] != nullptr) && (beta[a] != nullptr) == (scale[a] != nullptr), TSS_ERR_SHAPE);
+  }
+  const long total = (long)B * H * W * ((C + narms * ca) / 8);
+  tss::ProfScope prof(TSS_K_BILINEAR_FWD, (hipStream_t)stream, (double)B * H * W * (2 * C + narms * ca) * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_concat_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(ppm_concat_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g);
+  return tss::check_last("ppm_concat_fwd");
+}
+
+int tss_ppm_concat_bwd(const void* dout, long lddo, const void* const* raw, const long* ldr, const int* bins,
+                       const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
+                       double* const* bstats, void* const* e, const long* lde, int narms,
+                       int B, int H, int W, int C, int ca, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(ca > 0 && (ca % 8) == 0 && ca <= 256 && (NT % (ca / 8)) == 0 && (lddo % 8) == 0 && lddo >= C + narms * ca, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(dout), TSS_ERR_ALIGN);
+  PpmArgs g = {};
+  const int rc = ppm_fill(g, narms, bins, B, H, W, C, ca);
+  if (rc) return rc;
+  g.x = dout; g.ldx = lddo;
+  for (int a = 0; a < narms; ++a) {
+    TSS_REQUIRE(raw[a] && e[a] && ldr[a] >= ca && lde[a] >= ca, TSS_ERR_SHAPE);
+    TSS_REQUIRE((long)B * bins[a] * bins[a] <= TSS_STAT_SLABS || !bstats[a], TSS_ERR_SHAPE);   // one slab row per (image, cell)
+    g.raw[a] = raw[a]; g.ldr[a] = ldr[a]; g.mean[a] = mean[a]; g.scale[a] = scale[a]; g.beta[a] = beta[a]; g.relu[a] = relu[a];
+    g.bstats[a] = bstats[a]; g.e[a] = e[a]; g.lde[a] = lde[a];
+  }
+  const int grid = B * g.cell0[narms];
+  tss::ProfScope prof(TSS_K_BILINEAR_BWD, (hipStream_t)stream, (double)B * H * W * narms * ca * esz(dtype), 0);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_concat_bwd_kernel<bf16_t>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g);
+  else hipLaunchKernelGGL(ppm_concat_bwd_kernel<float>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g);
+  return tss::check_last("ppm_concat_bwd");
 }
 
 int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream) {

@@ -605,7 +605,7 @@ class ConvUnitFn(Function):
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
 
 class JoinCfg:
-    __slots__ = ('a_link', 'b_link', 'relu')
+    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus')
 
 
 def join(a, b=None, relu=False):
@@ -870,6 +870,104 @@ class ConcatUpFn(Function):
             call('tss_bilinear_nhwc_bwd', ptr(sl), ld(dout), ptr(db), ld(db), ptr(tmp), B, hb, wb, H, W, cb, dt, st)
             grads.append(db)
         return tuple(grads)
+
+
+# ----------------------------------------------------------------------------- pyramid pooling, all arms per launch
+
+ppm_fused = os.environ.get('TSS_PPM_FUSED', '1') != '0'   # False: every arm through the generic operators (A/B checks)
+
+
+def _hp(tensors):
+    """Host array of device pointers (None -> NULL) for the tss_ppm_* entry points."""
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _hl(vals):
+    import ctypes
+    return (ctypes.c_long * len(vals))(*[int(v) for v in vals])
+
+
+def _hi(vals):
+    import ctypes
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def adaptive_avg_pool_multi(x, bins):
+    """[AdaptiveAvgPool2d(b)(x) for b in bins] from one launch (and one launch for the summed gradient)."""
+    x = to_nhwc(materialize(x))
+    return PoolMultiFn.apply(x, tuple(int(b) for b in bins))
+
+
+class PoolMultiFn(Function):
+    @staticmethod
+    def forward(ctx, x, bins):
+        B, C, H, W = x.shape
+        ys = [new_nhwc(B, C, b, b, x.dtype, x.device) for b in bins]
+        call('tss_ppm_pool_fwd', ptr(x), ld(x), _hp(ys), _hl([ld(y) for y in ys]), _hi(bins), len(bins), B, H, W, C,
+             N.dtype_code(x.dtype), stream())
+        ctx.geom = (B, C, H, W, bins, x.dtype, x.device)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        B, C, H, W, bins, dtype, dev = ctx.geom
+        dys = [to_nhwc(d) if d is not None else new_nhwc(B, C, b, b, dtype, dev).zero_() for d, b in zip(dys, bins)]
+        dx = new_nhwc(B, C, H, W, dtype, dev)
+        call('tss_ppm_pool_bwd', _hp(dys), _hl([ld(d) for d in dys]), _hi(bins), len(bins), ptr(dx), ld(dx), B, H, W, C,
+             N.dtype_code(dtype), stream())
+        return dx, None
+
+
+def ppm_arms_fusable(x, arms):
+    """concat_upsampled_arms covers these arms: <= 4 Deferred square maps of equal channel count, one slab row per cell."""
+    if not ppm_fused or not 1 <= len(arms) <= 4 or not all(isinstance(a, Deferred) for a in arms):
+        return False
+    ca = arms[0].raw.shape[1]
+    return all(a.raw.shape[1] == ca and a.raw.shape[2] == a.raw.shape[3] and a.raw.dtype == x.dtype
+               and x.shape[0] * a.raw.shape[2] ** 2 <= N.stat_slabs() for a in arms) and ca % 8 == 0 and 256 % (ca // 8) == 0
+
+
+def concat_upsampled_arms(x, arms):
+    """torch.cat([x, *[upsample(relu(bn(arm))) for arm in arms]], 1): the pending BatchNorm + ReLU of every arm is applied
+    per bilinear tap, all arms in one launch; backward hands every arm its masked gradient and BatchNorm-backward sums."""
+    x = to_nhwc(materialize(x))
+    ds = [a.take() for a in arms]
+    cfg = JoinCfg()
+    cfg.links = [d.link for d in ds]
+    cfg.relus = [bool(d.relu) for d in ds]
+    return PpmConcatFn.apply(x, cfg, *[d.raw for d in ds])
+
+
+class PpmConcatFn(Function):
+    @staticmethod
+    def _tables(cfg):
+        links = cfg.links
+        return (_hp([l.mean if l is not None else None for l in links]), _hp([l.scale if l is not None else None for l in links]),
+                _hp([l.beta if l is not None else None for l in links]), _hi(cfg.relus))
+
+    @staticmethod
+    def forward(ctx, x, cfg, *raws):
+        B, C, H, W = x.shape
+        n, ca = len(raws), raws[0].shape[1]
+        bins = [r.shape[2] for r in raws]
+        out = new_nhwc(B, C + n * ca, H, W, x.dtype, x.device)
+        call('tss_ppm_concat_fwd', ptr(x), ld(x), _hp(raws), _hl([ld(r) for r in raws]), _hi(bins), *PpmConcatFn._tables(cfg),
+             n, ptr(out), ld(out), B, H, W, C, ca, N.dtype_code(x.dtype), stream())
+        ctx.cfg, ctx.geom = cfg, (B, C, H, W, ca, bins)
+        ctx.save_for_backward(*raws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        raws = ctx.saved_tensors
+        B, C, H, W, ca, bins = ctx.geom
+        dout = to_nhwc(dout)
+        es = [new_nhwc(B, ca, b, b, dout.dtype, dout.device) for b in bins]
+        call('tss_ppm_concat_bwd', ptr(dout), ld(dout), _hp(raws), _hl([ld(r) for r in raws]), _hi(bins),
+             *PpmConcatFn._tables(ctx.cfg), _hp([l.bstats if l is not None else None for l in ctx.cfg.links]),
+             _hp(es), _hl([ld(e) for e in es]), len(raws), B, H, W, C, ca, N.dtype_code(dout.dtype), stream())
+        return (dout[:, :C], None, *es)
 
 
 # ----------------------------------------------------------------------------- loss / metrics (caller side)
