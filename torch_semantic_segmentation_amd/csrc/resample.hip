@@ -493,9 +493,14 @@ __global__ __launch_bounds__(NT) void ppm_concat_fwd_kernel(const PpmArgs g) {
       V8<T>::load(base + ((long)ty.i1 * bins + tx.i0) * ld, v10);
       V8<T>::load(base + ((long)ty.i1 * bins + tx.i1) * ld, v11);
       const bool aff = g.scale[arm] != nullptr;
+      {   // six 16-byte loads through null-safe pointers (24 scalar loads behind a branch otherwise)
+        const float* safe = reinterpret_cast<const float*>(base);
+        const float* pm = aff ? g.mean[arm] + c0 : safe; const float* ps = aff ? g.scale[arm] + c0 : safe;
+        const float* pb = aff ? g.beta[arm] + c0 : safe;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        mu[j] = aff ? g.mean[arm][c0 + j] : 0.f; sc[j] = aff ? g.scale[arm][c0 + j] : 1.f; be[j] = aff ? g.beta[arm][c0 + j] : 0.f;
+        for (int h = 0; h < 8; h += 4) { V4<float>::load(pm + h, mu + h); V4<float>::load(ps + h, sc + h); V4<float>::load(pb + h, be + h); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { mu[j] = aff ? mu[j] : 0.f; sc[j] = aff ? sc[j] : 1.f; be[j] = aff ? be[j] : 0.f; }
       }
       const float lo = g.relu[arm] ? 0.f : -TSS_INF;
 #pragma unroll
