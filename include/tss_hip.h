@@ -202,12 +202,16 @@ int tss_bn_bwd_finalize_sync(const double* bstats, const double* gsums, const fl
  *           TSS/models/fastscnn.py:89, TSS/models/contextnet.py:126. */
 int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, const float* ba,
                  const void* b, long ldb, const float* mb, const float* sb, const float* bb,
-                 void* out, long ldo, int relu, long P, int C, int dtype, void* stream);
-/* e = dout * relu'(out) (written if e != NULL); stats_x (optional) = partial sums of e and e * (x_raw - mean_x) */
+                 void* out, long ldo, int relu, float drop_p, const unsigned long long* seed_slot,
+                 long P, int C, int dtype, void* stream);
+/* seed_slot != NULL (needs relu): nn.Dropout(drop_p) of the Classifier (TSS/models/fastscnn.py:96, contextnet.py:85) applied to
+ * the joined activation in the same pass, with the mask tss_dropout would draw from that slot.
+ * e = dout_scale * dout * relu'(out) (written if e != NULL); stats_x (optional) = partial sums of e and e * (x_raw - mean_x).
+ * dout_scale = 1/(1 - p) for a join that applied dropout (out > 0 <=> kept and active, so no mask is regenerated), else 1. */
 int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
                  const void* a_raw, long lda, const float* mean_a, double* stats_a,
                  const void* b_raw, long ldb, const float* mean_b, double* stats_b,
-                 void* e, long lde, long P, int C, int dtype, void* stream);
+                 void* e, long lde, float dout_scale, long P, int C, int dtype, void* stream);
 
 /* ---- dropout / bias gradient / optimizer ------------------------------------------------------------
  * replaces: nn.Dropout(0.1) TSS/models/fastscnn.py:96, TSS/models/contextnet.py:85 (Philox; mask recomputed in backward);

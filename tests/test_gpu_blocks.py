@@ -197,6 +197,41 @@ def test_pyramid_pooling_all_arms_per_launch_matches_per_arm_operators(dtype, sh
         assert cases.rel_err(b1[k], b0[k]) < tol, k
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dropout_folded_into_the_join_is_bit_identical_to_its_own_pass(dtype):
+    """Classifier tail (... -> BN -> ReLU -> Dropout -> Conv2d, TSS/models/fastscnn.py:92-98): the join that materialises
+    the activation applies the dropout mask itself (same Philox counters as tss_dropout); backward only rescales, because
+    out > 0 <=> kept and active.  Same seed, same bits as the separate dropout pass, forward and backward."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+
+    def run(fused):
+        torch.manual_seed(17)
+        ops._dropout_counters.clear()            # the device-side Philox counter restarts from torch.initial_seed()
+        m = F_.Classifier(32, 19).to(DEV)
+        m[2].p = 0.3
+        tssa.set_compute_dtype(m, dtype)
+        m.train()
+        x = torch.randn(2, 32, 8, 24, device=DEV).requires_grad_(True)
+        old = ops.fuse_dropout
+        ops.fuse_dropout = fused
+        try:
+            out = m(x.to(dtype) if dtype != torch.float32 else x)
+            out.float().backward(torch.ones_like(out, dtype=torch.float32))
+        finally:
+            ops.fuse_dropout = old
+        return out.detach().float(), x.grad.float(), [p.grad.float().clone() for p in m.parameters()]
+    o1, dx1, g1 = run(True)
+    o0, dx0, g0 = run(False)
+    assert torch.equal(o1, o0) and torch.equal(dx1, dx0)
+    for a, b in zip(g1, g0):
+        assert cases.rel_err(a.cpu(), b.cpu()) < 1e-5      # weight-gradient sums may differ in order only
+    # the mask is real: about 30 % of the (positive) activations feeding the last conv were dropped
+    assert (o1 != 0).any()
+
+
 def test_cpu_tensors_raise():
     m = cases.product_block('fast_pw_act')
     with pytest.raises(RuntimeError, match='HIP path only'):

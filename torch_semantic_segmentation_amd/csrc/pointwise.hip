@@ -208,6 +208,9 @@ struct JoinArgs {
   // backward
   const void* dout; long lddo; void* e; long lde; double* stats_a; double* stats_b;
   long P; int C, CV, NPL;
+  // dropout folded into a ReLU join (Classifier: ... -> BN -> ReLU -> Dropout): forward keeps/zeroes with the Philox mask of
+  // dropout_kernel; backward needs no mask -- out > 0 <=> kept and active -- only the 1/(1-p) factor (dscale)
+  float drop_p; const unsigned long long* seed_slot; float dscale;
 };
 
 // 8 per-channel constants of a lane: two unconditional 16-byte loads through a null-safe pointer, then a select
@@ -219,6 +222,26 @@ __device__ __forceinline__ void coef8(const float* p, const float* safe, int c0,
   V4<float>::load(q + 4, v + 4);
 #pragma unroll
   for (int j = 0; j < 8; ++j) out[j] = (has && active) ? v[j] : dflt;
+}
+
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__global__ void dropout_tick_kernel(unsigned long long* counter, unsigned long long* slot) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { *slot = *counter; *counter += 1ull; }
 }
 
 template <typename T>
@@ -242,6 +265,10 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
   coef8(g.sb ? g.bb : nullptr, safe, c0, true, 0.f, bb);
   const long stride = (long)gridDim.x * g.NPL;
   const float relu_lo = g.relu ? 0.f : -__builtin_inff();
+  const unsigned long long dseed = g.seed_slot ? *g.seed_slot : 0ull;
+  const uint32_t dk0 = (uint32_t)dseed, dk1 = (uint32_t)(dseed >> 32) ^ 0x5EEDu;
+  const float dinv = 1.f / (1.f - g.drop_p);
+  const uint32_t dthresh = (uint32_t)((double)g.drop_p * 4294967296.0);
   const bool hb = b != nullptr;
   const T* b2 = hb ? b : a;                                      // dummy second stream when there is none
   const long ldb2 = hb ? g.ldb : g.lda;
@@ -256,6 +283,17 @@ __global__ __launch_bounds__(NT) void join_fwd_kernel(const JoinArgs g) {
       v[j] = (v[j] - ma[j]) * sa[j] + ba[j];
       if (hb) v[j] += (u[j] - mb[j]) * sb[j] + bb[j];
       v[j] = fmaxf(v[j], relu_lo);
+    }
+    if (g.seed_slot) {   // same counters / keys as dropout_kernel on the materialised tensor: identical mask, identical bits
+      uint32_t r0[4], r1[4];
+      const uint64_t ctr = (uint64_t)(p * g.C + c0) >> 2;
+      philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), dk0, dk1, r0);
+      philox4x32((uint32_t)(ctr + 1), (uint32_t)((ctr + 1) >> 32), dk0, dk1, r1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = (r0[j] >= dthresh) ? V8<T>::round(v[j]) * dinv : 0.f;
+        v[4 + j] = (r1[j] >= dthresh) ? V8<T>::round(v[4 + j]) * dinv : 0.f;
+      }
     }
     V8<T>::store(out + p * g.ldo + c0, v);
   }
@@ -299,6 +337,10 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
       const typename V8<T>::Raw rB = V8<T>::load_raw(pb + p * ldb + c0);
       float v[8], o[8], ua[8], ub[8];
       V8<T>::unpack(rd, v); V8<T>::unpack(ro, o); V8<T>::unpack(rA, ua); V8<T>::unpack(rB, ub);
+      if (g.dscale != 1.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = V8<T>::round(v[j] * g.dscale);
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (hr && !(o[j] > 0.f)) v[j] = 0.f;
       if (e) V8<T>::store(e + p * g.lde + c0, v);
@@ -357,26 +399,6 @@ int join_geometry(JoinArgs& g, int* threads, int* grid) {
 }
 
 // ------------------------------------------------------------------------------------------ dropout
-__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  uint32_t c[4] = {c0, c1, 0u, 0u};
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    const uint32_t n3 = (uint32_t)p0;
-    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
-}
-
-__global__ void dropout_tick_kernel(unsigned long long* counter, unsigned long long* slot) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) { *slot = *counter; *counter += 1ull; }
-}
-
 // y = x * keep / (1 - p); the same kernel serves backward (x := grad).  One Philox call per 4 elements,
 // keyed by (seed slot, logical element index / 4) so the mask is independent of the launch geometry.
 template <typename T>
@@ -560,13 +582,16 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
 
 int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, const float* ba,
                  const void* b, long ldb, const float* mb, const float* sb, const float* bb,
-                 void* out, long ldo, int relu, long P, int C, int dtype, void* stream) {
+                 void* out, long ldo, int relu, float drop_p, const unsigned long long* seed_slot,
+                 long P, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lda % 8) == 0 && lda >= C && (ldo % 8) == 0 && ldo >= C && (!b || ((ldb % 8) == 0 && ldb >= C)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!seed_slot || (relu && drop_p > 0.f && drop_p < 1.f), TSS_ERR_SHAPE);   // the backward relies on out > 0 <=> kept
   TSS_REQUIRE(tss::aligned16(a) && tss::aligned16(out) && tss::aligned16(b), TSS_ERR_ALIGN);
   JoinArgs g = {};
   g.a = a; g.lda = lda; g.ma = ma; g.sa = sa; g.ba = ba; g.b = b; g.ldb = ldb; g.mb = mb; g.sb = sb; g.bb = bb;
   g.out = out; g.ldo = ldo; g.relu = relu; g.P = P; g.C = C;
+  g.drop_p = seed_slot ? drop_p : 0.f; g.seed_slot = seed_slot; g.dscale = 1.f;
   int threads, grid;
   const int rc = join_geometry(g, &threads, &grid);
   if (rc) return rc;
@@ -580,16 +605,17 @@ int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, cons
 int tss_join_bwd(const void* dout, long lddo, const void* out, long ldo, int relu,
                  const void* a_raw, long lda, const float* mean_a, double* stats_a,
                  const void* b_raw, long ldb, const float* mean_b, double* stats_b,
-                 void* e, long lde, long P, int C, int dtype, void* stream) {
+                 void* e, long lde, float dout_scale, long P, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lddo % 8) == 0 && lddo >= C && (!relu || (out && (ldo % 8) == 0 && ldo >= C)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(dout_scale > 0.f && (dout_scale == 1.f || relu), TSS_ERR_SHAPE);
   TSS_REQUIRE((!stats_a || (a_raw && (lda % 8) == 0 && lda >= C)) && (!stats_b || (b_raw && (ldb % 8) == 0 && ldb >= C)), TSS_ERR_SHAPE);
   TSS_REQUIRE(!e || ((lde % 8) == 0 && lde >= C), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(dout) && tss::aligned16(e), TSS_ERR_ALIGN);
   JoinArgs g = {};
   g.dout = dout; g.lddo = lddo; g.out = const_cast<void*>(out); g.ldo = ldo; g.relu = relu;
   g.a = a_raw; g.lda = lda; g.ma = mean_a; g.stats_a = stats_a; g.b = b_raw; g.ldb = ldb; g.mb = mean_b; g.stats_b = stats_b;
-  g.e = e; g.lde = lde; g.P = P; g.C = C;
+  g.e = e; g.lde = lde; g.P = P; g.C = C; g.dscale = dout_scale;
   int threads, grid;
   const int rc = join_geometry(g, &threads, &grid);
   if (rc) return rc;

@@ -80,7 +80,10 @@ class FusedSequential(nn.Sequential):
             elif isinstance(m, nn.Dropout):
                 _leaf_guard(m)
                 if m.training and m.p > 0:
-                    d = Deferred(ops.dropout(ops.materialize(d), m.p, True))
+                    if isinstance(d, Deferred) and d.relu and 0 < m.p < 1 and ops.fuse_dropout:
+                        d = Deferred(ops.join(d, None, True, dropout_p=m.p))   # BN + ReLU + dropout in one pass
+                    else:
+                        d = Deferred(ops.dropout(ops.materialize(d), m.p, True))
                 i += 1
             elif isinstance(m, nn.UpsamplingBilinear2d):
                 _leaf_guard(m)

@@ -605,14 +605,18 @@ class ConvUnitFn(Function):
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
 
 class JoinCfg:
-    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus')
+    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus', 'drop_p')
 
 
-def join(a, b=None, relu=False):
-    """relu?(bn_a(a) + bn_b(b)) -> ordinary NHWC tensor.  a, b: Deferred (without pending ReLU) or tensors."""
+def join(a, b=None, relu=False, dropout_p=0.0):
+    """relu?(bn_a(a) + bn_b(b)) -> ordinary NHWC tensor.  a, b: Deferred (without pending ReLU) or tensors.
+    dropout_p > 0 (ReLU joins only): nn.Dropout applied in the same pass, forward and backward."""
     a = as_deferred(a).take()
     cfg = JoinCfg()
     cfg.relu = bool(relu)
+    cfg.drop_p = float(dropout_p)
+    if cfg.drop_p and not (relu and 0.0 < cfg.drop_p < 1.0):
+        raise RuntimeError('join: dropout can only be folded into a ReLU join, 0 < p < 1')
     if a.relu and (b is not None or not relu):
         raise RuntimeError('join: a pending ReLU can only be folded into a single-input relu join')
     cfg.a_link = a.link
@@ -633,8 +637,12 @@ class JoinFn(Function):
     def forward(ctx, a, b, cfg):
         out = new_nhwc(*a.shape, a.dtype, a.device)
         al, bl = cfg.a_link, cfg.b_link
+        slot = None
+        if cfg.drop_p:
+            slot = torch.empty(1, dtype=torch.int64, device=a.device)
+            call('tss_dropout_tick', ptr(_dropout_counter(a.device)), ptr(slot), stream())
         call('tss_join_fwd', ptr(a), ld(a), *_aff(al), ptr(b), ld(b) if b is not None else 0, *_aff(bl),
-             ptr(out), ld(out), int(cfg.relu), npix(a), a.shape[1], N.dtype_code(a.dtype), stream())
+             ptr(out), ld(out), int(cfg.relu), cfg.drop_p, ptr(slot), npix(a), a.shape[1], N.dtype_code(a.dtype), stream())
         ctx.cfg = cfg
         ctx.has_b = b is not None
         ctx.save_for_backward(a if al is not None else None, b if bl is not None else None,
@@ -652,8 +660,8 @@ class JoinFn(Function):
             call('tss_join_bwd', ptr(dout), ld(dout), ptr(out), ld(out) if out is not None else 0, int(cfg.relu),
                  ptr(a), ld(a) if a is not None else 0, ptr(al.mean) if al else None, ptr(al.bstats) if al else None,
                  ptr(b), ld(b) if b is not None else 0, ptr(bl.mean) if bl else None, ptr(bl.bstats) if bl else None,
-                 ptr(e), ld(e) if e is not None else 0, npix(dout), dout.shape[1],
-                 N.dtype_code(dout.dtype), stream())
+                 ptr(e), ld(e) if e is not None else 0, 1.0 / (1.0 - cfg.drop_p) if cfg.drop_p else 1.0,
+                 npix(dout), dout.shape[1], N.dtype_code(dout.dtype), stream())
         g = e if e is not None else dout
         return g, (g if ctx.has_b else None), None
 
@@ -874,6 +882,7 @@ class ConcatUpFn(Function):
 
 # ----------------------------------------------------------------------------- pyramid pooling, all arms per launch
 
+fuse_dropout = True    # nn.Dropout after a pending BatchNorm + ReLU rides in the join that materialises it (False: own pass)
 ppm_fused = os.environ.get('TSS_PPM_FUSED', '1') != '0'   # False: every arm through the generic operators (A/B checks)
 
 
