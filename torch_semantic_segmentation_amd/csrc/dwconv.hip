@@ -64,22 +64,35 @@ __device__ __forceinline__ void flush_stats(const A s1[8], const A s2[8], double
   }
 }
 
-// [C][9] f32 weights -> LDS [tap][C].  All global loads of a lane are issued before the first LDS store (a plain
-// load/store loop is serialised by the compiler: 20 dependent L2 round trips per block at C = 576).
+// [C][9] f32 weights -> LDS [tap][half][C/8][4]: the 8 weights of a lane's channel vector are two float4, the low halves of
+// all channel vectors contiguous, then the high halves -- consecutive lanes read consecutive 16-byte words (conflict-free
+// ds_read_b128; with [tap][C] the two float4 of a lane sat 32 bytes from its neighbour's: 2-way conflicts on every read, and
+// the transposing store hit one bank 9 times over: SQ_LDS_BANK_CONFLICT = 13 M cycles per launch).  The loop runs over
+// the LDS destination (conflict-free stores, gathered L2 reads); all loads of a lane are issued before the first store.
 __device__ __forceinline__ void stage_weights(float* wl, const float* w, int C, int tid, int nthreads) {
-  const int n = C * 9;
+  const int n = C * 9, hc = C >> 1;
   constexpr int U = 14;   // C <= 768 with >= 192 threads: at most three trips (one for C <= 384)
   for (int base = 0; base < n; base += nthreads * U) {
     float v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = base + tid + u * nthreads; v[u] = w[i < n ? i : 0]; }
+    for (int u = 0; u < U; ++u) {
+      const int d = base + tid + u * nthreads;
+      const int dd = d < n ? d : 0;
+      const int t = dd / C, r = dd - t * C;
+      const int half = r >= hc ? 1 : 0, q = r - half * hc;
+      const int c = (q >> 2) * 8 + half * 4 + (q & 3);
+      v[u] = w[c * 9 + t];
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int i = base + tid + u * nthreads;
-      if (i < n) { const int c = i / 9, t = i - c * 9; wl[t * C + c] = v[u]; }
+      const int d = base + tid + u * nthreads;
+      if (d < n) wl[d] = v[u];
     }
   }
 }
+// the two float4 of channel vector cg (= c0 / 8) for tap t
+#define TSS_DW_W0(wl, t, C, c0) (*reinterpret_cast<const float4*>((wl) + (t) * (C) + ((c0) >> 1)))
+#define TSS_DW_W1(wl, t, C, c0) (*reinterpret_cast<const float4*>((wl) + (t) * (C) + ((C) >> 1) + ((c0) >> 1)))
 
 // 8 per-channel constants of a lane: two unconditional 16-byte loads through a null-safe pointer, then a select
 // (a `ptr ? ptr[c] : dflt` per element compiles to a branch and a wait per load: a serial chain of L2 round trips at
@@ -153,8 +166,8 @@ __global__ __launch_bounds__(NT_MAX) void dw_fwd_kernel(const DwArgs g) {
     for (int t = 0; t < 9; ++t) {
       float v[8];
       V8<T>::unpack(raw[t], v);
-      const float4 w0 = *reinterpret_cast<const float4*>(wl + t * g.C + c0);
-      const float4 w1 = *reinterpret_cast<const float4*>(wl + t * g.C + c0 + 4);
+      const float4 w0 = TSS_DW_W0(wl, t, g.C, c0);
+      const float4 w1 = TSS_DW_W1(wl, t, g.C, c0);
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -245,8 +258,8 @@ __global__ __launch_bounds__(NT_MAX) void dw_bwd_data_kernel(const DwArgs g) {
     for (int t = 0; t < 9; ++t) {
       float ev[8];
       V8<T>::unpack(re[t], ev);
-      const float4 w0 = *reinterpret_cast<const float4*>(wl + t * g.C + c0);
-      const float4 w1 = *reinterpret_cast<const float4*>(wl + t * g.C + c0 + 4);
+      const float4 w0 = TSS_DW_W0(wl, t, g.C, c0);
+      const float4 w1 = TSS_DW_W1(wl, t, g.C, c0);
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
       if (yr) {
         float yv[8];
@@ -475,8 +488,8 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
       float wv[3][8];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0);
-        const float4 w1 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0 + 4);
+        const float4 w0 = TSS_DW_W0(wl, ky * 3 + kx, g.C, c0);
+        const float4 w1 = TSS_DW_W1(wl, ky * 3 + kx, g.C, c0);
         wv[kx][0] = w0.x; wv[kx][1] = w0.y; wv[kx][2] = w0.z; wv[kx][3] = w0.w;
         wv[kx][4] = w1.x; wv[kx][5] = w1.y; wv[kx][6] = w1.z; wv[kx][7] = w1.w;
       }
@@ -754,8 +767,8 @@ __global__ __launch_bounds__(NT_MAX, (WG ? WG_WAVES : (D == 1 ? 2 : 1))) void dw
       float wv[3][8];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0);
-        const float4 w1 = *reinterpret_cast<const float4*>(wl + (ky * 3 + kx) * g.C + c0 + 4);
+        const float4 w0 = TSS_DW_W0(wl, ky * 3 + kx, g.C, c0);
+        const float4 w1 = TSS_DW_W1(wl, ky * 3 + kx, g.C, c0);
         wv[kx][0] = w0.x; wv[kx][1] = w0.y; wv[kx][2] = w0.z; wv[kx][3] = w0.w;
         wv[kx][4] = w1.x; wv[kx][5] = w1.y; wv[kx][6] = w1.z; wv[kx][7] = w1.w;
       }

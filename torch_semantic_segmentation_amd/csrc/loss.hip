@@ -109,10 +109,16 @@ template <typename T, int CP>
 __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
                                                                  float* dlow, double* acc, int B, int C, int h, int w,
                                                                  int H, int W, int ignore_index, int band_rows) {
-  constexpr int MAXCELL = NT + 2;
-  __shared__ __align__(16) float G[NT * CP];          // per-lane gradients of the row being flushed
+  constexpr int MAXCELL = NT + 2, WTAB = 1024;
+  // Hh[k][lane][c]: the one-hot half of the gradient, sum over the rows seen so far of (row weight) * [target == c], kept
+  // per low-res row (k = buffer of row rA / rB).  The softmax half lives in registers (gA, gB); the two meet at flush time.
+  // The kernel is VALU-bound (SQ_ACTIVE_INST_VALU = 89 % of the SIMD cycles): a compare + select per class for the one-hot
+  // term and for the target logit was 84 of the 332 vector instructions per pixel; this way it is two LDS updates, and the
+  // target logits are recovered per low-res row as sum_c a[c] * Hh[c] (same products, summed in a different order).
+  __shared__ __align__(16) float Hh[2][NT * CP];
   __shared__ int Li0[NT], Li1[NT], Wlo[MAXCELL], Whi[MAXCELL];
   __shared__ float Ll1[NT];
+  __shared__ float Wt[WTAB];                          // gather weights [cell][lane - Wlo[cell]] (fixed for the block)
   __shared__ double red[2][NT / 64];
   const int tid = threadIdx.x;
   const int nstrip = (W + NT - 1) / NT, nband = (H + band_rows - 1) / band_rows;
@@ -132,12 +138,33 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
   Li0[tid] = xin ? tx.i0 - cx0 : -1;      // lanes past the image edge match no cell
   Li1[tid] = xin ? tx.i1 - cx0 : -1;
   Ll1[tid] = tx.l1;
+  // widest window of lanes whose taps can include one low-res column: uniform bound from the scale
+  const int maxwin = sx > 0.f ? (int)(2.f / sx) + 6 : NT;
+  const bool wtab = (long)ncell * maxwin <= WTAB;
   for (int cell = tid; cell < ncell; cell += NT) {   // lanes of this strip whose taps can include low-res column cx0 + cell
     int lo, hi;
     ac_window(sx, cx0 + cell, W, &lo, &hi);
     lo -= strip * NT; hi -= strip * NT;
-    Wlo[cell] = lo < 0 ? 0 : lo;
-    Whi[cell] = hi > NT - 1 ? NT - 1 : hi;
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > NT - 1 ? NT - 1 : hi;
+    if (wtab && hi - lo + 1 > maxwin) hi = lo + maxwin - 1;        // cannot happen (conservative bound); keeps the table safe
+    Wlo[cell] = lo;
+    Whi[cell] = hi;
+  }
+#pragma unroll
+  for (int c4 = 0; c4 < CP; c4 += 4) {
+    *reinterpret_cast<float4*>(&Hh[0][tid * CP + c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(&Hh[1][tid * CP + c4]) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  if (wtab) {
+    for (int i = tid; i < ncell * maxwin; i += NT) {
+      const int cell = i / maxwin, k = i - cell * maxwin;
+      const int l = Wlo[cell] + k;
+      float wgt = 0.f;
+      if (l <= Whi[cell]) { const float l1 = Ll1[l]; wgt = (Li0[l] == cell ? 1.f - l1 : 0.f) + (Li1[l] == cell ? l1 : 0.f); }
+      Wt[i] = wgt;
+    }
   }
 
   float aA[CP], aB[CP], gA[CP], gB[CP];
@@ -153,38 +180,55 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
       for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? tx.l0 * u[q] + tx.l1 * v[q] : -TSS_INF;
     }
   };
-  // finished low-res row r: every lane parks its g[] in LDS (plain stores), then one thread per (cell, class) gathers
-  // the <= ~2*scale+4 lanes whose column taps include that cell and adds the sum to dlow.  (LDS float atomics for the
-  // scatter were measured at ~180 cycles per wave instruction: 550 us of a 790 us kernel.)
-  auto flush_row = [&](int r, const float* g) {
+  float lsum = 0.f, lcnt = 0.f;
+  // finished low-res row r (buffer k): the lane's gradient g[] - Hh[k][] is parked in Hh[k] (plain stores), then one thread
+  // per (cell, class) gathers the <= ~2*scale+4 lanes whose column taps include that cell and adds the sum to dlow; the
+  // lane's target logits of the row leave the loss sum.  (LDS float atomics for the scatter were measured at ~180 cycles
+  // per wave instruction: 550 us of a 790 us kernel.)
+  auto flush_row = [&](int r, int k, const float* g, const float* a) {
+    float* G = Hh[k];
+    float zt = 0.f;
 #pragma unroll
-    for (int c4 = 0; c4 < CP; c4 += 4)
-      *reinterpret_cast<float4*>(G + tid * CP + c4) = make_float4(g[c4], g[c4 + 1], g[c4 + 2], g[c4 + 3]);
+    for (int c4 = 0; c4 < CP; c4 += 4) {
+      const float4 hv = *reinterpret_cast<const float4*>(G + tid * CP + c4);
+      const float hq[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) if (c4 + q < C) zt += a[c4 + q] * hq[q];     // padding classes: a = -inf, Hh = 0
+      *reinterpret_cast<float4*>(G + tid * CP + c4) = make_float4(g[c4] - hq[0], g[c4 + 1] - hq[1], g[c4 + 2] - hq[2], g[c4 + 3] - hq[3]);
+    }
+    lsum -= zt;
     __syncthreads();
     float* drow = dlow + ((b * h + r) * (long)w + cx0) * ldl;
     for (int i = tid; i < ncell * CP; i += NT) {
       const int cell = i / CP, c = i - cell * CP;
       const int llo = Wlo[cell], lhi = Whi[cell];
       float sum = 0.f;
-      for (int l = llo; l <= lhi; ++l) {
-        const float l1 = Ll1[l];
-        const float wgt = (Li0[l] == cell ? 1.f - l1 : 0.f) + (Li1[l] == cell ? l1 : 0.f);
-        sum += wgt * G[l * CP + c];
+      if (wtab) {
+        const float* wt = Wt + cell * maxwin - llo;
+        for (int l = llo; l <= lhi; ++l) sum += wt[l] * G[l * CP + c];
+      } else {
+        for (int l = llo; l <= lhi; ++l) {
+          const float l1 = Ll1[l];
+          const float wgt = (Li0[l] == cell ? 1.f - l1 : 0.f) + (Li1[l] == cell ? l1 : 0.f);
+          sum += wgt * G[l * CP + c];
+        }
       }
       if (c < C && sum != 0.f) atomicAdd(drow + (long)cell * ldl + c, sum);
     }
     __syncthreads();
+#pragma unroll
+    for (int c4 = 0; c4 < CP; c4 += 4) *reinterpret_cast<float4*>(G + tid * CP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
   int rA = ac_tap(sy, ya, h).i0;
   int rB = rA + (rA < h - 1 ? 1 : 0);
+  int kA = 0;                                  // Hh[kA] belongs to row rA, Hh[kA ^ 1] to row rB
   load_row(rA, aA);
   load_row(rB, aB);
 #pragma unroll
   for (int c = 0; c < CP; ++c) { gA[c] = 0.f; gB[c] = 0.f; }
   __syncthreads();
 
-  float lsum = 0.f, lcnt = 0.f;
   const long long* trow = target + (b * H + ya) * (long)W + (xin ? x : 0);
   long long tnext = *trow;
   for (int y = ya; y < yb; ++y) {
@@ -192,7 +236,8 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
     if (y + 1 < yb) tnext = trow[(long)(y + 1 - ya) * W];      // next row's target under this row's arithmetic
     const Tap ty = ac_tap(sy, y, h);                           // uniform over the block
     if (ty.i0 != rA) {                                         // row tap advanced (by exactly one: H >= h)
-      flush_row(rA, gA);
+      flush_row(rA, kA, gA, aA);
+      kA ^= 1;
       rA = rB;
       rB = rA + (rA < h - 1 ? 1 : 0);
 #pragma unroll
@@ -206,27 +251,33 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
       z[c] = (c < C) ? ty.l0 * aA[c] + ty.l1 * aB[c] : -TSS_INF;
       m = fmaxf(m, z[c]);
     }
-    const bool valid = xin && t != ignore_index;
-    const int ti = (t >= 0 && t < CP) ? (int)t : -1;     // 32-bit compares below
-    float ssum = 0.f, zt = 0.f;
+    const bool valid = xin && t != ignore_index && t >= 0 && t < C;
+    float ssum = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      if (ti == c) zt = z[c];
       z[c] = __expf(z[c] - m);          // e_c (0 for the padding classes)
       ssum += z[c];
     }
-    if (valid) { lsum += m + __logf(ssum) - zt; lcnt += 1.f; }
+    if (valid) {
+      lsum += m + __logf(ssum);
+      lcnt += 1.f;
+      float* ha = &Hh[kA][tid * CP + (int)t];                 // this lane's own row of the table: no race
+      float* hb = &Hh[kA ^ 1][tid * CP + (int)t];
+      *ha += ty.l0;
+      *hb += ty.l1;
+    }
     const float inv = valid ? __builtin_amdgcn_rcpf(ssum) : 0.f;
-    const float one = valid ? 1.f : 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      const float dz = z[c] * inv - (ti == c ? one : 0.f);
-      gA[c] += ty.l0 * dz;
-      gB[c] += ty.l1 * dz;
+      const float pz = z[c] * inv;
+      gA[c] += ty.l0 * pz;
+      gB[c] += ty.l1 * pz;
     }
   }
-  flush_row(rA, gA);
-  if (rB != rA) flush_row(rB, gB);
+  flush_row(rA, kA, gA, aA);
+  if (rB != rA) flush_row(rB, kA ^ 1, gB, aB);
+  else {   // the band ended on the last low-res row (rB == rA): the l1 weights are zero there, nothing to flush
+  }
 
   double ds = wave_sum((double)lsum), dc = wave_sum((double)lcnt);
   const int wave = tid >> 6;
