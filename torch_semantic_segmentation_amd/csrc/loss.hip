@@ -110,6 +110,7 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
                                                                  float* dlow, double* acc, int B, int C, int h, int w,
                                                                  int H, int W, int ignore_index, int band_rows) {
   constexpr int MAXCELL = NT + 2, WTAB = 1024;
+  constexpr float LOG2E = 1.44269504088896340736f;
   // Hh[k][lane][c]: the one-hot half of the gradient, sum over the rows seen so far of (row weight) * [target == c], kept
   // per low-res row (k = buffer of row rA / rB).  The softmax half lives in registers (gA, gB); the two meet at flush time.
   // The kernel is VALU-bound (SQ_ACTIVE_INST_VALU = 89 % of the SIMD cycles): a compare + select per class for the one-hot
@@ -177,10 +178,10 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
       V4<T>::load(p0 + c4, u);
       V4<T>::load(p1 + c4, v);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? tx.l0 * u[q] + tx.l1 * v[q] : -TSS_INF;
+      for (int q = 0; q < 4; ++q) a[c4 + q] = (c4 + q < C) ? (tx.l0 * u[q] + tx.l1 * v[q]) * LOG2E : -TSS_INF;
     }
   };
-  float lsum = 0.f, lcnt = 0.f;
+  float lsum = 0.f, lcnt = 0.f;     // loss sum in base-2 units (the rows carry logits * log2(e): one v_exp per class, no multiply)
   // finished low-res row r (buffer k): the lane's gradient g[] - Hh[k][] is parked in Hh[k] (plain stores), then one thread
   // per (cell, class) gathers the <= ~2*scale+4 lanes whose column taps include that cell and adds the sum to dlow; the
   // lane's target logits of the row leave the loss sum.  (LDS float atomics for the scatter were measured at ~180 cycles
@@ -255,11 +256,11 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
     float ssum = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
-      z[c] = __expf(z[c] - m);          // e_c (0 for the padding classes)
+      z[c] = __builtin_amdgcn_exp2f(z[c] - m);          // e_c (0 for the padding classes)
       ssum += z[c];
     }
     if (valid) {
-      lsum += m + __logf(ssum);
+      lsum += m + __builtin_amdgcn_logf(ssum);      // log2
       lcnt += 1.f;
       float* ha = &Hh[kA][tid * CP + (int)t];                 // this lane's own row of the table: no race
       float* hb = &Hh[kA ^ 1][tid * CP + (int)t];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low
   else {   // the band ended on the last low-res row (rB == rA): the l1 weights are zero there, nothing to flush
   }
 
-  double ds = wave_sum((double)lsum), dc = wave_sum((double)lcnt);
+  double ds = wave_sum((double)lsum * 0.69314718055994530942), dc = wave_sum((double)lcnt);   // back to nats
   const int wave = tid >> 6;
   if ((tid & 63) == 0) { red[0][wave] = ds; red[1][wave] = dc; }
   __syncthreads();
