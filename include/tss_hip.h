@@ -121,6 +121,10 @@ int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int Hin, int Win, int Cin, int N, int stride, int dil,
                            int dtype, void* stream);
+/* bf16 unfold for the dense 3x3 weight gradient: col[p][c*9 + tap] = act(x[p + off(tap)][c]) (0 outside the image), stride 1,
+ * padding = dilation.  dW ([N][Cin][3][3]) is then tss_pwconv_bwd_weight(e, ..., x = col, ldx = 9*Cin, no affine, K = 9*Cin). */
+int tss_im2col3x3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                  void* col, int B, int H, int W, int C, int dil, int dtype, void* stream);
 
 /* ---- stem: 3x3 stride-s conv on the NCHW image (Cin*9 <= 64), NHWC output ----------------------------
  * replaces: nn.Conv2d(in_channels,32,3,stride=2,padding=1) TSS/models/fastscnn.py:30, TSS/models/contextnet.py:38,48. */

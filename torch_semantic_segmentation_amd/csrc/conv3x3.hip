@@ -302,6 +302,37 @@ __global__ __launch_bounds__(256) void permute_w3x3_bf16_kernel(const float* w, 
   }
 }
 
+// Weight gradient of the dense 3x3: the activated input is unfolded once into [P][Cin*9] bf16 with column c*9 + tap
+// (zero where the tap leaves the image), which makes dW[n][c][tap] = sum_p g[p][n] * col[p][c*9 + tap] a plain pointwise
+// weight gradient with K = 9*Cin whose output layout IS torch's [N][Cin][3][3] -- the pipelined MFMA kernel of wgrad.hip
+// does the rest (general tap loop: 228 us on the 8x128x32x64 map; unfold 37 MB + wgfast: see profiles/README.md).
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* x, long ldx, const float* mean, const float* scale,
+                                                        const float* bias, int relu, T* col, int B, int H, int W, int C, int dil) {
+  const long total = (long)B * H * W * C;
+  const float lo = relu ? 0.f : -TSS_INF;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const long pix = p;
+    const int xx = (int)(p % W); p /= W;
+    const int yy = (int)(p % H);
+    const long b = p / H;
+    const float mu = scale ? mean[c] : 0.f, sc = scale ? scale[c] : 1.f, be = scale ? bias[c] : 0.f;
+    T v[9];
+    bool ok[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {           // nine independent 2-byte loads (lanes run along the channels: coalesced)
+      const int iy = yy + (t / 3 - 1) * dil, ix = xx + (t % 3 - 1) * dil;
+      ok[t] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const long q = ok[t] ? (b * H + iy) * (long)W + ix : pix;
+      v[t] = x[q * ldx + c];
+    }
+    T* dst = col + pix * ((long)C * 9) + (long)c * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dst[t] = ok[t] ? (T)fmaxf(((float)v[t] - mu) * sc + be, lo) : (T)0.f;
+  }
+}
+
 template <bool BWD>
 void launch_lean(const C3Args& g, hipStream_t stream) {
   static bool attr = false;
@@ -352,6 +383,20 @@ bool tss_conv3x3_lean_bwd_data(const void* e, long lde, const void* yraw, long l
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   launch_lean<true>(g, stream);
   return true;
+}
+
+extern "C" int tss_im2col3x3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                              void* col, int B, int H, int W, int C, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && ldx >= C && dil >= 1 && x && col, TSS_ERR_SHAPE);
+  TSS_REQUIRE((in_mean != nullptr) == (in_scale != nullptr) && (in_bias != nullptr) == (in_scale != nullptr), TSS_ERR_SHAPE);
+  const long total = (long)B * H * W * C;
+  if (total == 0) return TSS_OK;
+  long grid = (total + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, in_mean, in_scale,
+                     in_bias, in_relu, (T*)col, B, H, W, C, dil);
+  return tss::check_last("im2col3x3");
 }
 
 extern "C" int tss_permute_w3x3_bf16(const float* w, void* w_tnc, void* w_tcn, int N, int Cin, void* stream) {

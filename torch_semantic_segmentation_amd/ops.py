@@ -564,6 +564,16 @@ class ConvUnitFn(Function):
                 fused_dw = bool(defer and fuse_dw_backward and N.lib().tss_dwconv3x3_bwd_fused_supported(Cout, s, d, dt))
                 if not fused_dw:
                     call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
+            elif (e.dtype == torch.bfloat16 and s == 1 and y is not None and (Cin * 9) % 8 == 0 and Cout % 8 == 0
+                  and not N.fast_paths_disabled()):
+                # unfold once (bf16 [P][Cin*9], column c*9 + tap), then the pointwise MFMA weight-gradient kernel with
+                # K = 9*Cin writes torch's [N][Cin][3][3] layout directly
+                col = torch.empty((P, Cin * 9), dtype=torch.bfloat16, device=dev)
+                call('tss_im2col3x3', *xargs, ptr(col), B, Hin, Win, Cin, d, dt, wst)
+                nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin * 9, Cout, dt)
+                ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+                call('tss_pwconv_bwd_weight', *gargs, ptr(col), Cin * 9, None, None, None, 0, ptr(dw), ptr(ws), 0,
+                     P, Cin * 9, Cout, dt, wst)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
             if need_dx:
