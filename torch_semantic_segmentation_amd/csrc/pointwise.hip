@@ -18,7 +18,7 @@ constexpr int NT = 256;
 // x 88 launches per step; 32 channels per block: 6.4 us -- each block still streamed 262 KB through ONE CU, and a layer
 // has only C/32 = 2..24 such blocks; 8 channels per block: 65 KB per block, four times as many CUs pulling: 5.35 us
 // (4 channels per block, 32-byte segments: 6.5 us).
-constexpr int FIN_CH = 8, FIN_RG = 4, FIN_WAVES = 16, FIN_NT = FIN_WAVES * 64;
+constexpr int FIN_CH = 8, FIN_RG = 4, FIN_WAVES = 4, FIN_NT = FIN_WAVES * 64;
 static_assert(2 * FIN_CH * FIN_RG == 64, "one wave = row groups x 2 columns x channels");
 __device__ __forceinline__ void slab_sum(const double* slabs, int C, double* s0, double* s1, int* c_out) {
   __shared__ double red[FIN_WAVES][64];
