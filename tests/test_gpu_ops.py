@@ -247,6 +247,47 @@ def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
     assert rel(d_ws, ref) < 5e-3
 
 
+@pytest.mark.parametrize('K,Nn,P', [(384, 64, 40000), (576, 96, 16384), (768, 128, 30000), (64, 384, 40000), (96, 576, 16384),
+                                    (128, 768, 30000), (128, 128, 70001)])
+def test_pointwise_lean_kernels_every_tile_size_vs_general_kernels(K, Nn, P):
+    """tss_pwconv_fwd / tss_pwconv_bwd_data through the C ABI at sizes that select each tile variant of the lean bf16 kernels
+    (single-chunk 128 / 64-pixel tiles; multi-chunk 128, 64 and 32-pixel tiles; ragged last tile) against the general
+    kernels on the same operands: outputs within bf16 rounding of intermediates, statistics sums to 1e-3."""
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(K + Nn)
+    S = N.stat_slabs()
+    x = torch.randn(P, K, device=DEV).bfloat16()
+    w = torch.randn(Nn, K, device=DEV) * (1.0 / K ** 0.5)
+    e = torch.randn(P, Nn, device=DEV).bfloat16()
+    mK, sK, bK = torch.randn(K, device=DEV) * 0.1, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    ga, gb = torch.rand(Nn, device=DEV) + 0.5, torch.randn(Nn, device=DEV) * 0.05
+    gce, gmu = torch.randn(Nn, device=DEV) * 0.01, torch.randn(Nn, device=DEV) * 0.1
+    st = N.stream()
+
+    def run(disable):
+        N.call('tss_set_option', 1, int(disable))
+        try:
+            y = torch.empty(P, Nn, device=DEV, dtype=torch.bfloat16)
+            stats = torch.empty(S, 2 * Nn, dtype=torch.float64, device=DEV)
+            N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(bK), 1, N.ptr(w), None, None, N.ptr(y), Nn,
+                   N.ptr(stats), P, K, Nn, 1, st)
+            ein = torch.empty(P, K, device=DEV, dtype=torch.bfloat16)
+            bst = torch.empty(S, 2 * K, dtype=torch.float64, device=DEV)
+            N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), None,
+                   N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(bK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st)
+            torch.cuda.synchronize()
+        finally:
+            N.call('tss_set_option', 1, 0)
+        return y.float(), stats.sum(0), ein.float(), bst.sum(0)
+    y1, s1, e1, b1 = run(False)
+    y0, s0, e0, b0 = run(True)
+
+    def l2(a, b):
+        return float((a - b).double().norm() / b.double().norm().clamp_min(1e-30))
+    assert l2(y1, y0) < 1e-2 and l2(e1, e0) < 2e-2
+    assert l2(s1, s0) < 2e-3 and l2(b1, b0) < 5e-3
+
+
 def test_trainer_static_batch_skips_the_staging_copy_and_checks_shapes():
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import engine as E
