@@ -71,6 +71,42 @@ def test_block_matches_reference(golden, name, mode):
                 assert int(b) == 1
 
 
+@pytest.mark.parametrize('name', ['fast_dw_s1', 'fast_dw_s2', 'fast_dw_d4', 'fast_ds_s1', 'fast_bneck_res', 'fast_bneck_s2',
+                                  'ctx_dense3x3', 'fast_pw_act'])
+def test_block_matches_cpu_oracle_at_a_size_with_many_tiles_per_block(name):
+    """The golden fixtures are 8 x 16 maps: one tile per block everywhere.  Same blocks, same closed-form weights, at
+    4 x C x 96 x 160 (persistent blocks sweep several tiles, ragged last tiles, several slab rows per block) against the CPU
+    oracle run here: forward, dX, dW within the north-star's 1e-3 (train mode, f32)."""
+    import torch_semantic_segmentation_amd as tssa
+    from oracle.recipe import lattice_input
+    C = cases.BLOCK_SHAPES[name][0][1]
+    shape = (4, C, 96, 160)
+    x0 = lattice_input(*shape)
+    ref = cases.oracle_block(name)
+    ref.load_state_dict(formula_state(ref), strict=True)
+    cases.zero_dropout(ref)
+    ref.train()
+    xr = x0.clone().requires_grad_(True)
+    outr = ref(xr)
+    cot = cases.block_cotangent(outr.shape)
+    outr.backward(cot)
+    m = cases.product_block(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_dropout(m)
+    m.train().to(DEV)
+    tssa.set_compute_dtype(m, torch.float32)
+    x = x0.clone().to(DEV).requires_grad_(True)
+    out = m(x)
+    out.backward(cot.to(DEV))
+    assert close(out.detach().cpu().numpy(), outr.detach().numpy()), 'forward'
+    assert close(x.grad.cpu().numpy(), xr.grad.numpy(), floor=5e-4), 'dx'
+    for (pn, p), (rn, r) in zip(m.named_parameters(), ref.named_parameters()):
+        assert p.shape == r.shape, (pn, rn)
+        # sums over 61 k pixels in f32; a BatchNorm bias that feeds another BatchNorm has an analytically zero gradient
+        # whose computed value is summation noise of that size on BOTH sides (the CPU's is the larger one)
+        assert close(p.grad.cpu().numpy(), r.grad.numpy(), rel=2e-3, floor=3e-2), pn
+
+
 @pytest.mark.parametrize('name', ['fast_bneck_res', 'fast_ds_s2', 'fast_fusion', 'ctx_classifier', 'fast_stem',
                                   'ctx_dense3x3', 'fast_ppm'])
 def test_block_bf16_tracks_f32(golden, name):
