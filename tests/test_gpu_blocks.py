@@ -268,6 +268,43 @@ def test_dropout_folded_into_the_join_is_bit_identical_to_its_own_pass(dtype):
     assert (o1 != 0).any()
 
 
+@pytest.mark.parametrize('name', ['fast_bneck_res', 'fast_bneck_s2', 'fast_ds_s2', 'fast_dw_d4', 'fast_dw_s1'])
+def test_bf16_lean_kernels_agree_with_general_kernels_at_many_tiles_per_block(name):
+    """As test_bf16_lean_kernels_agree_with_general_kernels, at 4 x C x 96 x 160: the persistent loops of the lean kernels
+    (cross-tile prefetch, several tiles and slab rows per block, 256-pixel weight-gradient splits) against the general ones."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import _native as N
+    from oracle.recipe import lattice_input
+    C = cases.BLOCK_SHAPES[name][0][1]
+    x0 = lattice_input(4, C, 96, 160)
+
+    def run(disable):
+        m = cases.product_block(name)
+        m.load_state_dict(formula_state(m), strict=True)
+        cases.zero_dropout(m)
+        m.train().to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        x = x0.clone().to(DEV).to(torch.bfloat16).requires_grad_(True)
+        N.call('tss_set_option', 1, int(disable))
+        try:
+            out = m(x)
+            out.backward(cases.block_cotangent(out.shape).to(DEV).to(out.dtype))
+            torch.cuda.synchronize()
+        finally:
+            N.call('tss_set_option', 1, 0)
+        return (out.detach().float().cpu().numpy(), x.grad.float().cpu().numpy(),
+                {k: p.grad.float().cpu().numpy() for k, p in m.named_parameters()})
+
+    def l2(a, b):
+        return np.linalg.norm(a.astype(np.float64) - b) / max(np.linalg.norm(b), 1e-12)
+    o1, dx1, g1 = run(False)
+    o0, dx0, g0 = run(True)
+    assert l2(o1, o0) < 1.5e-2 and l2(dx1, dx0) < 5e-2
+    for k in g0:
+        if g0[k].ndim == 4 and np.linalg.norm(g0[k]) > 1e-2:
+            assert l2(g1[k], g0[k]) < 8e-2, k
+
+
 def test_cpu_tensors_raise():
     m = cases.product_block('fast_pw_act')
     with pytest.raises(RuntimeError, match='HIP path only'):
