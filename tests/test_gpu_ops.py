@@ -248,7 +248,7 @@ def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
 
 
 @pytest.mark.parametrize('K,Nn,P', [(384, 64, 40000), (576, 96, 16384), (768, 128, 30000), (64, 384, 40000), (96, 576, 16384),
-                                    (128, 768, 30000), (128, 128, 70001)])
+                                    (128, 768, 30000), (128, 128, 70001), (128, 128, 270000), (64, 384, 180000)])
 def test_pointwise_lean_kernels_every_tile_size_vs_general_kernels(K, Nn, P):
     """tss_pwconv_fwd / tss_pwconv_bwd_data through the C ABI at sizes that select each tile variant of the lean bf16 kernels
     (single-chunk 128 / 64-pixel tiles; multi-chunk 128, 64 and 32-pixel tiles; ragged last tile) against the general

@@ -12,6 +12,7 @@
 //   * full tiles take a path with no bounds checks at all (only the last tile of a layer is ragged);
 //   * the epilogue derives the statistics from the bits it is about to store and writes through 4 row pointers.
 // The f32 parity path, K > 128, dense 3x3 and ragged channel counts stay on convgemm_kernel.
+#include <cstdlib>
 #include "common.h"
 #include "wgreduce.h"
 
@@ -712,7 +713,8 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   const int nchunks = (g.N + NCH - 1) / NCH;
   const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
-  long cap = 64 / nchunks;
+  long cap = ((BWD ? TM == 32 : TM == 64) ? 96 : 64) / nchunks;   // the small-tile variants run 3 blocks per CU
+  if (cap > 64) cap = 64;                                          // 8 * gslots slab rows
   if (cap < 1) cap = 1;
   if (gs > cap) gs = cap;
   g.gslots = (int)gs;
@@ -750,7 +752,13 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
   if (w_bf16 && (K % 8) == 0 && tss::aligned16(w_bf16)) { g.wb = (const T*)w_bf16; g.ldwb = K; }   // rows of K contraction channels
-  if (K <= KMAX) launch_fast<false, 128>(g, stream); else launch_fast_mc<false>(g, stream);
+  if (K <= KMAX) {
+    // 64-pixel tiles (3 blocks per CU instead of 2) unless the layer is long enough to amortise the big tile: the per-tile
+    // chain of memory latencies, not bandwidth, bounds all but the longest layers (tools/pw_timing.sh, tools/ab_pw_tiles.sh)
+    static const long thr = getenv("TSS_PW_FWD_SMALL") ? atol(getenv("TSS_PW_FWD_SMALL")) : 4200;
+    const long t128 = (P + 127) / 128 * ((N + NCH - 1) / NCH);
+    if (t128 < thr) launch_fast<false, 64>(g, stream); else launch_fast<false, 128>(g, stream);
+  } else launch_fast_mc<false>(g, stream);
   return true;
 }
 
@@ -771,6 +779,10 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wb = (const T*)wT_bf16; g.ldwb = N; }   // transpose [conv K][conv N]: rows of N contraction channels
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  if (N <= KMAX) launch_fast<true, 64>(g, stream); else launch_fast_mc<true>(g, stream);
+  if (N <= KMAX) {
+    static const long thr = getenv("TSS_PW_BWD_SMALL") ? atol(getenv("TSS_PW_BWD_SMALL")) : 4200;   // 32-pixel tiles, as above
+    const long t64 = (P + 63) / 64 * ((K + NCH - 1) / NCH);
+    if (t64 < thr) launch_fast<true, 32>(g, stream); else launch_fast<true, 64>(g, stream);
+  } else launch_fast_mc<true>(g, stream);
   return true;
 }
