@@ -702,7 +702,8 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   const int nchunks = (g.N + NCH - 1) / NCH;
   // fewer than 256 block-tiles of 128 pixels: halve the tile so that every CU gets a block
   const long t128 = (g.P + BM - 1) / BM * nchunks;
-  if (t128 < 192) launch_fast_mc_tm<BWD, 32>(g, stream);
+  static const long thr32 = getenv("TSS_PW_MC_SMALL") ? atol(getenv("TSS_PW_MC_SMALL")) : 192;
+  if (t128 < thr32) launch_fast_mc_tm<BWD, 32>(g, stream);
   else if (t128 < 256) launch_fast_mc_tm<BWD, 64>(g, stream);
   else launch_fast_mc_tm<BWD, BM>(g, stream);
 }
