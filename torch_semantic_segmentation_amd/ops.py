@@ -1104,8 +1104,11 @@ class UpsampleCrossEntropyFn(Function):
         B, C, h, w = low.shape
         dev = low.device
         target = target.contiguous()
-        dacc = torch.zeros((B, h, w, ld(low)), dtype=torch.float32, device=dev)
-        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        # one zero-fill for both accumulators: [loss sum, #valid] as f64 in front (16 bytes), the f32 low-res gradient behind
+        n = B * h * w * ld(low)
+        zbuf = torch.zeros(4 + n, dtype=torch.float32, device=dev)
+        acc = zbuf[:4].view(torch.float64)
+        dacc = zbuf[4:].view(B, h, w, ld(low))
         scal = torch.empty(2, dtype=torch.float32, device=dev)
         call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(dacc), ptr(acc), ptr(scal[0:1]),
              ptr(scal[1:2]), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
