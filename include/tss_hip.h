@@ -252,13 +252,16 @@ int tss_adaptive_pool_bwd(const void* dy, long lddy, void* dx, long lddx, int B,
                           int dtype, void* stream);
 /* PyramidPoolingModule (TSS/models/fastscnn.py:101-123), the element-wise stages of ALL arms per launch (narms <= 4; the
  * pointer / size arrays are HOST arrays of narms entries):
- *   pool_fwd   : y[a] = AdaptiveAvgPool2d(bins[a])(x), NHWC [B][bins][bins][C]
+ *   pool_fwd   : y[a] = AdaptiveAvgPool2d(bins[a])(x), NHWC [B][bins][bins][C]; with few images the windows are cut into S row
+ *                slices (tss_ppm_pool_slices) whose partial sums meet in ws, combined by a second small launch
  *   pool_bwd   : dx = sum_a pool_a^T(dy[a])
  *   concat_fwd : out = cat(x, upsample(relu?(bn_a(raw[a]))) for every arm), align_corners=True, raw[a] = [B][bins][bins][ca];
  *                mean/scale/beta[a] NULL: raw[a] is already the activation
  *   concat_bwd : e[a] = relu'(.) * upsample^T(dout[:, C + a*ca : C + (a+1)*ca]) and, when bstats[a] != NULL, the slab rows
  *                (sum e, sum e*(raw - mean)) of the arm's BatchNorm backward (needs B * bins^2 <= tss_stat_slabs()) */
+int tss_ppm_pool_slices(int B, int ncells);   /* S: row slices per window pool_fwd uses when given a workspace (1: none needed) */
 int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms,
+                     float* ws /* NULL, or B * sum(bins^2) * S * C floats (partial sums, no initialisation needed) */,
                      int B, int H, int W, int C, int dtype, void* stream);
 int tss_ppm_pool_bwd(const void* const* dy, const long* lddy, const int* bins, int narms, void* dx, long lddx,
                      int B, int H, int W, int C, int dtype, void* stream);

@@ -376,12 +376,16 @@ struct PpmArgs {
   int narms, B, H, W, C, ca;
 };
 
+// S > 1 (few images: one 3 x 2048 x 4096 inference has 50 windows, the one-bin window alone 2 MB): every window is cut into S
+// row slices whose f32 partial sums go to `ws`; ppm_pool_combine_kernel adds them in slice order and divides.
 template <typename T>
-__global__ __launch_bounds__(NT) void ppm_pool_fwd_kernel(const PpmArgs g, int CV, int NPL) {
+__global__ __launch_bounds__(NT) void ppm_pool_fwd_kernel(const PpmArgs g, int CV, int NPL, int S, float* ws) {
   __shared__ float red[NT * 8];
   const int cells = g.cell0[g.narms];
-  const int cid = blockIdx.x % cells;
-  const long b = blockIdx.x / cells;
+  const int sl = blockIdx.x % S;
+  const int wid = blockIdx.x / S;
+  const int cid = wid % cells;
+  const long b = wid / cells;
   int arm = 0;
 #pragma unroll
   for (int a = 1; a < PPM_MAX; ++a) if (a < g.narms && cid >= g.cell0[a]) arm = a;
@@ -390,21 +394,22 @@ __global__ __launch_bounds__(NT) void ppm_pool_fwd_kernel(const PpmArgs g, int C
   T* y = reinterpret_cast<T*>(g.e[arm]);
   const int H = g.H, W = g.W, C = g.C;
   const int bi = cell / bins, bj = cell % bins;
-  const int y0 = pool_start(bi, H, bins), y1 = pool_end(bi, H, bins);
+  const int wy0 = pool_start(bi, H, bins), wy1 = pool_end(bi, H, bins);
   const int x0 = pool_start(bj, W, bins), x1 = pool_end(bj, W, bins);
+  const int y0 = wy0 + (int)((long)(wy1 - wy0) * sl / S), y1 = wy0 + (int)((long)(wy1 - wy0) * (sl + 1) / S);
   const int tid = threadIdx.x, cg = tid % CV, pl = tid / CV;
   const bool active = pl < NPL;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  const int ww = x1 - x0, n = (y1 - y0) * ww, nwin = (wy1 - wy0) * ww;
   if (active) {
     for (int k0 = pl; k0 < n; k0 += NPL * 8) {
       typename V8<T>::Raw raw[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int k = k0 + u * NPL;
-        const int kk = k < n ? k : pl;
+        const int kk = k < n ? k : 0;
         const int yy = y0 + kk / ww, xx = x0 + kk % ww;
         raw[u] = V8<T>::load_raw(x + ((b * H + yy) * (long)W + xx) * g.ldx + cg * 8);
       }
@@ -424,7 +429,27 @@ __global__ __launch_bounds__(NT) void ppm_pool_fwd_kernel(const PpmArgs g, int C
   for (int c = tid; c < C; c += blockDim.x) {
     float t = 0.f;
     for (int q = 0; q < NPL; ++q) t += red[q * C + c];
-    y[(b * bins * bins + cell) * g.lde[arm] + c] = (T)(t / (float)n);
+    if (S == 1) y[(b * bins * bins + cell) * g.lde[arm] + c] = (T)(t / (float)nwin);
+    else ws[((long)wid * S + sl) * C + c] = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void ppm_pool_combine_kernel(const PpmArgs g, int S, const float* ws) {
+  const int cells = g.cell0[g.narms];
+  const int wid = blockIdx.x, cid = wid % cells;
+  const long b = wid / cells;
+  int arm = 0;
+#pragma unroll
+  for (int a = 1; a < PPM_MAX; ++a) if (a < g.narms && cid >= g.cell0[a]) arm = a;
+  const int bins = g.bins[arm], cell = cid - g.cell0[arm];
+  const int bi = cell / bins, bj = cell % bins;
+  const int nwin = (pool_end(bi, g.H, bins) - pool_start(bi, g.H, bins)) * (pool_end(bj, g.W, bins) - pool_start(bj, g.W, bins));
+  T* y = reinterpret_cast<T*>(g.e[arm]);
+  for (int c = threadIdx.x; c < g.C; c += blockDim.x) {
+    float t = 0.f;
+    for (int q = 0; q < S; ++q) t += ws[((long)wid * S + q) * g.C + c];
+    y[(b * bins * bins + cell) * g.lde[arm] + c] = (T)(t / (float)nwin);
   }
 }
 
@@ -794,7 +819,14 @@ int ppm_fill(PpmArgs& g, int narms, const int* bins, int B, int H, int W, int C,
 }
 }  // namespace
 
-int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms,
+int tss_ppm_pool_slices(int B, int ncells) {   // row slices per window: > 1 only when the windows alone cannot fill the chip
+  const long w = (long)B * ncells;
+  if (w <= 0 || w > 128) return 1;
+  long S = (1024 + w - 1) / w;
+  return (int)(S > 16 ? 16 : S);
+}
+
+int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms, float* ws,
                      int B, int H, int W, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(C <= NT * 8 && (ldx % 8) == 0 && ldx >= C && tss::aligned16(x), TSS_ERR_SHAPE);
@@ -805,10 +837,15 @@ int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, c
   for (int a = 0; a < narms; ++a) { TSS_REQUIRE(y[a] && ldy[a] >= C, TSS_ERR_SHAPE); g.e[a] = y[a]; g.lde[a] = ldy[a]; }
   const int CV = C / 8, NPL = NT / CV;
   const int threads = (CV * NPL + 63) / 64 * 64;
-  const int grid = B * g.cell0[narms];
+  const int S = ws ? tss_ppm_pool_slices(B, g.cell0[narms]) : 1;   // ws: B * cells * S * C floats
+  const int grid = B * g.cell0[narms] * S;
   tss::ProfScope prof(TSS_K_POOL_FWD, (hipStream_t)stream, (double)narms * B * H * W * C * esz(dtype), 0);
-  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_pool_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL);
-  else hipLaunchKernelGGL(ppm_pool_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL);
+  if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_pool_fwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL, S, ws);
+  else hipLaunchKernelGGL(ppm_pool_fwd_kernel<float>, dim3(grid), dim3(threads), 0, (hipStream_t)stream, g, CV, NPL, S, ws);
+  if (S > 1) {
+    if (dtype == TSS_BF16) hipLaunchKernelGGL(ppm_pool_combine_kernel<bf16_t>, dim3(B * g.cell0[narms]), dim3(128), 0, (hipStream_t)stream, g, S, ws);
+    else hipLaunchKernelGGL(ppm_pool_combine_kernel<float>, dim3(B * g.cell0[narms]), dim3(128), 0, (hipStream_t)stream, g, S, ws);
+  }
   return tss::check_last("ppm_pool_fwd");
 }
 

@@ -923,7 +923,10 @@ class PoolMultiFn(Function):
     def forward(ctx, x, bins):
         B, C, H, W = x.shape
         ys = [new_nhwc(B, C, b, b, x.dtype, x.device) for b in bins]
-        call('tss_ppm_pool_fwd', ptr(x), ld(x), _hp(ys), _hl([ld(y) for y in ys]), _hi(bins), len(bins), B, H, W, C,
+        ncells = sum(b * b for b in bins)
+        S = N.lib().tss_ppm_pool_slices(B, ncells)
+        ws = torch.empty(B * ncells * S * C, dtype=torch.float32, device=x.device) if S > 1 else None
+        call('tss_ppm_pool_fwd', ptr(x), ld(x), _hp(ys), _hl([ld(y) for y in ys]), _hi(bins), len(bins), ptr(ws), B, H, W, C,
              N.dtype_code(x.dtype), stream())
         ctx.geom = (B, C, H, W, bins, x.dtype, x.device)
         return tuple(ys)
