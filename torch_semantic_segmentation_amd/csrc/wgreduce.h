@@ -3,6 +3,7 @@
 // next, these blocks ride in front of ITS grid (blockIdx < nred) -- one launch less per layer (>= 5 us each in a
 // replayed graph) and the reduction runs in the shadow of the streaming blocks.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 
 namespace tss_wg {
@@ -27,7 +28,8 @@ inline Split split_for(long P, int K, int N) {
   // CUs without a block (the 1/32-resolution layers: 160-192 blocks, each a serial chain of 8 stages at one memory
   // latency per stage, tools/wg_timing.sh): then 256 pixels per block (784 -> 681 us over the 27 launches; 128: 705 us)
   const long full = s.tiles * ((P + 511) / 512);
-  const long min_px = full < 256 ? WG_SMALL_PX : 512;
+  static const long small_full = getenv("TSS_WG_SMALL_FULL") ? atol(getenv("TSS_WG_SMALL_FULL")) : 256;   // A/B override
+  const long min_px = full < small_full ? WG_SMALL_PX : 512;
   const long min_stages = (min_px + s.pt - 1) / s.pt;
   long ns = 1024 / s.tiles;
   if (ns < 1) ns = 1;
