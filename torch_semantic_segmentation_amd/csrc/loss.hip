@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
 //   horizontally through LDS (one thread per low-res cell and class) and added to the f32 gradient (global atomics:
 //   ~650 per 8 output rows of a block, each address touched by <= 4 blocks).
 template <typename T, int CP>
-__global__ __launch_bounds__(NT, 3) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
+__global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
                                                                  float* dlow, double* acc, int B, int C, int h, int w,
                                                                  int H, int W, int ignore_index, int band_rows) {
   constexpr int MAXCELL = NT + 2, WTAB = 1024;
