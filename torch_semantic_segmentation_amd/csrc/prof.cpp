@@ -15,19 +15,19 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     {"pwconv_fwd", "pwfast_kernel<false>|pwfast_mc_kernel<false>|convgemm_kernel"},
     {"pwconv_bwd_data", "pwfast_kernel<true>|pwfast_mc_kernel<true>|convgemm_kernel"},
     {"pwconv_bwd_weight", "wgfast_kernel|wgrad_kernel"},
-    {"conv3x3_fwd", "convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
+    {"conv3x3_fwd", "conv3x3_lean_kernel<false>|convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "conv3x3_lean_kernel<true>|convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
     {"stem3x3_fwd", "stem_fwd_mfma_kernel|convgemm_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_mfma_kernel|stem_wgrad_kernel"},
     {"dwconv3x3_fwd", "dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_strip_kernel"},
     {"dwconv3x3_bwd_weight", "dw_bwd_weight_strip_kernel"},
     {"bn_finalize", "bn_finalize_kernel"}, {"bn_bwd_finalize", "bn_bwd_finalize_kernel"},
     {"join_fwd", "join_fwd_kernel"}, {"join_bwd", "join_bwd_kernel"},
     {"dropout", "dropout_kernel"}, {"bias_grad", "colsum_kernel"}, {"adamw", "adamw_kernel"},
-    {"bilinear_nhwc_fwd", "bilinear_nhwc_fwd_kernel"}, {"bilinear_nhwc_bwd_rows", "bilinear_nhwc_bwd_rows_kernel"},
+    {"bilinear_nhwc_fwd", "bilinear_nhwc_fwd_kernel|ppm_concat_fwd_kernel"}, {"bilinear_nhwc_bwd_rows", "bilinear_nhwc_bwd_rows_kernel|ppm_concat_bwd_kernel"},
     {"bilinear_nhwc_bwd_cols", "bilinear_nhwc_bwd_cols_kernel"},
     {"bilinear_planar_fwd", "bilinear_planar_fwd_kernel"},
     {"upsample_head_fwd", "upsample_head_fwd_kernel"}, {"upsample_head_bwd_rows", "upsample_head_bwd_rows_kernel"},
     {"upsample_head_bwd_cols", "upsample_head_bwd_cols_kernel"},
-    {"adaptive_pool_fwd", "adaptive_pool_fwd_kernel"}, {"adaptive_pool_bwd", "adaptive_pool_bwd_kernel"},
+    {"adaptive_pool_fwd", "adaptive_pool_fwd_kernel|ppm_pool_fwd_kernel"}, {"adaptive_pool_bwd", "adaptive_pool_bwd_kernel|ppm_pool_bwd_kernel"},
     {"copy_nhwc", "copy_nhwc_kernel"},
     {"cross_entropy_fwd", "ce_fwd_kernel"}, {"cross_entropy_bwd", "ce_bwd_kernel"}, {"argmax_confusion", "argmax_confusion_kernel"},
     {"upsample_ce_fwd", "upsample_ce_onepass_kernel"}, {"upsample_ce_bwd", "upsample_ce_scale_kernel"},
