@@ -53,7 +53,13 @@ def _worker(rank, world, port, out):
     y = torch.randint(0, 5, (8, 12, 12), generator=g)
     idx = E.shard_batch(8, world, rank)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=1e-5)
-    tr = E.Trainer(model, opt, nn.CrossEntropyLoss(), world_size=world)
+    tr = E.Trainer(model, opt, nn.CrossEntropyLoss())          # world size derived from the live process group
+    assert tr.world_size == world
+    try:
+        E.Trainer(model, opt, nn.CrossEntropyLoss(), world_size=world + 1)
+        raise AssertionError('a world_size that disagrees with torch.distributed must be refused')
+    except ValueError:
+        pass
     tr.step_async(x[idx], y[idx])
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]

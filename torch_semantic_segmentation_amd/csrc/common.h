@@ -199,6 +199,20 @@ inline int persistent_blocks(long tiles, int cap = TSS_MAX_PERSISTENT_BLOCKS) {
   return (int)((b + 7) / 8 * 8);
 }
 
+// hipFuncSetAttribute is per device: one flag per device ordinal (the call is idempotent, so a race between the forward and
+// the autograd thread is harmless)
+struct DevOnce {
+  bool done[64] = {};
+  bool first() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d = (d >= 0 && d < 64) ? d : 0;
+    if (done[d]) return false;
+    done[d] = true;
+    return true;
+  }
+};
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace tss

@@ -335,11 +335,10 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* x, long ldx, co
 
 template <bool BWD>
 void launch_lean(const C3Args& g, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
+  static tss::DevOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_lean_kernel<BWD>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
-    attr = true;
   }
   const long ntiles = (long)g.B * g.H * ((g.W + TW - 1) / TW);
   const int grid = (int)(ntiles < TSS_STAT_SLABS ? ntiles : TSS_STAT_SLABS);

@@ -449,11 +449,10 @@ template <typename T> size_t smem_bytes() {
 
 template <typename T, bool HAS_A1, int MODE>
 void launch_one(const GemmArgs& g, int grid, hipStream_t stream) {
-  static bool attr = false;  // raise the dynamic-LDS limit once per instantiation
-  if (!attr) {
+  static tss::DevOnce attr;  // raise the dynamic-LDS limit once per instantiation
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convgemm_kernel<T, HAS_A1, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<T>());
-    attr = true;
   }
   hipLaunchKernelGGL((convgemm_kernel<T, HAS_A1, MODE>), dim3(grid), dim3(NT), smem_bytes<T>(), stream, g);
 }

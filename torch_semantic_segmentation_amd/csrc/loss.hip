@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void ce_fwd_kernel(const T* logits, const long 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       l[j] = m[j] + __logf(s[j]);
-      if (t[j] != ignore_index) { lsum += (double)(l[j] - lt[j]); lcnt += 1.0; }
+      if (t[j] != ignore_index && t[j] >= 0 && t[j] < C) { lsum += (double)(l[j] - lt[j]); lcnt += 1.0; }   // same validity rule as the fused head
     }
     V8<float>::store(lse_out + b * HW + off, l);
   }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
     long long t[8];
     V8<float>::load(lse + b * HW + off, l);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { t[j] = target[b * HW + off + j]; w[j] = (t[j] != ignore_index) ? gs : 0.f; }
+    for (int j = 0; j < 8; ++j) { t[j] = target[b * HW + off + j]; w[j] = (t[j] != ignore_index && t[j] >= 0 && t[j] < C) ? gs : 0.f; }
     for (int c = 0; c < C; ++c) {
       float v[8], d[8];
       V8<T>::load(logits + (b * C + c) * HW + off, v);

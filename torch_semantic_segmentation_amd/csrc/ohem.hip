@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT) void ohem_pixel_kernel(const T* logits, const l
     for (int j = 0; j < 8; ++j) {
       l[j] = m[j] + __logf(s[j]);
       const float d = l[j] - lt[j];
-      p[j] = (t[j] != ignore_index) ? fmaxf(d, 0.f) : 0.f;     // a CE value is >= 0 (rounding may give -1e-7)
+      p[j] = (t[j] != ignore_index && t[j] >= 0 && t[j] < C) ? fmaxf(d, 0.f) : 0.f;     // a CE value is >= 0 (rounding may give -1e-7)
     }
     V8<float>::store(lse_out + b * HW + off, l);
     V8<float>::store(pix + b * HW + off, p);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void ohem_bwd_kernel(const T* logits, const lon
     for (int j = 0; j < 8; ++j) {
       t[j] = target[b * HW + off + j];
       const float sel = p[j] > cut ? wgt : (p[j] == cut ? weq : 0.f);
-      w[j] = (t[j] != ignore_index) ? sel * gs : 0.f;
+      w[j] = (t[j] != ignore_index && t[j] >= 0 && t[j] < C) ? sel * gs : 0.f;
     }
     for (int c = 0; c < C; ++c) {
       float v[8], d[8];

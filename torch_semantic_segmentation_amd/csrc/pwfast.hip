@@ -689,10 +689,9 @@ void launch_fast_mc_tm(FastArgs& g, hipStream_t stream) {
   if (gs > cap) gs = cap;
   g.gslots = (int)gs;
   const int grid = 8 * nchunks * (int)gs + g.nred8;
-  static bool attr = false;
-  if (!attr) {
+  static tss::DevOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
   }
   hipLaunchKernelGGL((pwfast_mc_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
 }
@@ -720,10 +719,9 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   if (gs > cap) gs = cap;
   g.gslots = (int)gs;
   const int grid = 8 * nchunks * (int)gs + g.nred8;
-  static bool attr = false;
-  if (!attr) {
+  static tss::DevOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr = true;
   }
   hipLaunchKernelGGL((pwfast_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
 }

@@ -587,10 +587,9 @@ void launch_fast_pt(WgradArgs& g, hipStream_t stream, bool defer_reduce) {
   const tss_wg::Split sp = tss_wg::split_for(g.P, g.KD, g.ND);
   g.nsplit = sp.nsplit;
   constexpr int smem = 2 * TN * (PT * 2 + 16);
-  static bool attr = false;
-  if (!attr) {
+  static tss::DevOnce attr;
+  if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgfast_kernel<PT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr = true;
   }
   hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(sp.tiles * g.nsplit), dim3(NT), smem, stream, g);
   if (g.ws && !defer_reduce) {

@@ -64,11 +64,49 @@ class FlatAdamW(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()
 
+    def _check_aliases(self):
+        """Every p.grad must still be its slice of flat_grad (model.zero_grad(set_to_none=True) or an optimizer-external
+        `p.grad = ...` detaches it; stepping would then silently apply zero gradients)."""
+        off = 0
+        base = self.flat_grad.data_ptr()
+        for p in self.param_groups[0]['params']:
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                raise RuntimeError('FlatAdamW: a parameter gradient no longer aliases the flat gradient buffer (was '
+                                   'model.zero_grad(set_to_none=True) called?); use optimizer.zero_grad() or reattach()')
+            off += p.numel()
+
+    def reattach(self):
+        """Point every p.grad back at its slice of the flat gradient buffer."""
+        off = 0
+        for p in self.param_groups[0]['params']:
+            k = p.numel()
+            p.grad = self.flat_grad[off:off + k].view_as(p)
+            off += k
+
+    def state_dict(self):
+        """torch.optim state_dict plus the flat moments and the device-side step counter (checkpoint / resume)."""
+        sd = super().state_dict()
+        sd['flat'] = {'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
+                      'state_vec': self.state_vec.clone()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        flat = state_dict.pop('flat', None)
+        super().load_state_dict(state_dict)
+        if flat is not None:
+            with torch.no_grad():
+                self.exp_avg.copy_(flat['exp_avg'])
+                self.exp_avg_sq.copy_(flat['exp_avg_sq'])
+                self.state_vec.copy_(flat['state_vec'])
+
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
         if not self.flat_param.is_cuda:
             raise RuntimeError('FlatAdamW runs on the HIP path only (no CPU fallback)')
+        self._check_aliases()
         self.lr_dev.fill_(float(g['lr']))
         b1, b2 = g['betas']
         N.call('tss_adamw_step', N.ptr(self.flat_param), N.ptr(self.flat_grad), N.ptr(self.exp_avg),
@@ -111,11 +149,19 @@ def allreduce_mean_(flat, world_size, group=None):
 # ----------------------------------------------------------------------------- trainer
 
 class Trainer:
-    def __init__(self, model, optimizer, loss_fn, device=None, use_graph=False, world_size=1,
+    def __init__(self, model, optimizer, loss_fn, device=None, use_graph=False, world_size=None,
                  non_blocking=True, fuse_head_loss=True):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.device = device
         self.non_blocking = non_blocking
+        # gradients are SUMMED over the ranks and scaled by 1/world_size: the factor must be the size of the group the
+        # all-reduce runs over, so it is derived from torch.distributed unless given (and checked when given)
+        live = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world_size is None:
+            world_size = live
+        elif world_size != live:
+            raise ValueError('Trainer(world_size=%d) but torch.distributed has %d rank(s): gradients would be scaled wrongly'
+                             % (world_size, live))
         self.world_size = world_size
         self.use_graph = use_graph
         self.flat = isinstance(optimizer, FlatAdamW)

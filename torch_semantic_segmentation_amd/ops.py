@@ -233,6 +233,11 @@ def _check_device(t):
     if not t.is_cuda:
         raise RuntimeError('torch_semantic_segmentation_amd runs on the MI355X HIP path only: got a %s tensor. '
                            'There is no CPU fallback (the CPU oracle lives in oracle/, for tests).' % t.device)
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        # the C ABI launches on the current device's current stream: a tensor of another device would be dereferenced there
+        raise RuntimeError('tensor lives on cuda:%d but the current device is cuda:%d; wrap the call in '
+                           'torch.cuda.device(%d) (one process per GPU is the supported layout)'
+                           % (t.device.index, torch.cuda.current_device(), t.device.index))
     N.lib()
 
 
