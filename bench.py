@@ -24,15 +24,16 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable copy rate)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_COPY_GBS = 6290.0        # ... and the measured float4 copy rate on MI355X (79 % of spec)
 MFMA_BF16_PEAK_TF = 2500.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--mode', default='train', choices=['train', 'eval'],
@@ -50,6 +51,10 @@ def parse():
                     help='also report the PCIe-inclusive rate: the batch is copied from pinned host memory every step '
                          '(never the headline value; printed to stderr)')
     ap.add_argument('--stock', action='store_true', help='also time the stock PyTorch-ROCm (MIOpen) path of the oracle modules')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the extra.contextnet14 / extra.eval_c5 legs (BASELINE configs 3 and 5; N=1, default workload only)')
+    ap.add_argument('--syncbn', action='store_true',
+                    help='convert_syncbn_model before training (cross-replica BatchNorm, SURVEY.md section 8f N1)')
     args = ap.parse_args()
     dflt = (8, 1024, 2048) if args.mode == 'train' else (1, 2048, 4096)
     args.batch, args.height, args.width = (args.batch or dflt[0], args.height or dflt[1], args.width or dflt[2])
@@ -95,18 +100,19 @@ def pmc_traffic(symbol, args):
     import glob
     import json
     if (args.model, args.batch, args.height, args.width, args.dtype) != ('fastscnn', 8, 1024, 2048, 'bf16'):
-        return None
+        return None, None
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', '*_pmc_traffic.json')))
     if not files:
-        return None
+        return None, None
     table = json.load(open(files[-1]))
+    source = 'profiles/' + os.path.basename(files[-1]) + ' (committed rocprofv3 --pmc passes of this command; not read live)'
     tot = n = 0.0       # launch-weighted mean over every kernel the entry point dispatched to
     for alt in symbol.split('|'):
         for k, v in table.items():
             if k.startswith(alt.split('<')[0]) and (('<' not in alt) or k.startswith(alt.rstrip('>'))):
                 tot += v['hbm_bytes_per_launch'] * v['launches_sampled']
                 n += v['launches_sampled']
-    return round(tot / n) if n else None
+    return (round(tot / n), source) if n else (None, None)
 
 
 def host_cores():
@@ -171,6 +177,95 @@ def stock_gpu(model_name, batch, h, w, device, steps=5):
     return batch * steps / (time.time() - t0)
 
 
+def timed_steps(step_fn, steps, device, barrier=None, chunk=10):
+    """Time EXACTLY `steps` calls of step_fn between two (barrier + synchronize) pairs; besides the wall time of the
+    whole region, HIP events on the launch stream every `chunk` steps give per-chunk times without any host sync inside
+    the region (median / min of those: SURVEY.md section 8d asks for the median of >= 50 steps)."""
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    out = None
+    for i in range(steps):
+        out = step_fn()
+        if (i + 1) % chunk == 0 or i + 1 == steps:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((ev, (i + 1)))
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per = []
+    prev_ev, prev_i = marks[0], 0
+    for ev, i in marks[1:]:
+        per.append(prev_ev.elapsed_time(ev) / (i - prev_i))
+        prev_ev, prev_i = ev, i
+    per.sort()
+    chunks = {'steps_per_chunk': chunk, 'n_chunks': len(per), 'median_ms_per_step': round(per[len(per) // 2], 4),
+              'min_ms_per_step': round(per[0], 4), 'max_ms_per_step': round(per[-1], 4)}
+    return elapsed, chunks, out
+
+
+def extra_train(model_name, batch, h, w, device, steps, warmup):
+    """One more BASELINE config in the same run (N = 1): same Trainer path as the headline, different model."""
+    from torch_semantic_segmentation_amd import engine as E
+    model, tssa = build_model(model_name)
+    model.to(device)
+    tssa.set_compute_dtype(model, torch.bfloat16)
+    opt = E.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    tr = E.Trainer(model, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=True)
+    x, y = synthetic(batch, h, w, 1234, device)
+    tr.step_async(x, y)
+    x, y = tr.static_batch(x, y)
+    for _ in range(warmup):
+        tr.step_async(x, y)
+    elapsed, chunks, loss = timed_steps(lambda: tr.step_async(x, y), steps, device)
+    ms = 1e3 * elapsed / steps
+    a = algorithmic_step_bytes(model_name, batch, h, w, 2)
+    res = {'workload': '%s train step, %d x 3 x %d x %d, bf16' % (model_name, batch, h, w), 'ms_per_step': round(ms, 3),
+           'images_per_sec': round(batch * steps / elapsed, 2), 'steps': steps, 'chunks': chunks, 'final_loss': round(float(loss), 4)}
+    if a:
+        res['step_roofline'] = roofline_block(a, ms)
+    del tr, opt, model
+    torch.cuda.empty_cache()
+    return res
+
+
+def extra_eval(model_name, h, w, device, steps, warmup):
+    """BASELINE config 5: eval-mode forward of one 3 x 2048 x 4096 image through the x8 head, HIP-graph replay."""
+    from torch_semantic_segmentation_amd import engine as E
+    model, tssa = build_model(model_name)
+    model.to(device).eval()
+    tssa.set_compute_dtype(model, torch.bfloat16)
+    x, _ = synthetic(1, h, w, 1234, device)
+    fwd = E.GraphedInference(model)
+    x = fwd.static_input(x)
+    with torch.no_grad():
+        for _ in range(max(warmup, 2)):
+            fwd(x)
+        elapsed, chunks, _ = timed_steps(lambda: fwd(x), steps, device)
+    ms = 1e3 * elapsed / steps
+    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}[model_name]
+    a = (S_ref * h * w / (8.0 * 1024 * 2048) + 19.0 * h * w) * 2
+    res = {'workload': '%s eval-mode forward incl. x8 head, 1 x 3 x %d x %d, bf16' % (model_name, h, w),
+           'ms_per_step': round(ms, 3), 'images_per_sec': round(steps / elapsed, 2), 'steps': steps, 'chunks': chunks,
+           'step_roofline': roofline_block(a, ms)}
+    del fwd, model
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_block(alg_bytes, ms):
+    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    return {'alg_bytes_per_step': round(alg_bytes), 'achieved_GBps': round(gbs, 1), 'frac_of_8TBps': round(gbs / HBM_PEAK_GBS, 4),
+            'frac_of_measured_copy': round(gbs / HBM_COPY_GBS, 4)}
+
+
 def main_eval(args):
     """SURVEY config C5 / TSS/utils/benchmark.py: eval-mode forward (running BatchNorm statistics, no dropout, no grad)
     through the x8 decoder head, HIP-graph replay, input resident in HBM."""
@@ -207,8 +302,7 @@ def main_eval(args):
                       'logits': list(out.shape)}}
     if S_ref:   # A = (sum over blocks of in + out elements + full-resolution logits) * b
         a = (S_ref * args.batch * args.height * args.width / (8.0 * 1024 * 2048) + args.batch * 19.0 * args.height * args.width) * esz
-        res['step_roofline'] = {'alg_bytes_per_step': round(a), 'achieved_GBps': round(a / (ms * 1e-3) / 1e9, 1),
-                                'frac_of_8TBps': round(a / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        res['step_roofline'] = roofline_block(a, ms)
     print(json.dumps(res))
 
 
@@ -238,6 +332,8 @@ def main():
     model.to(device)
     dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     tssa.set_compute_dtype(model, dtype)
+    if args.syncbn:
+        tssa.convert_syncbn_model(model)
     opt = E.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
     loss_fn = tssa.CrossEntropyLoss(ignore_index=255)
     x, y = synthetic(args.batch, args.height, args.width, 1234 + rank, device)
@@ -266,18 +362,8 @@ def main():
         x, y = trainer.static_batch(x, y)
     for _ in range(max(args.warmup - 1, 0)):
         loss = trainer.step_async(x, y)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step_async(x, y)
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    barrier = dist.barrier if dist.is_initialized() else None
+    elapsed, chunks, loss = timed_steps(lambda: trainer.step_async(x, y), args.steps, device, barrier=barrier)
     if dist.is_initialized():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -323,8 +409,10 @@ def main():
         total_ms = sum(s['ms'] for s in by_symbol.values())
         sym, top = max(by_symbol.items(), key=lambda kv: kv[1]['ms'])
         gbs = top['bytes'] / (top['ms'] * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(sym, args)
         roofline = {'bound': 'hbm', 'kernel': sym, 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(sym, args),
+                    'frac': round(gbs / HBM_PEAK_GBS, 4), 'frac_of_measured_copy': round(gbs / HBM_COPY_GBS, 4),
+                    'traffic': traffic, 'traffic_source': traffic_source,
                     'launches_per_step': top['launches'] // nprof,
                     'avg_launch_us': round(1e3 * top['ms'] / top['launches'], 2),
                     'alg_bytes_per_launch': round(top['bytes'] / top['launches']),
@@ -358,14 +446,23 @@ def main():
             'config': {'workload': '%s train step (zero_grad+fwd+CE(ignore 255)+bwd+AdamW), %d x 3 x %d x %d per GPU, '
                                    '19 classes, random-init weights' % (args.model, args.batch, args.height, args.width),
                        'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
-                       'hip_graph': graph_used, 'final_loss': round(final_loss, 4)},
+                       'hip_graph': graph_used, 'final_loss': round(final_loss, 4), 'syncbn': bool(args.syncbn)},
+            'timing': chunks,
         }
         if a_step:
-            out['step_roofline'] = {'alg_bytes_per_step': round(a_step), 'achieved_GBps': round(a_step / (ms * 1e-3) / 1e9, 1),
-                                    'frac_of_8TBps': round(a_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            out['step_roofline'] = roofline_block(a_step, ms)
         if roofline:
             out['roofline'] = roofline
             out['kernel_breakdown'] = breakdown
+        default_workload = (args.model, args.batch, args.height, args.width, args.dtype) == ('fastscnn', 8, 1024, 2048, 'bf16')
+        if world == 1 and default_workload and not args.no_extras:
+            # BASELINE configs 3 and 5 in the same driver-run line (never the headline value)
+            del trainer
+            torch.cuda.empty_cache()
+            n_extra = max(50, min(args.steps, 100))
+            out['extra'] = {'contextnet14': extra_train('contextnet14', 8, 1024, 2048, device, n_extra, 5),
+                            'eval_c5': extra_eval('fastscnn', 2048, 4096, device, n_extra, 5),
+                            'eval_c5_contextnet14': extra_eval('contextnet14', 2048, 4096, device, n_extra, 5)}
         if args.stock:
             out['stock_pytorch_rocm_images_per_sec'] = round(stock_gpu(args.model, args.batch, args.height, args.width, device), 2)
         if world == 1 and not args.no_cpu_baseline:

@@ -110,19 +110,36 @@ def test_block_matches_cpu_oracle_at_a_size_with_many_tiles_per_block(name):
 @pytest.mark.parametrize('name', ['fast_bneck_res', 'fast_ds_s2', 'fast_fusion', 'ctx_classifier', 'fast_stem',
                                   'ctx_dense3x3', 'fast_ppm'])
 def test_block_bf16_tracks_f32(golden, name):
-    """bf16 activations: relative L2 error against the f32 reference stays at bf16 level (no structural error)."""
+    """bf16 activations against the reference's f32 golden vectors.  The operands of this fixture are NOT bf16-representable
+    (closed-form f32 weights and inputs), so the error includes the rounding of inputs and weights; the bound is therefore
+    the yardstick rule of tests/test_gpu_lean_vs_oracle.py -- the lean kernels may be at most 2x as far from the reference
+    as the general bf16 kernels on the same case -- under absolute caps (forward 3e-2, weight gradients 1e-1 relative L2;
+    r01 had 6e-2 / 0.3 and no yardstick)."""
+    from torch_semantic_segmentation_amd import _native as N
     g = golden['train']
-    m, xs, out = run_block(name, 'train', torch.bfloat16)
 
     def l2(a, b):
         a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
         return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
-    assert out.dtype == torch.bfloat16
-    assert l2(out.detach().float().cpu().numpy(), g[name + '/out']) < 6e-2
-    for pname, p in m.named_parameters():
-        ref = g['%s/dw.%s' % (name, pname)]
-        if p.dim() == 4 and np.linalg.norm(ref) > 1e-2:
-            assert l2(p.grad.cpu().numpy(), ref) < 0.3, pname   # BN-backward cancellation amplifies bf16 rounding
+
+    def run(disable):
+        N.call('tss_set_option', 1, int(disable))
+        try:
+            m, xs, out = run_block(name, 'train', torch.bfloat16)
+        finally:
+            N.call('tss_set_option', 1, 0)
+        assert out.dtype == torch.bfloat16
+        errs = {'out': l2(out.detach().float().cpu().numpy(), g[name + '/out'])}
+        for pname, p in m.named_parameters():
+            ref = g['%s/dw.%s' % (name, pname)]
+            if p.dim() == 4 and np.linalg.norm(ref) > 1e-2:
+                errs[pname] = l2(p.grad.cpu().numpy(), ref)
+        return errs
+    lean, general = run(False), run(True)
+    print(name, {k: ('%.2e' % lean[k], '%.2e' % general[k]) for k in lean})
+    for k in lean:
+        cap = 3e-2 if k == 'out' else 1e-1
+        assert lean[k] <= min(2 * general[k] + 2e-3, cap), (k, lean[k], general[k])
 
 
 @pytest.mark.parametrize('name', ['fast_pw_act', 'fast_pw_noact', 'fast_bneck_res', 'fast_bneck_s2', 'fast_ds_s2',

@@ -1,0 +1,231 @@
+"""GPU parity at the sizes BASELINE.json names ("no -m gpu test touches a BASELINE-sized tensor").
+
+  config 1  4 x 3 x 512 x 1024 f32, seeded N(0,1) inputs, default init: FastSCNN and ContextNet14 against the CPU oracle --
+            the north_star's literal sentence ("logits within 1e-3 rel fp32, argmax masks bit-exact"), eval AND train
+            mode, plus the train-mode loss and gradients of FastSCNN (f64 oracle, conditioning-aware bound).
+  config 2/3  8 x 3 x 1024 x 2048 bf16 train step through Trainer(use_graph=True) (the benchmarked path: lean kernels,
+            fused head + loss, FlatAdamW, HIP-graph replay) against the f32 general-kernel path of the same library at
+            the same size, with the general bf16 kernels as the yardstick.
+  config 5  1 x 3 x 2048 x 4096 eval: f32 logits against the CPU oracle, fused argmax + confusion == unfused, bf16 lean
+            forward against f32 within the bf16 yardstick.
+
+The CPU oracle needs ~1-4 s per forward at these sizes (16 host threads); every case runs it once.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import nets as O
+from oracle.recipe import synthetic_batch
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _pair(name, seed=0):
+    torch.manual_seed(seed)
+    ref = O.build(name)
+    hip = cases.product_model(name)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    cases.zero_dropout(ref)
+    cases.zero_dropout(hip)
+    return ref, hip.to(DEV)
+
+
+def _argmax_check(logits_hip, logits_ref, pred_hip):
+    """argmax masks bit-exact, except where the ORACLE's own top-2 gap is below what 1e-3-relative logits can resolve."""
+    ref_arg = logits_ref.argmax(1)
+    top2 = logits_ref.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])
+    mism = pred_hip.cpu().long() != ref_arg
+    err = (logits_hip.float().cpu() - logits_ref).abs().max().item()
+    assert (gap[mism] <= 2 * err + 1e-7).all(), 'argmax differs at a pixel whose top-2 gap exceeds twice the logit error'
+    return mism.float().mean().item()
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_config1_eval_logits_and_argmax_vs_cpu_oracle(name):
+    import torch_semantic_segmentation_amd as tssa
+    ref, hip = _pair(name)
+    x, _ = synthetic_batch(4, 512, 1024)
+    ref.eval(); hip.eval()
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(DEV))
+        pred, _ = tssa.argmax_confusion(got)
+    assert tuple(got.shape) == (4, 19, 512, 1024) and got.dtype == torch.float32
+    rel = cases.rel_err(got.cpu().numpy(), want.numpy())
+    assert rel < 1e-3, rel
+    frac = _argmax_check(got, want, pred)
+    assert frac < 1e-4, frac
+    print('%s config-1 eval: logits rel err %.2e, argmax mismatch fraction %.2e' % (name, rel, frac))
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_config1_train_mode_forward_vs_cpu_oracle(name):
+    """Batch-statistics BatchNorm at config 1: logits within 1e-3 of the f32 oracle (FastSCNN) / within 3x the oracle's own
+    f32-vs-f64 distance (ContextNet: its 40-layer context branch amplifies rounding, tests/golden/make_golden.py G3c),
+    loss to 1e-4, running statistics after the step."""
+    import torch_semantic_segmentation_amd as tssa
+    ref, hip = _pair(name)
+    x, y = synthetic_batch(4, 512, 1024)
+    ref.train(); hip.train()
+    with torch.no_grad():
+        want = ref(x)
+        # the f32 run above already updated the running statistics of `ref`: a fresh copy (same seed) for the f64 run
+        torch.manual_seed(0)
+        fresh = O.build(name)
+        cases.zero_dropout(fresh)
+        fresh.double().train()
+        want64 = fresh(x.double())
+        got = hip(x.to(DEV))
+    e_ref32 = cases.rel_err(want.numpy(), want64.numpy())
+    e_hip = cases.rel_err(got.cpu().numpy(), want64.numpy())
+    print('%s config-1 train forward: |hip - f64| %.2e, |oracle f32 - f64| %.2e' % (name, e_hip, e_ref32))
+    assert e_hip <= max(1e-3, 3 * e_ref32), (e_hip, e_ref32)
+    loss_r = nn.functional.cross_entropy(want64, y, ignore_index=255).item()
+    loss_h = tssa.cross_entropy(got, y.to(DEV), ignore_index=255).item()
+    assert abs(loss_h / loss_r - 1) < 1e-4
+    for (k, b), (_, br) in zip(hip.named_buffers(), fresh.named_buffers()):
+        if k.endswith(('running_mean', 'running_var')):
+            assert cases.rel_err(b.cpu().numpy(), br.numpy()) < max(1e-3, 3 * e_ref32), k
+        elif k.endswith('num_batches_tracked'):
+            assert int(b) == 1
+
+
+def test_config1_fastscnn_train_step_gradients_vs_f64_oracle():
+    """BASELINE config 1 as a whole: forward + CE(ignore 255) + backward, f32, against the f64 oracle; the bound is 3x the
+    f32 oracle's own distance from f64 at this size (measured here, printed), floor 2e-3."""
+    import torch_semantic_segmentation_amd as tssa
+    x, y = synthetic_batch(4, 512, 1024)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(0)
+        m = O.build('fastscnn')
+        cases.zero_dropout(m)
+        m.to(dt).train()
+        loss = loss_fn(m(x.to(dt)), y)
+        loss.backward()
+        grads[dt] = (torch.cat([p.grad.flatten().double() for p in m.parameters()]), loss.item())
+    _, hip = _pair('fastscnn')
+    hip.train()
+    out = hip(x.to(DEV))
+    loss_h = tssa.cross_entropy(out, y.to(DEV), ignore_index=255)
+    loss_h.backward()
+    gh = torch.cat([p.grad.flatten().double().cpu() for p in hip.parameters()])
+    g32, g64 = grads[torch.float32][0], grads[torch.float64][0]
+    e_ref32 = ((g32 - g64).norm() / g64.norm()).item()
+    e_hip = ((gh - g64).norm() / g64.norm()).item()
+    print('config-1 FastSCNN gradients: |hip - f64| %.3e, |oracle f32 - f64| %.3e' % (e_hip, e_ref32))
+    assert abs(loss_h.item() / grads[torch.float64][1] - 1) < 1e-5
+    assert e_hip <= max(2e-3, 3 * e_ref32), (e_hip, e_ref32)
+
+
+def _flat_grads(model):
+    return torch.cat([p.grad.detach().flatten().double() for p in model.parameters()]).cpu()
+
+
+def _per_tensor_norms(model):
+    return np.array([p.grad.detach().double().norm().item() for p in model.parameters()])
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_baseline_size_bf16_train_step_through_the_graphed_trainer(name):
+    """8 x 3 x 1024 x 2048, the benchmark's exact path: Trainer(use_graph=True) + FlatAdamW + fused head/loss + lean bf16
+    kernels.  Reference at this size = the f32 general-kernel path of the library (pinned to the oracle by every 1e-3
+    test of this suite at smaller sizes); yardstick = the general bf16 kernels on the same batch."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(0)
+    base = cases.product_model(name)
+    cases.zero_dropout(base)
+    state = copy.deepcopy(base.state_dict())
+    x, y = synthetic_batch(8, 1024, 2048)
+    x, y = x.to(DEV), y.to(DEV)
+
+    def run(dtype, disable_fast, graph):
+        m = cases.product_model(name)
+        m.load_state_dict(state, strict=True)
+        cases.zero_dropout(m)
+        m.to(DEV)
+        tssa.set_compute_dtype(m, dtype)
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=graph)
+        N.call('tss_set_option', 1, int(disable_fast))
+        try:
+            loss = tr.step_async(x, y).item()
+            torch.cuda.synchronize()
+        finally:
+            N.call('tss_set_option', 1, 0)
+        nbt = [int(b) for k, b in m.named_buffers() if k.endswith('num_batches_tracked')]
+        stats = torch.cat([b.detach().flatten().double() for k, b in m.named_buffers() if k.endswith(('running_mean', 'running_var'))]).cpu()
+        res = (loss, _flat_grads(m), _per_tensor_norms(m), nbt, stats)
+        del tr, opt, m
+        torch.cuda.empty_cache()
+        return res
+    l32, g32, n32, _, s32 = run(torch.float32, True, False)
+    lgen, ggen, ngen, _, sgen = run(torch.bfloat16, True, False)
+    llean, glean, nlean, nbt, slean = run(torch.bfloat16, False, True)
+    assert all(v == 1 for v in nbt), 'num_batches_tracked must be 1 after one replayed step (warm-up runs leave no trace)'
+    assert np.isfinite(glean.numpy()).all() and (nlean > 0).all(), 'every parameter gets a finite, non-zero gradient'
+    e_gen = ((ggen - g32).norm() / g32.norm()).item()
+    e_lean = ((glean - g32).norm() / g32.norm()).item()
+    print('%s 8x3x1024x2048: loss f32 %.6f  bf16-general %.6f  bf16-lean(graph) %.6f; grad L2 err general %.3e lean %.3e'
+          % (name, l32, lgen, llean, e_gen, e_lean))
+    assert abs(llean / l32 - 1) < 1e-3 and abs(lgen / l32 - 1) < 1e-3
+    assert e_lean <= 2 * e_gen + 2e-3, (e_lean, e_gen)
+    big = n32 > 1e-3 * n32.max()          # per-parameter gradient norms, tensors that carry signal
+    rn_gen = np.abs(ngen[big] / n32[big] - 1)
+    rn_lean = np.abs(nlean[big] / n32[big] - 1)
+    print('   per-parameter |norm ratio - 1|: general max %.3e median %.3e; lean max %.3e median %.3e'
+          % (rn_gen.max(), np.median(rn_gen), rn_lean.max(), np.median(rn_lean)))
+    assert rn_lean.max() <= 2 * rn_gen.max() + 2e-2
+    assert np.median(rn_lean) <= 2 * np.median(rn_gen) + 2e-3
+    assert ((slean - s32).norm() / s32.norm()).item() <= 2 * ((sgen - s32).norm() / s32.norm()).item() + 1e-3
+
+
+def test_config5_eval_2048x4096_vs_cpu_oracle_and_fused_head():
+    """1 x 3 x 2048 x 4096 eval forward (row-sliced pyramid pooling, 1000+ tile sweeps, the x8 head on 8.4 M pixels):
+    f32 logits within 1e-3 of the CPU oracle, argmax exact outside sub-resolution ties; the fused upsample + argmax +
+    confusion operator equals argmax_confusion on the materialised logits; bf16 lean forward within the bf16 yardstick."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import _native as N
+    ref, hip = _pair('fastscnn')
+    x, y = synthetic_batch(1, 2048, 4096)
+    ref.eval(); hip.eval()
+    with torch.no_grad():
+        want = ref(x)
+        got = hip(x.to(DEV))
+        pred, cm = tssa.argmax_confusion(got, y.to(DEV), ignore_index=255)
+        low = hip.forward_lowres(x.to(DEV))
+        pred_f, cm_f = tssa.upsample_argmax_confusion(low, y.to(DEV), scale_factor=8, ignore_index=255)
+    rel = cases.rel_err(got.cpu().numpy(), want.numpy())
+    assert rel < 1e-3, rel
+    frac = _argmax_check(got, want, pred)
+    # fused head: same arithmetic order is not guaranteed -> allow flips only at unresolvable ties
+    mism = pred_f != pred
+    top2 = got.topk(2, dim=1).values
+    gap = (top2[:, 0] - top2[:, 1])
+    assert (gap[mism] < 1e-5 * got.abs().max()).all()
+    assert int(cm.sum()) == int((y != 255).sum()) == int(cm_f.sum())
+    assert (cm - cm_f).abs().sum().item() <= 2 * int(mism.sum())
+    print('config-5 f32: logits rel err %.2e, argmax mismatch vs oracle %.2e, fused-vs-unfused flips %d' % (rel, frac, int(mism.sum())))
+    with torch.no_grad():
+        errs = {}
+        for disable in (True, False):
+            tssa.set_compute_dtype(hip, torch.bfloat16)
+            N.call('tss_set_option', 1, int(disable))
+            try:
+                lb = hip.forward_lowres(x.to(DEV)).float()
+            finally:
+                N.call('tss_set_option', 1, 0)
+            errs[disable] = ((lb - low).norm() / low.norm()).item()
+        tssa.set_compute_dtype(hip, torch.float32)
+    print('config-5 bf16 low-res logits L2 err vs f32: general %.3e lean %.3e' % (errs[True], errs[False]))
+    assert errs[False] <= 2 * errs[True] + 2e-3

@@ -1,0 +1,283 @@
+"""GPU parity of the BENCHMARKED kernels: every lean bf16 kernel family (pwfast / pwfast_mc / wgfast / conv3x3_lean /
+stem MFMA / im2col weight gradient / depthwise strips) against the f64 CPU oracle -- not against the repo's own general
+kernels -- on bf16-representable inputs, weights and cotangents.
+
+What is compared.  A chain of reference units (oracle/nets.py `unit`: conv -> BatchNorm(train) -> [ReLU],
+TSS/models/fastscnn.py:164-185, TSS/models/contextnet.py:150-177) is run by the oracle in float64 on the CPU and by the
+HIP path with bf16 activations.  Inputs, conv weights and the cotangent are rounded to bf16 first, so both sides start
+from identical numbers; what is left on the HIP side is (i) the bf16 rounding of every tensor it stores (raw conv
+outputs, input gradients: 2^-9 relative per element) and (ii) its accumulation order.  (i) is inherent to the storage
+format and identical for the lean and the general kernels, which is why the bound is derived from a yardstick measured
+on the same case: the error of the GENERAL bf16 kernels (tss_set_option(TSS_OPT_DISABLE_FAST_PATHS, 1); the kernels the
+f32 golden tests pin) against the same f64 oracle.  Assertions, per tensor (relative L2):
+    err_lean <= 2 * err_general + FLOOR     and     err_lean <= CAP[kind]
+so a lean kernel that is wrong by a few percent fails even where bf16 noise is large, and a wrong-by-10 % weight
+gradient fails everywhere.  The table of measured errors is printed (pytest -s) and written to
+gpurun_out/lean_parity.txt; profiles/ keeps a copy per round.
+
+Shapes are chosen so that every template instance the dispatchers can pick is hit (tile sizes 32/64/128 of
+pwfast(_mc)_kernel forward and backward, wgfast_kernel<64>/<128>, multi-chunk contractions, ragged last tiles, several
+tiles and slab rows per block).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from oracle import nets as O
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+# relative-L2 caps per tensor kind (bf16 storage noise is ~2e-3 per stored tensor and adds up along the chain; the
+# BatchNorm backward cancels the two largest terms of a gradient, which amplifies it for dgamma/dbeta of inner layers)
+CAP = {'out': 1.2e-2, 'dx': 2.5e-2, 'dw': 2.5e-2, 'dgamma': 4e-2, 'dbeta': 4e-2, 'stat': 2e-3}
+FLOOR = 1.5e-3
+_ROWS = []
+
+
+def bf16_round_(t):
+    return t.copy_(t.to(torch.bfloat16).to(t.dtype))
+
+
+def l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def product_chain(spec):
+    """spec: list of (kind, cin, cout, kwargs) with kind in {'pw', 'dw', 'dense', 'stem'} -> one FusedSequential, so the
+    BatchNorm(+ReLU) between two units stays deferred exactly as inside the models."""
+    import importlib
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    from torch_semantic_segmentation_amd.models._fused import FusedSequential
+    blocks = []
+    for kind, cin, cout, kw in spec:
+        act = kw.get('act', True)
+        if kind == 'pw':
+            blocks.append(F.Conv2dBlock(cin, cout, kernel_size=1, use_activation=act))
+        elif kind == 'dw':
+            d = kw.get('dilation', 1)
+            blocks.append(F.DWConv2dBlock(cin, cout, kernel_size=3, padding=d, stride=kw.get('stride', 1), dilation=d,
+                                          use_activation=act))
+        else:   # dense 3x3 / stem
+            blocks.append(F.Conv2dBlock(cin, cout, kernel_size=3, padding=1, stride=kw.get('stride', 1), use_activation=act))
+    return FusedSequential(*blocks)
+
+
+def oracle_chain(spec):
+    blocks = []
+    for kind, cin, cout, kw in spec:
+        act = kw.get('act', True)
+        if kind == 'pw':
+            blocks.append(O.unit(cin, cout, 1, act=act))
+        elif kind == 'dw':
+            blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), dilation=kw.get('dilation', 1), depthwise=True, act=act))
+        else:
+            blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), act=act))
+    return nn.Sequential(*blocks)
+
+
+def run_case(spec, shape, seed=0):
+    """-> (oracle f64 results, lean results, general results), each a dict name -> numpy array."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(seed)
+    ref = oracle_chain(spec)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.Conv2d):
+                bf16_round_(m.weight)
+            if isinstance(m, nn.BatchNorm2d):     # non-trivial affine, f32 on both sides
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.3, 0.3)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(seed + 1)
+    x = bf16_round_(torch.randn(*shape, generator=g))
+    ref.double().train()
+    xr = x.double().requires_grad_(shape[1] % 8 == 0)
+    out_r = ref(xr)
+    cot = bf16_round_(torch.randn(*out_r.shape, generator=g) * 0.5 + 0.1)
+    out_r.backward(cot.double())
+
+    def collect(model, out, xg):
+        res = {'out': out.detach().double().cpu().numpy()}
+        if xg is not None:
+            res['dx'] = xg.detach().double().cpu().numpy()
+        for n, p in model.named_parameters():
+            kind = 'dw' if p.dim() == 4 else ('dgamma' if n.endswith('weight') else 'dbeta')
+            res['%s:%s' % (kind, n)] = p.grad.detach().double().cpu().numpy()
+        for n, b in model.named_buffers():
+            if n.endswith(('running_mean', 'running_var')):
+                res['stat:' + n] = b.detach().double().cpu().numpy()
+        return res
+    want = collect(ref, out_r, xr.grad)
+
+    def hip(disable_fast):
+        m = product_chain(spec)
+        m.load_state_dict(state, strict=True)
+        m.to(DEV).train()
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        is_act = shape[1] % 8 == 0
+        xh = x.to(DEV).to(torch.bfloat16 if is_act else torch.float32).requires_grad_(is_act)
+        N.call('tss_set_option', 1, int(disable_fast))
+        try:
+            out = m(xh)
+            out.backward(cot.to(DEV).to(out.dtype))
+            torch.cuda.synchronize()
+        finally:
+            N.call('tss_set_option', 1, 0)
+        assert out.dtype == torch.bfloat16
+        return collect(m, out, xh.grad)
+    return want, hip(False), hip(True)
+
+
+def check(case, want, lean, general):
+    bad = []
+    for k in want:
+        kind = k.split(':')[0]
+        if np.linalg.norm(want[k]) < 1e-6 * max(want[k].size, 1) ** 0.5:     # analytically-zero gradients: nothing to compare
+            continue
+        e_lean, e_gen = l2(lean[k], want[k]), l2(general[k], want[k])
+        bound = min(2.0 * e_gen + FLOOR, CAP[kind])
+        _ROWS.append('%-34s %-34s lean %.3e  general %.3e  bound %.3e%s' % (case, k, e_lean, e_gen, bound,
+                                                                           '' if e_lean <= bound else '  <-- FAIL'))
+        if not e_lean <= bound:
+            bad.append((k, e_lean, e_gen, bound))
+    return bad
+
+
+def teardown_module(module):
+    if not _ROWS:
+        return
+    text = '\n'.join(_ROWS)
+    print('\n' + text)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(root, 'gpurun_out', 'lean_parity.txt'), 'w') as f:
+            f.write('# relative L2 error against the f64 CPU oracle on bf16-representable operands; bound = min(2*general + %.1e, cap)\n'
+                    % FLOOR)
+            f.write(text + '\n')
+    except OSError:
+        pass
+
+
+PW = [
+    # (id, spec, input shape)            kernels the dispatchers pick for the unit(s) under test
+    # K <= 128 forward tile 64, backward-data tile 32 (contraction = conv N <= 128), wgfast<64>; ragged last tile
+    ('pw_48_96_32_small', [('pw', 48, 96, {}), ('pw', 96, 32, {'act': False})], (2, 48, 25, 39)),
+    # several tiles and slab rows per persistent block
+    ('pw_64_128_128_mid', [('pw', 64, 128, {}), ('pw', 128, 128, {})], (4, 64, 96, 160)),
+    # wgfast<128> (both chunk widths <= 64); forward tile 128 and backward tile 64 need > 4200 tiles: 540 k pixels
+    ('pw_32_48_64_long', [('pw', 32, 48, {}), ('pw', 48, 64, {})], (2, 32, 512, 528)),
+    # expand / project pair of an inverted residual: N = 384 in three chunks; K = 384 multi-chunk forward (tile 128),
+    # multi-chunk backward-data of the expand layer
+    ('pw_64_384_64_mc128', [('pw', 64, 384, {}), ('pw', 384, 64, {'act': False})], (4, 64, 96, 160)),
+    # the same pair with < 192 block-tiles (tile 32) and 192..255 (tile 64): the 1/32-resolution layers of the benchmark
+    ('pw_96_576_96_mc32', [('pw', 96, 576, {}), ('pw', 576, 96, {'act': False})], (2, 96, 32, 64)),
+    ('pw_128_768_128_mc64', [('pw', 128, 768, {}), ('pw', 768, 128, {'act': False})], (4, 128, 56, 128)),
+    # pyramid-pooling 1x1 (256 -> 128: K in two chunks) after a plain layer
+    ('pw_128_256_128', [('pw', 128, 256, {}), ('pw', 256, 128, {})], (8, 128, 32, 64)),
+]
+
+
+@pytest.mark.parametrize('case', PW, ids=[c[0] for c in PW])
+def test_pointwise_lean_kernels_vs_f64_oracle(case):
+    name, spec, shape = case
+    bad = check(name, *run_case(spec, shape))
+    assert not bad, bad
+
+
+DW = [
+    ('dw_s1_c384', [('pw', 64, 384, {}), ('dw', 384, 384, {}), ('pw', 384, 64, {'act': False})], (2, 64, 40, 72)),
+    ('dw_s2_c192', [('pw', 32, 192, {}), ('dw', 192, 192, {'stride': 2}), ('pw', 192, 48, {'act': False})], (2, 32, 48, 80)),
+    ('dw_d4_c128', [('pw', 64, 128, {'act': False}), ('dw', 128, 128, {'dilation': 4}), ('pw', 128, 128, {'act': False})], (2, 64, 40, 72)),
+    ('dw_s1_c768', [('pw', 128, 768, {}), ('dw', 768, 768, {}), ('pw', 768, 128, {'act': False})], (2, 128, 16, 40)),
+    ('dw_s2_c32_noact', [('pw', 32, 32, {}), ('dw', 32, 32, {'stride': 2, 'act': False}), ('pw', 32, 48, {})], (2, 32, 64, 96)),
+]
+
+
+@pytest.mark.parametrize('case', DW, ids=[c[0] for c in DW])
+def test_depthwise_strip_kernels_vs_f64_oracle(case):
+    name, spec, shape = case
+    bad = check(name, *run_case(spec, shape))
+    assert not bad, bad
+
+
+DENSE = [
+    # ContextNet context.7: ConvBlock(128, 128, 3) between two 1x1 units: conv3x3_lean fwd / bwd-data + im2col wgrad
+    ('dense3x3_128', [('pw', 96, 128, {}), ('dense', 128, 128, {}), ('pw', 128, 128, {'act': False})], (2, 96, 20, 70)),
+    ('dense3x3_64_32', [('pw', 32, 64, {}), ('dense', 64, 32, {}), ('pw', 32, 32, {})], (2, 32, 9, 130)),
+    # the 3 -> 32 stride-2 stem from the f32 NCHW image (MFMA forward + weight gradient), then dw + pw as in downsample
+    ('stem_dw_pw', [('stem', 3, 32, {'stride': 2}), ('dw', 32, 32, {'stride': 2, 'act': False}), ('pw', 32, 48, {})], (2, 3, 96, 160)),
+]
+
+
+@pytest.mark.parametrize('case', DENSE, ids=[c[0] for c in DENSE])
+def test_dense3x3_and_stem_lean_kernels_vs_f64_oracle(case):
+    name, spec, shape = case
+    bad = check(name, *run_case(spec, shape))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('name', ['fast_bneck_res', 'fast_bneck_s2', 'fast_ds_s2', 'fast_fusion', 'fast_classifier',
+                                  'ctx_classifier', 'fast_ppm', 'ctx_bneck_e1', 'ctx_linear_bneck'])
+def test_blocks_bf16_vs_f64_oracle_with_yardstick(name):
+    """The reference's own blocks (rows C-H, M-P) in bf16 against the f64 oracle at 4 x C x 48 x 80, same yardstick rule."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import _native as N
+    torch.manual_seed(3)
+    shapes = [(4, s[1], s[2] * (6 if len(cases.BLOCK_SHAPES[name]) == 1 else 3), s[3] * (5 if len(cases.BLOCK_SHAPES[name]) == 1 else 3))
+              for s in cases.BLOCK_SHAPES[name]]
+    ref = cases.oracle_block(name)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.Conv2d):
+                bf16_round_(m.weight)
+                if m.bias is not None:
+                    bf16_round_(m.bias)
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.3, 0.3)
+    cases.zero_dropout(ref)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    xs = [bf16_round_(torch.randn(*s, generator=g)) for s in shapes]
+    ref.double().train()
+    xr = [x.double().requires_grad_(True) for x in xs]
+    out_r = ref(*xr)
+    cot = bf16_round_(torch.randn(*out_r.shape, generator=g) * 0.5 + 0.1)
+    out_r.backward(cot.double())
+
+    def collect(model, out, xg):
+        res = {'out': out.detach().double().cpu().numpy()}
+        for i, t in enumerate(xg):
+            res['dx:%d' % i] = t.grad.detach().double().cpu().numpy()
+        for n, p in model.named_parameters():
+            kind = 'dw' if p.dim() == 4 else ('dgamma' if n.endswith('weight') else 'dbeta')
+            res['%s:%s' % (kind, n)] = p.grad.detach().double().cpu().numpy()
+        return res
+    want = collect(ref, out_r, xr)
+
+    def hip(disable):
+        m = cases.product_block(name)
+        m.load_state_dict(state, strict=True)
+        cases.zero_dropout(m)
+        m.to(DEV).train()
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        xh = [x.to(DEV).to(torch.bfloat16).requires_grad_(True) for x in xs]
+        N.call('tss_set_option', 1, int(disable))
+        try:
+            out = m(*xh)
+            out.backward(cot.to(DEV).to(out.dtype))
+            torch.cuda.synchronize()
+        finally:
+            N.call('tss_set_option', 1, 0)
+        return collect(m, out, xh)
+    bad = check(name, want, hip(False), hip(True))
+    assert not bad, bad

@@ -80,27 +80,16 @@ def test_frozen_bn_train_step_vs_reference(golden_dir, name):
 
 
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
-def test_train_mode_step_vs_reference_and_f64_oracle(golden_dir, name):
-    """Train-mode (batch-statistics BatchNorm) step.  Loss and running statistics are checked against the
-    reference's golden output.  Whole-model train-mode GRADIENTS are ill-conditioned in f32 -- the reference's own
-    f32 and f64 runs disagree by 2-130% on these networks -- so they are judged against an f64
-    run of the oracle: the HIP path must be as close to f64 as the reference's f32 run is (x8 slack: both errors are amplified rounding noise), or 2e-3."""
+def test_train_mode_step_loss_vs_reference(golden_dir, name):
+    """Train-mode (batch-statistics BatchNorm) step on the closed-form fixture G3: the loss (forward, well conditioned)
+    against the reference's golden value, and the step bookkeeping.  Gradients of THIS fixture are not compared: on
+    2 x 4 maps with the sine weights the reference's own f32 and f64 gradients differ by 90-130 %, so no bound derived
+    from it binds; they are held to the f64 reference on the well-conditioned fixture G3c below."""
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import engine as E
     g = cases.load_npz(os.path.join(golden_dir, 'train_steps.npz'))
     x = lattice_input(*cases.TRAIN_SHAPE)
     y = lattice_target(cases.TRAIN_SHAPE[0], cases.TRAIN_SHAPE[2], cases.TRAIN_SHAPE[3])
-
-    def oracle(dtype):
-        r = O.build(name)
-        r.load_state_dict(formula_state(r), strict=True)
-        cases.zero_dropout(r)
-        r.to(dtype).train()
-        nn.CrossEntropyLoss(ignore_index=255)(r(x.to(dtype)), y).backward()
-        bufs = {k: v.detach().double() for k, v in r.named_buffers() if k.endswith(('running_mean', 'running_var'))}
-        return torch.cat([p.grad.flatten() for p in r.parameters()]).double(), bufs
-    (g64, b64), (g32, b32) = oracle(torch.float64), oracle(torch.float32)
-
     m = cases.product_model(name)
     m.load_state_dict(formula_state(m), strict=True)
     cases.zero_dropout(m)
@@ -109,14 +98,61 @@ def test_train_mode_step_vs_reference_and_f64_oracle(golden_dir, name):
     trainer = E.create_segmentation_trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), DEV)
     loss = trainer.update((x, y))
     assert abs(loss / g[name + '/losses'][0] - 1) < 2e-4
-    for key, ref64 in b64.items():      # running statistics after the step, same conditioning-aware rule
-        e32 = ((b32[key] - ref64).norm() / ref64.norm()).item()
-        eh = ((m.get_buffer(key).double().cpu() - ref64).norm() / ref64.norm()).item()
-        assert eh <= max(1e-3, 8 * e32), (key, eh, e32)
-    gh = torch.cat([p.grad.flatten().cpu() for p in m.parameters()]).double()
-    err_ref32 = ((g32 - g64).norm() / g64.norm()).item()
+    assert all(int(b) == 1 for k, b in m.named_buffers() if k.endswith('num_batches_tracked'))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_train_mode_gradients_vs_f64_reference_default_init(golden_dir, name):
+    """Whole-model train-mode gradients on fixture G3c (tests/golden/make_golden.py gen_seeded): default init under
+    torch.manual_seed(0), the seeded N(0,1) batch at 2 x 3 x 96 x 160, Dropout 0.  The reference ran it in f32 and in f64;
+    err_ref32 = |g32 - g64| / |g64| is stored in the fixture (FastSCNN 1.7e-3, ContextNet14 1.2e-1: its 40-layer context
+    branch amplifies rounding noise layer by layer).  The HIP f32 path must be within 3x that of the f64 gradients
+    (floor 2e-3) -- for FastSCNN a 5e-3 bound on the full 1.1 M-element gradient.  The f64 side is the oracle run here,
+    itself checked against the fixture (same numbers as the reference to 1e-9)."""
+    import torch_semantic_segmentation_amd as tssa
+    g = cases.load_npz(os.path.join(golden_dir, 'train_seeded.npz'))
+    x, y = synthetic_batch(2, 96, 160)
+    torch.manual_seed(0)
+    ref = O.build(name)
+    hip = cases.product_model(name)
+    hip.load_state_dict(ref.state_dict(), strict=True)
+    cases.zero_dropout(ref); cases.zero_dropout(hip)
+    ref.double().train()
+    out64 = ref(x.double())
+    loss64 = nn.CrossEntropyLoss(ignore_index=255)(out64, y)
+    loss64.backward()
+    n64 = np.array([p.grad.norm().item() for p in ref.parameters()])
+    assert np.allclose(n64, g[name + '/grad_norms64'], rtol=1e-7, atol=1e-12), 'the f64 oracle run here is not the reference run'
+    assert abs(loss64.item() / float(g[name + '/loss64']) - 1) < 1e-10
+    hip.to(DEV).train()
+    out_h = hip(x.to(DEV))
+    loss_h = tssa.cross_entropy(out_h, y.to(DEV), ignore_index=255)
+    loss_h.backward()
+    err_ref32 = float(g[name + '/err_ref32'])
+    err_logits_ref32 = float(g[name + '/err_logits_ref32'])
+    err_logits = cases.rel_err(out_h.detach().cpu().numpy(), out64.detach().numpy())
+    assert err_logits <= max(1e-3, 3 * err_logits_ref32), (err_logits, err_logits_ref32)
+    assert abs(loss_h.item() / loss64.item() - 1) < max(2e-5, 3 * abs(float(g[name + '/loss32']) / float(g[name + '/loss64']) - 1))
+    g64 = torch.cat([p.grad.flatten() for p in ref.parameters()])
+    gh = torch.cat([p.grad.flatten().double().cpu() for p in hip.parameters()])
     err_hip = ((gh - g64).norm() / g64.norm()).item()
-    assert err_hip <= max(2e-3, 8 * err_ref32), (err_hip, err_ref32)
+    per_ref = g[name + '/err_ref32_per_tensor']
+    per_hip = np.array([((p.grad.double().cpu() - q.grad).norm() / q.grad.norm().clamp_min(1e-300)).item()
+                        for p, q in zip(hip.parameters(), ref.parameters())])
+    share = n64 / np.linalg.norm(n64)
+    print('%s train-mode gradients vs f64: hip %.3e, reference f32 %.3e (bound 3x); logits hip %.2e ref32 %.2e; '
+          'worst tensor ratio hip/ref32 %.2f' % (name, err_hip, err_ref32, err_logits, err_logits_ref32,
+                                                 float(np.max(per_hip[share > 1e-3] / np.maximum(per_ref[share > 1e-3], 1e-4)))))
+    assert err_hip <= max(2e-3, 3 * err_ref32), (err_hip, err_ref32)
+    # tensor by tensor (those that carry more than 0.1 % of the gradient norm): each against its own yardstick
+    heavy = share > 1e-3
+    assert (per_hip[heavy] <= np.maximum(6 * per_ref[heavy], 1e-2)).all(), \
+        [(n, a, b) for (n, _), a, b, h in zip(hip.named_parameters(), per_hip, per_ref, heavy) if h and a > max(6 * b, 1e-2)]
+    for k, b in hip.named_buffers():      # running statistics after the step, against the reference's f64 norms
+        if k.endswith(('running_mean', 'running_var')):
+            want = float(g['%s/buf_norm64.%s' % (name, k)])
+            assert abs(b.double().norm().item() / max(want, 1e-30) - 1) < max(1e-4, 3 * err_logits_ref32), k
 
 
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet12'])
@@ -146,11 +182,11 @@ def test_seeded_inputs_vs_oracle(name):
     gh = torch.cat([p.grad.flatten().cpu() for p in hip.parameters()]).double()
     err_logits_ref32 = cases.rel_err(out_r.detach().numpy(), out64.detach().numpy())
     err_logits_hip = cases.rel_err(out_h.detach().cpu().numpy(), out64.detach().numpy())
-    assert err_logits_hip <= max(1e-3, 8 * err_logits_ref32), (err_logits_hip, err_logits_ref32)
+    assert err_logits_hip <= max(1e-3, 3 * err_logits_ref32), (err_logits_hip, err_logits_ref32)
     assert abs(loss_h.item() / loss_r.item() - 1) < 1e-4
     err_ref32 = ((g32 - g64).norm() / g64.norm()).item()
     err_hip = ((gh - g64).norm() / g64.norm()).item()
-    assert err_hip <= max(2e-3, 8 * err_ref32), (err_hip, err_ref32)
+    assert err_hip <= max(2e-3, 3 * err_ref32), (err_hip, err_ref32)
 
 
 def test_flat_adamw_and_graph_replay_match_eager():

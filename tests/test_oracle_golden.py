@@ -126,3 +126,26 @@ def test_oracle_keys_equal_reference():
         a, b = ours.state_dict(), theirs.state_dict()
         assert list(a) == list(b)
         assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+
+
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_seeded_default_init_step_bit_identical(golden_dir, name):
+    """G3c: default init under torch.manual_seed(0), seeded N(0,1) batch at 2x3x96x160, one train-mode forward/backward in
+    f32 and in f64 -- the oracle reproduces the reference's losses, per-parameter gradient norms and full gradients."""
+    from oracle.recipe import synthetic_batch
+    g = cases.load_npz(os.path.join(golden_dir, 'train_seeded.npz'))
+    x, y = synthetic_batch(2, 96, 160)
+    for dt, tag in ((torch.float32, '32'), (torch.float64, '64')):
+        torch.manual_seed(0)
+        m = O.build(name)
+        cases.zero_dropout(m)
+        m.to(dt).train()
+        loss = nn.CrossEntropyLoss(ignore_index=255)(m(x.to(dt)), y)
+        loss.backward()
+        assert loss.item() == float(g['%s/loss%s' % (name, tag)])
+        norms = np.array([p.grad.double().norm().item() for p in m.parameters()])
+        assert np.array_equal(norms, g['%s/grad_norms%s' % (name, tag)])
+        if tag == '64':
+            for key in g:
+                if key.startswith(name + '/grad64.'):
+                    assert np.array_equal(m.get_parameter(key[len(name) + 8:]).grad.numpy(), g[key]), key
