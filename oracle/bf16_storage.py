@@ -1,0 +1,53 @@
+"""CPU oracle, part 3 (TEST INFRASTRUCTURE ONLY): the reference's arithmetic with the STORAGE FORMAT of the bf16 path.
+
+The HIP path with bf16 activations stores every convolution output, every block output and every gradient that
+travels between two layers as bfloat16; everything else -- BatchNorm statistics, the normalisation
+applied on load, accumulators -- is f32/f64.  Comparing it with a pure f64 run of the reference mixes two effects: the
+2^-9 rounding of stored tensors (harmless, random) and the ReLU masks that flip where a rounded pre-activation crosses
+zero (0.2-0.5 % of the elements; each flip moves a gradient element by its full magnitude, so weight gradients differ
+by 4-8 % in relative L2 although nothing is wrong).  To pin the bf16 KERNELS tightly, the oracle here runs the same
+reference modules (oracle/nets.py, which restates TSS/models/fastscnn.py and TSS/models/contextnet.py) in float64 and
+rounds exactly the tensors the HIP path stores:
+
+  * forward : the output of every nn.Conv2d, of every pooling / upsampling module and of every block that the product
+              materialises (the residual blocks, the fusion modules, the pyramid module, the root) is rounded to bf16;
+  * backward: the gradient arriving at each of those tensors is rounded to bf16 (what the backward kernels store).
+
+The masks of both sides then agree (they are computed from the same rounded pre-activations), and what is left is the
+accumulation order and the rounding of MFMA operands: ~1e-3..1e-2 relative L2 instead of 4-8e-2.
+"""
+import torch
+from torch import nn
+
+from . import nets
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def round_bf16(x):
+    return _RoundBF16.apply(x)
+
+
+_STORED = (nn.Conv2d, nn.AdaptiveAvgPool2d, nn.UpsamplingBilinear2d, nn.Upsample,
+           nets.InvertedResidual, nets.Pyramid, nets.FastFusion, nets.CtxFusion)
+
+
+def emulate_bf16_storage(module, root=True):
+    """Register forward hooks on `module` (an oracle module tree) that round the tensors the bf16 HIP path stores.
+    Returns the hook handles (call .remove() on each to undo)."""
+    handles = []
+
+    def hook(_m, _inp, out):
+        return round_bf16(out) if torch.is_tensor(out) else out
+    for m in module.modules():
+        if isinstance(m, _STORED) or (root and m is module):
+            handles.append(m.register_forward_hook(hook))
+    return handles

@@ -2,7 +2,10 @@
 stem MFMA / im2col weight gradient / depthwise strips) against the f64 CPU oracle -- not against the repo's own general
 kernels -- on bf16-representable inputs, weights and cotangents.
 
-What is compared.  A chain of reference units (oracle/nets.py `unit`: conv -> BatchNorm(train) -> [ReLU],
+What is compared.  The oracle is the reference's arithmetic in float64 WITH the storage format of the bf16 path
+(oracle/bf16_storage.py: conv outputs, block outputs and the gradients between layers are rounded to bf16, so both sides
+derive their ReLU masks from the same numbers; against a plain f64 run the masks that flip at rounded pre-activations
+alone put 4-8e-2 on every weight gradient, measured in round 2, and would hide a wrong kernel).  A chain of reference units (oracle/nets.py `unit`: conv -> BatchNorm(train) -> [ReLU],
 TSS/models/fastscnn.py:164-185, TSS/models/contextnet.py:150-177) is run by the oracle in float64 on the CPU and by the
 HIP path with bf16 activations.  Inputs, conv weights and the cotangent are rounded to bf16 first, so both sides start
 from identical numbers; what is left on the HIP side is (i) the bf16 rounding of every tensor it stores (raw conv
@@ -27,6 +30,7 @@ import torch
 from torch import nn
 
 from oracle import nets as O
+from oracle.bf16_storage import emulate_bf16_storage
 from tests import cases
 
 pytestmark = pytest.mark.gpu
@@ -34,8 +38,9 @@ DEV = 'cuda:0'
 
 # relative-L2 caps per tensor kind (bf16 storage noise is ~2e-3 per stored tensor and adds up along the chain; the
 # BatchNorm backward cancels the two largest terms of a gradient, which amplifies it for dgamma/dbeta of inner layers)
-CAP = {'out': 1.2e-2, 'dx': 2.5e-2, 'dw': 2.5e-2, 'dgamma': 4e-2, 'dbeta': 4e-2, 'stat': 2e-3}
+CAP = {'out': 1e-2, 'dx': 2e-2, 'dw': 2e-2, 'dgamma': 4e-2, 'dbeta': 4e-2, 'stat': 2e-3}
 FLOOR = 1.5e-3
+DIRECT = 1e-2       # lean against general on the same operands (relative L2): they may differ by accumulation order only
 _ROWS = []
 
 
@@ -99,6 +104,7 @@ def run_case(spec, shape, seed=0):
     g = torch.Generator().manual_seed(seed + 1)
     x = bf16_round_(torch.randn(*shape, generator=g))
     ref.double().train()
+    emulate_bf16_storage(ref)
     xr = x.double().requires_grad_(shape[1] % 8 == 0)
     out_r = ref(xr)
     cot = bf16_round_(torch.randn(*out_r.shape, generator=g) * 0.5 + 0.1)
@@ -142,12 +148,13 @@ def check(case, want, lean, general):
         kind = k.split(':')[0]
         if np.linalg.norm(want[k]) < 1e-6 * max(want[k].size, 1) ** 0.5:     # analytically-zero gradients: nothing to compare
             continue
-        e_lean, e_gen = l2(lean[k], want[k]), l2(general[k], want[k])
+        e_lean, e_gen, e_dir = l2(lean[k], want[k]), l2(general[k], want[k]), l2(lean[k], general[k])
         bound = min(2.0 * e_gen + FLOOR, CAP[kind])
-        _ROWS.append('%-34s %-34s lean %.3e  general %.3e  bound %.3e%s' % (case, k, e_lean, e_gen, bound,
-                                                                           '' if e_lean <= bound else '  <-- FAIL'))
-        if not e_lean <= bound:
-            bad.append((k, e_lean, e_gen, bound))
+        ok = e_lean <= bound and e_dir <= DIRECT
+        _ROWS.append('%-30s %-30s lean %.3e  general %.3e  bound %.3e  lean-vs-general %.3e%s'
+                     % (case, k, e_lean, e_gen, bound, e_dir, '' if ok else '  <-- FAIL'))
+        if not ok:
+            bad.append((k, e_lean, e_gen, bound, e_dir))
     return bad
 
 
@@ -249,6 +256,7 @@ def test_blocks_bf16_vs_f64_oracle_with_yardstick(name):
     g = torch.Generator().manual_seed(4)
     xs = [bf16_round_(torch.randn(*s, generator=g)) for s in shapes]
     ref.double().train()
+    emulate_bf16_storage(ref)
     xr = [x.double().requires_grad_(True) for x in xs]
     out_r = ref(*xr)
     cot = bf16_round_(torch.randn(*out_r.shape, generator=g) * 0.5 + 0.1)

@@ -151,8 +151,9 @@ def test_train_mode_gradients_vs_f64_reference_default_init(golden_dir, name):
         [(n, a, b) for (n, _), a, b, h in zip(hip.named_parameters(), per_hip, per_ref, heavy) if h and a > max(6 * b, 1e-2)]
     for k, b in hip.named_buffers():      # running statistics after the step, against the reference's f64 norms
         if k.endswith(('running_mean', 'running_var')):
+            # norms, with an absolute floor: a BatchNorm behind (zero-mean input -> linear conv) has an analytically zero mean
             want = float(g['%s/buf_norm64.%s' % (name, k)])
-            assert abs(b.double().norm().item() / max(want, 1e-30) - 1) < max(1e-4, 3 * err_logits_ref32), k
+            assert abs(b.double().norm().item() - want) < max(1e-4, 3 * err_logits_ref32) * want + 1e-6 * b.numel() ** 0.5, k
 
 
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet12'])
