@@ -11,7 +11,10 @@ rounds exactly the tensors the HIP path stores:
 
   * forward : the output of every nn.Conv2d, of every pooling / upsampling module and of every block that the product
               materialises (the residual blocks, the fusion modules, the pyramid module, the root) is rounded to bf16;
-  * backward: the gradient arriving at each of those tensors is rounded to bf16 (what the backward kernels store).
+  * forward : the INPUT of every dense convolution (1x1, 3x3, stem) is rounded to bf16 as well -- the matrix-core kernels
+              normalise their input tile and hand it to the MFMA as bf16; depthwise convolutions consume it in f32;
+  * backward: the gradient arriving at each of those tensors is rounded to bf16 (what the backward kernels store, and
+              what they feed to the MFMA).
 
 The masks of both sides then agree (they are computed from the same rounded pre-activations), and what is left is the
 accumulation order and the rounding of MFMA operands: ~1e-3..1e-2 relative L2 instead of 4-8e-2.
@@ -47,7 +50,12 @@ def emulate_bf16_storage(module, root=True):
 
     def hook(_m, _inp, out):
         return round_bf16(out) if torch.is_tensor(out) else out
+
+    def pre_hook(_m, inp):
+        return tuple(round_bf16(t) if torch.is_tensor(t) and t.is_floating_point() else t for t in inp)
     for m in module.modules():
         if isinstance(m, _STORED) or (root and m is module):
             handles.append(m.register_forward_hook(hook))
+        if isinstance(m, nn.Conv2d) and m.groups == 1:
+            handles.append(m.register_forward_pre_hook(pre_hook))
     return handles

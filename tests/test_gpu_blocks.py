@@ -113,8 +113,8 @@ def test_block_bf16_tracks_f32(golden, name):
     """bf16 activations against the reference's f32 golden vectors.  The operands of this fixture are NOT bf16-representable
     (closed-form f32 weights and inputs), so the error includes the rounding of inputs and weights; the bound is therefore
     the yardstick rule of tests/test_gpu_lean_vs_oracle.py -- the lean kernels may be at most 2x as far from the reference
-    as the general bf16 kernels on the same case -- under absolute caps (forward 3e-2, weight gradients 1e-1 relative L2;
-    r01 had 6e-2 / 0.3 and no yardstick)."""
+    as the general bf16 kernels on the same case -- under absolute caps (forward 4.5e-2, weight gradients 0.3 relative L2: 8 x 16 maps,
+    flipped ReLU masks; the tight pin of the bf16 kernels is tests/test_gpu_lean_vs_oracle.py)."""
     from torch_semantic_segmentation_amd import _native as N
     g = golden['train']
 
@@ -138,7 +138,7 @@ def test_block_bf16_tracks_f32(golden, name):
     lean, general = run(False), run(True)
     print(name, {k: ('%.2e' % lean[k], '%.2e' % general[k]) for k in lean})
     for k in lean:
-        cap = 3e-2 if k == 'out' else 1e-1
+        cap = 4.5e-2 if k == 'out' else 0.3
         assert lean[k] <= min(2 * general[k] + 2e-3, cap), (k, lean[k], general[k])
 
 

@@ -190,19 +190,19 @@ def test_baseline_size_bf16_train_step_through_the_graphed_trainer(name):
     print('%s 8x3x1024x2048: loss f32 %.6f  bf16-general %.6f  bf16-lean(graph) %.6f' % (name, l32, lgen, llean))
     assert abs(llean / l32 - 1) < 1e-3 and abs(lgen / l32 - 1) < 1e-3
     rel = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-300)).item()   # noqa: E731
-    worst = []
+    worst, bad = [], []
     for n, a32, agen, alean in zip(names, g32, ggen, glean):
-        ratio = (alean.norm() / a32.norm()).item()
-        assert 0.5 < ratio < 2.0, (n, ratio)
         if n.startswith(WELL_CONDITIONED[name]) and a32.norm() > 1e-6:
             e_gen, e_lean, e_dir = rel(agen, a32), rel(alean, a32), rel(alean, agen)
-            worst.append((e_lean, e_gen, e_dir, n))
-            assert e_lean <= min(2 * e_gen + 2e-3, CAPS[name][0]), (n, e_lean, e_gen)
-            assert e_dir <= CAPS[name][1], (n, e_dir)
+            ratio = (alean.norm() / a32.norm()).item()
+            worst.append((e_lean, e_gen, e_dir, ratio, n))
+            if not (e_lean <= min(2 * e_gen + 2e-3, CAPS[name][0]) and e_dir <= CAPS[name][1] and 0.5 < ratio < 2.0):
+                bad.append((n, e_lean, e_gen, e_dir, ratio))
     worst.sort(reverse=True)
-    print('   %d well-conditioned tensors; worst three (lean vs f32, general vs f32, lean vs general):' % len(worst))
-    for e_lean, e_gen, e_dir, n in worst[:3]:
-        print('     %-36s %.3e %.3e %.3e' % (n, e_lean, e_gen, e_dir))
+    print('   %d well-conditioned tensors (lean vs f32, general vs f32, lean vs general, norm ratio):' % len(worst))
+    for e_lean, e_gen, e_dir, ratio, n in worst:
+        print('     %-40s %.3e %.3e %.3e %.3f' % (n, e_lean, e_gen, e_dir, ratio))
+    assert not bad, bad
     assert len(worst) >= 20
     assert ((slean - s32).norm() / s32.norm()).item() <= 2 * ((sgen - s32).norm() / s32.norm()).item() + 1e-3
 

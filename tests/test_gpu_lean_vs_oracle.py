@@ -144,11 +144,20 @@ def run_case(spec, shape, seed=0):
 
 def check(case, want, lean, general):
     bad = []
+    # a BatchNorm bias in front of (linear conv -> BatchNorm) has an analytically zero gradient: whatever the three runs
+    # hold there is rounding noise.  Errors of dgamma / dbeta are therefore measured against at least 1 % of the largest
+    # gradient of the same kind in the case.
+    top = {}
     for k in want:
         kind = k.split(':')[0]
-        if np.linalg.norm(want[k]) < 1e-6 * max(want[k].size, 1) ** 0.5:     # analytically-zero gradients: nothing to compare
-            continue
-        e_lean, e_gen, e_dir = l2(lean[k], want[k]), l2(general[k], want[k]), l2(lean[k], general[k])
+        top[kind] = max(top.get(kind, 0.0), float(np.linalg.norm(want[k])) / max(want[k].size, 1) ** 0.5)
+
+    def l2f(a, b, kind):
+        den = max(np.linalg.norm(np.asarray(b, dtype=np.float64)), 1e-2 * top[kind] * max(b.size, 1) ** 0.5, 1e-30)
+        return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) / den)
+    for k in want:
+        kind = k.split(':')[0]
+        e_lean, e_gen, e_dir = l2f(lean[k], want[k], kind), l2f(general[k], want[k], kind), l2f(lean[k], general[k], kind)
         bound = min(2.0 * e_gen + FLOOR, CAP[kind])
         ok = e_lean <= bound and e_dir <= DIRECT
         _ROWS.append('%-30s %-30s lean %.3e  general %.3e  bound %.3e  lean-vs-general %.3e%s'
