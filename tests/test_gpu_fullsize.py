@@ -138,9 +138,15 @@ WELL_CONDITIONED = {'fastscnn': ('classifier.', 'fusion.', 'features.3.conv.'),
                     'contextnet14': ('classifier.', 'feature_fusion.', 'spatial.')}
 
 
-# (cap on |lean - f32|, cap on |lean - general|) for those tensors.  ContextNet's decoder sees the output of the chaotic context
-# branch in its forward pass, so even its well-conditioned gradients inherit that branch's bf16 noise: looser caps.
-CAPS = {'fastscnn': (6e-2, 2e-2), 'contextnet14': (0.5, 0.1)}
+# Even these drift apart in bf16, layer by layer going backwards (measured, round 2: last conv 2-5e-3, one block earlier
+# 5-10e-2, the fusion module 0.3-0.5; the general and the lean bf16 kernels differ from EACH OTHER by half as much): with
+# random-init weights, N(0,1) images and random targets the gradient is the sqrt(N) residual of 16.8 M cancelling pixel
+# terms, every ReLU layer flips ~0.3 % of its masks under a 2^-9 perturbation and every BatchNorm backward subtracts the
+# two dominant components.  So the absolute caps apply to the LAST layer only (TIGHT); for every tensor in the list the
+# lean kernels must be no further from f32 than twice the general bf16 kernels, with a gradient norm within 2x of f32.
+# The bf16 kernels themselves are pinned at these sizes by tests/test_gpu_lean_vs_oracle.py::test_baseline_sized_layers...
+TIGHT = {'fastscnn': ('classifier.3.', 'classifier.1.3.'), 'contextnet14': ('classifier.5.', 'classifier.3.1.')}
+CAPS = (1.5e-2, 1e-2)    # |lean - f32|, |lean - general| on the TIGHT tensors
 
 
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
@@ -148,9 +154,9 @@ def test_baseline_size_bf16_train_step_through_the_graphed_trainer(name):
     """8 x 3 x 1024 x 2048, the benchmark's exact path: Trainer(use_graph=True) + FlatAdamW + fused head/loss + lean bf16
     kernels.  Reference at this size = the f32 general-kernel path of the library (pinned to the oracle by every 1e-3
     test of this suite at smaller sizes and by the config-1 tests above); yardstick = the general bf16 kernels on the
-    same batch.  Loss to 1e-3; per-tensor gradients of the well-conditioned tensors (see WELL_CONDITIONED) within
-    2x the yardstick and under 6e-2; lean == general to 2e-2 on them; every gradient finite and non-zero with a norm
-    within 2x of f32; running statistics; num_batches_tracked == 1 after one replay."""
+    same batch.  Loss to 1e-3; per-tensor gradients of the decoder-side tensors within 2x the yardstick, the last layer's
+    under 1.5e-2 (and lean == general to 1e-2 there); every gradient finite and non-zero; running statistics;
+    num_batches_tracked == 1 after one replay."""
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import engine as E
     from torch_semantic_segmentation_amd import _native as N
@@ -196,7 +202,10 @@ def test_baseline_size_bf16_train_step_through_the_graphed_trainer(name):
             e_gen, e_lean, e_dir = rel(agen, a32), rel(alean, a32), rel(alean, agen)
             ratio = (alean.norm() / a32.norm()).item()
             worst.append((e_lean, e_gen, e_dir, ratio, n))
-            if not (e_lean <= min(2 * e_gen + 2e-3, CAPS[name][0]) and e_dir <= CAPS[name][1] and 0.5 < ratio < 2.0):
+            ok = e_lean <= 2 * e_gen + 2e-3 and 0.5 < ratio < 2.0
+            if n.startswith(TIGHT[name]):
+                ok = ok and e_lean <= CAPS[0] and e_dir <= CAPS[1]
+            if not ok:
                 bad.append((n, e_lean, e_gen, e_dir, ratio))
     worst.sort(reverse=True)
     print('   %d well-conditioned tensors (lean vs f32, general vs f32, lean vs general, norm ratio):' % len(worst))
