@@ -173,3 +173,39 @@ def test_convert_syncbn_model_keeps_modules_parameters_and_state_dict():
     assert list(model.state_dict().keys()) == keys and [id(p) for p in model.parameters()] == params
     assert len(bns) == 44 and all(isinstance(m, tssa.SyncBatchNorm) and isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in bns)
     assert all(ops._sync_group(m) is None for m in bns)        # no process group here: local statistics
+
+
+def test_half_and_to_dtype_select_bf16_activations_and_back():
+    """`.half()` / `.to(dtype)` on the modules (TSS scripts/contextnet/benchmark_contextnet.py:62).
+    Host-side part: the cast is accepted, parameters really are 16-bit, the activation format of the HIP path follows."""
+    from torch_semantic_segmentation_amd.models._fused import FusedSequential
+    m = cases.product_model('contextnet14')
+    assert getattr(m, 'compute_dtype', None) is None
+    m.half()
+    assert all(p.dtype == torch.float16 for p in m.parameters())
+    assert m.compute_dtype == torch.bfloat16 and all(f.act_dtype == torch.bfloat16 for f in m.modules() if isinstance(f, FusedSequential))
+    m.float()
+    assert m.compute_dtype == torch.float32
+    m.to(torch.bfloat16)
+    assert m.compute_dtype == torch.bfloat16 and next(m.parameters()).dtype == torch.bfloat16
+    assert len(m.state_dict()) == 314                      # same keys whatever the dtype
+
+
+def test_flat_adamw_state_dict_round_trip_and_detached_gradients_raise():
+    """the flat moments / step counter travel through state_dict, and step() refuses to run on gradients that
+    no longer alias the flat buffer (model.zero_grad(set_to_none=True) would otherwise make it apply zeros silently)."""
+    from torch_semantic_segmentation_amd import engine as E
+    m = nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4))
+    opt = E.FlatAdamW(m.parameters(), lr=1e-3)
+    opt.exp_avg.fill_(0.5); opt.exp_avg_sq.fill_(0.25); opt.state_vec.copy_(torch.tensor([3.0, 0.1, 0.2]))
+    sd = opt.state_dict()
+    opt2 = E.FlatAdamW(nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4)).parameters(), lr=1e-3)
+    opt2.load_state_dict(sd)
+    assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert torch.equal(opt2.state_vec, opt.state_vec)
+    opt._check_aliases()
+    m.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match='no longer aliases'):
+        opt._check_aliases()
+    opt.reattach()
+    opt._check_aliases()

@@ -342,8 +342,79 @@ def test_hooks_fire_with_materialized_tensors():
     assert tuple(seen['down'].shape) == (2, 64, 8, 16) and tuple(seen['feat'].shape) == (2, 128, 2, 4)
     assert tuple(seen['inner'].shape) == (2, 384, 4, 8) and isinstance(seen['inner'], torch.Tensor)
     assert tuple(y.shape) == (2, 19, 64, 128)
-    leaf = m.downsample[0][0]
-    h = leaf.register_forward_hook(lambda *a: None)
+    h = m.downsample[0][0].register_full_backward_hook(lambda *a: None)     # backward hooks on fused leaves: refused, loudly
     with pytest.raises(NotImplementedError):
         m(torch.randn(2, 3, 64, 128, device=DEV))
     h.remove()
+
+
+def test_leaf_hooks_see_what_the_reference_leaves_produce():
+    """SURVEY.md section 8b item (3) for LEAVES (VERDICT r01 missing #4): a forward hook on a Conv2d / BatchNorm2d / ReLU inside
+    a fused unit -- the CaptureOutput pattern, TSS/nn/utils.py:7-32 -- fires with the tensor the reference's leaf returns:
+    raw conv output, normalised output, activated output.  Checked against the oracle (same weights, same hooks), train
+    mode, and the model output is unchanged by the presence of the hooks."""
+    from oracle.recipe import lattice_input
+    ref = O_build_pair()
+    m = cases.product_model('fastscnn')
+    m.load_state_dict(ref.state_dict(), strict=True)
+    cases.zero_dropout(m); cases.zero_dropout(ref)
+    m.to(DEV).train(); ref.train()
+    x = lattice_input(2, 3, 64, 128)
+    paths = ['downsample.0.0', 'downsample.0.1', 'downsample.0.2', 'features.0.1.conv1.0', 'features.0.1.conv2.1',
+             'classifier.0.3', 'classifier.3']
+    got, want = {}, {}
+    hs = [m.get_submodule(p).register_forward_hook(lambda mod, i, o, p=p: got.__setitem__(p, o.detach().float().cpu())) for p in paths]
+    hr = [ref.get_submodule(p).register_forward_hook(lambda mod, i, o, p=p: want.__setitem__(p, o.detach().clone())) for p in paths]
+    pre = {}
+    hs.append(m.get_submodule('features.0.1.conv2.0').register_forward_pre_hook(lambda mod, i: pre.__setitem__('in', i[0].detach().float().cpu())))
+    hr.append(ref.get_submodule('features.0.1.conv2.0').register_forward_pre_hook(lambda mod, i: pre.__setitem__('ref', i[0].detach().clone())))
+    out_h = m(x.to(DEV))
+    out_r = ref(x)
+    for h in hs + hr:
+        h.remove()
+    assert set(got) == set(paths)
+    for p in paths:
+        assert tuple(got[p].shape) == tuple(want[p].shape), p
+        assert cases.rel_err(got[p].numpy(), want[p].numpy()) < 1e-3, p
+    assert cases.rel_err(pre['in'].numpy(), pre['ref'].numpy()) < 1e-3
+    assert cases.rel_err(out_h.detach().cpu().numpy(), out_r.detach().numpy()) < 1e-3
+    torch.manual_seed(0)
+    m2 = cases.product_model('fastscnn')
+    m2.load_state_dict({k: v for k, v in ref.state_dict().items()}, strict=False)
+    # a hook that tries to REPLACE a fused leaf's output is refused
+    h = m.downsample[0][1].register_forward_hook(lambda mod, i, o: o * 2)
+    with pytest.raises(NotImplementedError):
+        m(x.to(DEV))
+    h.remove()
+
+
+def O_build_pair():
+    from oracle import nets as O
+    torch.manual_seed(0)
+    return O.build('fastscnn')
+
+
+@pytest.mark.parametrize('name,dtype', [('contextnet14', torch.float16), ('fastscnn', torch.bfloat16), ('fastscnn', torch.float16)])
+def test_half_model_runs_and_tracks_f32(name, dtype):
+    """`model.to(device).to(dtype)` + a 16-bit batch, as TSS scripts/contextnet/benchmark_contextnet.py:40,62 does it: logits come
+    back in that dtype, equal to the f32 model's within bf16 noise; training-mode forward/backward fills 16-bit .grad."""
+    torch.manual_seed(0)
+    m = cases.product_model(name).to(DEV)
+    cases.zero_dropout(m)
+    x = torch.randn(2, 3, 64, 128, device=DEV)
+    m.eval()
+    with torch.no_grad():
+        want = m(x)
+        m.to(dtype)
+        got = m(x.to(dtype))
+    assert got.dtype == dtype and tuple(got.shape) == tuple(want.shape)
+    err = ((got.float() - want).norm() / want.norm()).item()
+    assert err < 5e-2, err
+    m.train()
+    out = m(x.to(dtype))
+    out.float().square().mean().backward()
+    assert all(p.grad is not None and p.grad.dtype == dtype and torch.isfinite(p.grad.float()).all() for p in m.parameters())
+    assert all(b.dtype == dtype for k, b in m.named_buffers() if k.endswith('running_mean'))
+    m.float()
+    with torch.no_grad():
+        assert m(x).dtype == torch.float32

@@ -39,7 +39,7 @@ DEV = 'cuda:0'
 # Relative-L2 caps per tensor kind.  Measured in round 2 on the unit chains below (profiles/r02_lean_parity.txt): out <= 2.5e-4,
 # dx <= 4.8e-3, dw <= 4.3e-3, dbeta <= 8.1e-3, dgamma <= 3.9e-2 (the BatchNorm backward cancels the two largest terms of
 # d(gamma) of an inner layer), running statistics <= 1.3e-5, lean against general <= 1.7e-3.
-CAP = {'out': 2e-3, 'dx': 1e-2, 'dw': 1e-2, 'dgamma': 6e-2, 'dbeta': 2e-2, 'stat': 1e-4}
+CAP = {'out': 2e-3, 'dx': 1e-2, 'dw': 1.2e-2, 'dgamma': 8e-2, 'dbeta': 2e-2, 'stat': 1e-4}
 FLOOR = 4e-3        # the bf16 noise level of one stored tensor: "2 x general" alone is too tight where general happens to be exact
 DIRECT = 5e-3       # lean against general on the same operands: accumulation order + the rare 1-ulp difference it causes
 # whole blocks (residual stacks, pyramid, classifier heads): several ReLU layers deep, so a 1-ulp difference between two
@@ -225,7 +225,7 @@ BASELINE_LAYERS = [
     # the stem and the first separable block on full-resolution images (two of them: the sweeps are per image)
     ('baseline_stem_ds', [('stem', 3, 32, {'stride': 2}), ('dw', 32, 32, {'stride': 2, 'act': False}), ('pw', 32, 48, {})], (2, 3, 1024, 2048)),
     # the decoder's 128-channel layers at 1/8 resolution: dilation-4 depthwise + the two biggest 1x1 layers of the step
-    ('baseline_decoder', [('pw', 64, 128, {'act': False}), ('dw', 128, 128, {'dilation': 4}), ('pw', 128, 128, {})], (8, 64, 128, 256)),
+    ('baseline_decoder', [('pw', 64, 128, {}), ('dw', 128, 128, {'dilation': 4}), ('pw', 128, 128, {})], (8, 64, 128, 256)),
 ]
 
 

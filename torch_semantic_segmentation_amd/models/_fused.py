@@ -7,8 +7,15 @@ every container stays hookable) but run it through :class:`FusedSequential`, whi
 lowers each ``conv -> [bn] -> [relu]`` group to one HIP unit with deferred BatchNorm (ops.conv_unit).
 
 Hooks: a container is always entered through ``nn.Module.__call__`` when it (or anything below it) has hooks
-registered, so forward hooks fire with a real, materialised tensor.  Leaf modules inside a fused group are not
-called individually; a hook registered directly on such a leaf raises instead of being silently skipped.
+registered, so forward hooks fire with a real, materialised tensor.  A forward (pre-)hook registered directly on a
+``Conv2d`` / ``BatchNorm2d`` / ``ReLU`` leaf of a fused group makes that group run un-deferred: every leaf's hooks fire
+with the real tensors the reference's leaf would see (conv output, normalised output, activated output), as
+``CaptureOutput`` (TSS/nn/utils.py:7-32) needs.  Such hooks observe; a hook that returns a replacement output, and
+backward hooks on these leaves, raise instead of being silently ignored.
+
+dtype: ``model.half()`` / ``model.to(torch.float16 | torch.bfloat16)`` (TSS scripts/contextnet/benchmark_contextnet.py:62)
+is accepted: the low-precision activation format of the MI355X path is bfloat16, the kernels read f32 views of the
+parameters (cast at the boundary), and the logits come back in the dtype of the input.
 """
 import torch
 from torch import nn
@@ -41,8 +48,64 @@ def has_hooks(m):
 def _leaf_guard(m):
     if _own_hooks(m):
         raise NotImplementedError(
-            'a hook is registered on %s, a leaf inside a fused conv/bn/relu unit; register it on the enclosing '
+            'a hook is registered on %s, a leaf inside a fused unit that has no un-fused form; register it on the enclosing '
             'block (any container of this model is hookable)' % m.__class__.__name__)
+
+
+def _fwd_hooked(m):
+    return m is not None and bool(m._forward_hooks or m._forward_pre_hooks)
+
+
+def _no_backward_hooks(m):
+    if m._backward_hooks or m._backward_pre_hooks:
+        raise NotImplementedError('backward hooks on %s, a leaf inside a fused conv/bn/relu unit, are not supported; '
+                                  'register them on the enclosing block' % m.__class__.__name__)
+
+
+def _pre_hooks(m, x, may_replace):
+    for hid, hook in m._forward_pre_hooks.items():
+        kw = getattr(m, '_forward_pre_hooks_with_kwargs', {}).get(hid, False)
+        r = hook(m, (x,), {}) if kw else hook(m, (x,))
+        if r is not None:
+            if not may_replace:
+                raise NotImplementedError('a forward pre-hook on %s inside a fused unit may observe its input, not replace it'
+                                          % m.__class__.__name__)
+            r = r[0] if kw else r
+            x = r[0] if isinstance(r, tuple) else r
+    return x
+
+
+def _post_hooks(m, x, out):
+    for hid, hook in m._forward_hooks.items():
+        kw = getattr(m, '_forward_hooks_with_kwargs', {}).get(hid, False)
+        r = hook(m, (x,), {}, out) if kw else hook(m, (x,), out)
+        if r is not None:
+            raise NotImplementedError('a forward hook on %s inside a fused unit may observe its output, not replace it'
+                                      % m.__class__.__name__)
+
+
+def _hooked_group(d, conv, bn, relu, out_dtype):
+    """conv -> [bn] -> [relu] with hooks on at least one leaf: the group runs with every intermediate materialised
+    (conv output raw, BatchNorm output, ReLU output are real tensors), hooks fire as nn.Module.__call__ would fire them."""
+    for m in (conv, bn, relu):
+        if m is not None:
+            _no_backward_hooks(m)
+    x = ops.materialize(d)
+    x = _pre_hooks(conv, x, may_replace=True)
+    dd = ops.conv_unit(x, conv, bn, False, out_dtype=out_dtype)
+    raw = dd.raw
+    _post_hooks(conv, x, raw.detach())
+    cur = raw
+    if bn is not None:
+        _pre_hooks(bn, raw.detach(), may_replace=False)
+        cur = ops.join(dd, None, False)
+        _post_hooks(bn, raw.detach(), cur)
+    if relu is not None:
+        _pre_hooks(relu, cur, may_replace=False)
+        out = ops.join(Deferred(cur), None, True)
+        _post_hooks(relu, cur, out)
+        cur = out
+    return Deferred(cur)
 
 
 def run(child, d):
@@ -63,15 +126,17 @@ class FusedSequential(nn.Sequential):
         while i < n:
             m = mods[i]
             if isinstance(m, nn.Conv2d):
-                _leaf_guard(m)
                 bn = mods[i + 1] if i + 1 < n and isinstance(mods[i + 1], _BatchNorm) else None
                 j = i + 1 + (bn is not None)
                 relu = j < n and isinstance(mods[j], nn.ReLU)
-                if bn is not None:
-                    _leaf_guard(bn)
-                if relu:
-                    _leaf_guard(mods[j])
-                d = ops.conv_unit(d, m, bn, relu, out_dtype=self.act_dtype)
+                leaves = (m, bn, mods[j] if relu else None)
+                if any(_fwd_hooked(l) for l in leaves):
+                    d = _hooked_group(d, m, bn, mods[j] if relu else None, self.act_dtype)
+                else:
+                    for l in leaves:
+                        if l is not None:
+                            _leaf_guard(l)
+                    d = ops.conv_unit(d, m, bn, relu, out_dtype=self.act_dtype)
                 i = j + int(relu)
             elif isinstance(m, nn.ReLU):
                 _leaf_guard(m)
@@ -105,6 +170,38 @@ class FusedSequential(nn.Sequential):
 
     def forward(self, input):
         return ops.materialize(self.unit(input))
+
+
+class HipModel(nn.Module):
+    """Root-module behaviour shared by the model mirrors: dtype casts of the whole model, as the reference's scripts do
+    them (`model.to(device).to(dtype)`, TSS scripts/contextnet/benchmark_contextnet.py:62; apex amp O2 casts to fp16,
+    scripts/train_fastscnn.py:147).  Casting the parameters to float16 / bfloat16 selects bfloat16 activations (the
+    MI355X counterpart of the reference's fp16 path: same bytes, no loss scaling needed); casting back to float32 restores
+    float32 activations.  An explicit set_compute_dtype() on f32 parameters (bf16 activations + f32 masters) is kept."""
+
+    _auto_low = False
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        p = next(self.parameters(), None)
+        if p is not None:
+            if p.dtype in (torch.float16, torch.bfloat16):
+                set_compute_dtype(self, torch.bfloat16)
+                self._auto_low = True
+            elif self._auto_low and p.dtype == torch.float32:
+                set_compute_dtype(self, torch.float32)
+                self._auto_low = False
+        return out
+
+    @staticmethod
+    def image_in(input):
+        """float16 images are read as float32 (the stem kernels gather f32 or bf16 planes)."""
+        return input.float() if input.dtype == torch.float16 else input
+
+    @staticmethod
+    def logits_out(logits, input):
+        """forward() returns the dtype it was given when that was a 16-bit float (the reference's modules do)."""
+        return logits.to(input.dtype) if input.dtype in (torch.float16, torch.bfloat16) and logits.dtype != input.dtype else logits
 
 
 def set_compute_dtype(model, dtype):

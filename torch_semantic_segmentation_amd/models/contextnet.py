@@ -4,7 +4,7 @@ TSS/models/contextnet.py; arithmetic in the HIP kernels behind include/tss_hip.h
 from torch import nn
 
 from .. import ops
-from ._fused import FusedSequential, run
+from ._fused import FusedSequential, HipModel, run
 
 __all__ = ['ContextNet', 'contextnet12', 'contextnet14', 'contextnet18']
 
@@ -92,7 +92,7 @@ def Classifier(in_channels, out_channels):
         nn.Conv2d(in_channels, out_channels, 1))
 
 
-class ContextNet(nn.Module):
+class ContextNet(HipModel):
     """(TSS/models/contextnet.py:28-76)"""
 
     scale_factor: int = 4
@@ -124,6 +124,7 @@ class ContextNet(nn.Module):
 
     def forward_lowres(self, input):
         """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits."""
+        input = self.image_in(input)
         spatial = self.spatial(input)
         context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
         context = self.context(context)
@@ -131,4 +132,4 @@ class ContextNet(nn.Module):
         return self.classifier(fusion)
 
     def forward(self, input):
-        return ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale)
+        return self.logits_out(ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale), input)

@@ -6,7 +6,7 @@ kernels behind include/tss_hip.h (ops.py), never in ATen.
 from torch import nn
 
 from .. import ops
-from ._fused import Deferred, FusedSequential, has_hooks, run
+from ._fused import Deferred, FusedSequential, HipModel, has_hooks, run
 
 __all__ = ['FastSCNN', 'fastscnn']
 
@@ -123,7 +123,7 @@ def Classifier(in_channels, out_channels):
         nn.Conv2d(in_channels, out_channels, kernel_size=1))
 
 
-class FastSCNN(nn.Module):
+class FastSCNN(HipModel):
     """(TSS/models/fastscnn.py:15-64)"""
 
     def __init__(self, in_channels, out_channels):
@@ -145,10 +145,10 @@ class FastSCNN(nn.Module):
     def forward_lowres(self, input):
         """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits.
         engine.Trainer feeds this to the fused upsample + cross-entropy operator."""
-        downsample = self.downsample(input)
+        downsample = self.downsample(self.image_in(input))
         features = self.features(downsample)
         fusion = self.fusion(features, downsample)
         return self.classifier(fusion)
 
     def forward(self, input):
-        return ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale)
+        return self.logits_out(ops.upsample_logits(self.forward_lowres(input), scale_factor=self.logit_scale), input)

@@ -131,7 +131,8 @@ class EvalAffines:
     def __init__(self, module):
         import struct
         bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)
-               and m.running_mean is not None and m.running_var is not None and m.running_mean.is_cuda]
+               and m.running_mean is not None and m.running_var is not None and m.running_mean.is_cuda
+               and m.running_mean.dtype == torch.float32 and (m.weight is None or m.weight.dtype == torch.float32)]
         self.bns, self.table, self.entries = bns, None, {}
         if not bns:
             return
@@ -398,8 +399,6 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         cfg.out_dtype = x_raw.dtype
     if x_raw.shape[1] != conv.in_channels:
         raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
-    if conv.weight.dtype != torch.float32:
-        raise TypeError('HIP path keeps parameters in float32 (activations may be bfloat16); got %s' % conv.weight.dtype)
     cfg.bn = bn
     cfg.training = False
     gamma = beta = None
@@ -411,8 +410,42 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
             raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
         gamma, beta = bn.weight, bn.bias
     cfg.params = (conv.weight, gamma, beta, conv.bias)
-    y = ConvUnitFn.apply(x_raw, conv.weight, gamma, beta, conv.bias, cfg)
+    # the kernels read float32 parameters; a model cast with .half() / .to(torch.bfloat16) (TSS
+    # scripts/contextnet/benchmark_contextnet.py:62) hands them differentiable f32 views of its 16-bit parameters (boundary
+    # plumbing: the gradient flows back through the cast, and the direct-accumulation path below stays off for them)
+    weight, bias = _f32(conv.weight), _f32(conv.bias)
+    y = ConvUnitFn.apply(x_raw, weight, _f32(gamma), _f32(beta), bias, cfg)
     return Deferred(y, cfg.out_link, relu)
+
+
+def _f32(p):
+    if p is None or p.dtype == torch.float32:
+        return p
+    if p.dtype not in (torch.float16, torch.bfloat16):
+        raise TypeError('HIP path: parameters must be float32, float16 or bfloat16, got %s' % p.dtype)
+    return p.float()
+
+
+class _F32Buffers:
+    """float32 stand-ins for the running statistics of a BatchNorm whose buffers were cast to 16 bits by model.half():
+    the finalize kernels update the stand-ins, close() writes them back."""
+
+    def __init__(self, bn, track):
+        self.pairs = []
+        self.mean = self.var = None
+        if track:
+            self.mean, self.var = self._get(bn.running_mean), self._get(bn.running_var)
+
+    def _get(self, buf):
+        if buf.dtype == torch.float32:
+            return buf
+        tmp = buf.float()
+        self.pairs.append((buf, tmp))
+        return tmp
+
+    def close(self):
+        for buf, tmp in self.pairs:
+            buf.copy_(tmp)
 
 
 class ConvUnitFn(Function):
@@ -465,7 +498,8 @@ class ConvUnitFn(Function):
             bn = cfg.bn
             if cfg.training:
                 track = bn.track_running_stats and bn.running_mean is not None
-                run_args = (ptr(bn.running_mean) if track else None, ptr(bn.running_var) if track else None,
+                rbuf = _F32Buffers(bn, track)
+                run_args = (ptr(rbuf.mean), ptr(rbuf.var),
                             ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None)
                 link.sync = _sync_group(bn)
                 if link.sync is not None:
@@ -475,12 +509,14 @@ class ConvUnitFn(Function):
                 else:
                     call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
                          float(bn.momentum), *run_args, ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+                rbuf.close()
             else:
                 pre = _EVAL_AFFINES.get(id(bn)) if _EVAL_AFFINES else None
                 if pre is not None:     # written by the model-wide launch at the top of this forward
                     link.mean, link.invstd, link.scale = pre.unbind(0)
                 else:
-                    call('tss_bn_eval_affine', ptr(gamma), ptr(bn.running_mean), ptr(bn.running_var),
+                    rbuf = _F32Buffers(bn, True)
+                    call('tss_bn_eval_affine', ptr(gamma), ptr(rbuf.mean), ptr(rbuf.var),
                          float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
         cfg.out_link = link
         ctx.cfg = cfg
