@@ -315,6 +315,17 @@ int tss_argmax_confusion(const void* logits, const long long* target, unsigned c
                          unsigned long long* confusion, long B, int C, long HW, int ignore_index,
                          int dtype, void* stream);
 
+/* ---- host side of the step: the batch on the wire ----------------------------------------------------------------------
+ * replaces: the float32 image / int64 target the reference's DataLoader produces (albumentations.Normalize + ToTensor,
+ *           scripts/train_fastscnn.py:62-68) and copies to the device every iteration (TSS/engine.py:27).  The loader may ship
+ *           uint8 pixels (HWC as decoded, or CHW) and uint8 labels instead (5x fewer PCIe bytes); this entry writes
+ *           image_out[b][c][h][w] = (image/255 - mean[c]) / std[c] (f32 NCHW) and target_out = (int64) target into the
+ *           buffers the step reads.  mean3 / std3 are HOST arrays of C floats (NULL: 0 / 1); either tensor may be NULL. */
+int tss_decode_batch_u8(const unsigned char* image, int image_is_hwc, const float* mean3, const float* std3, float* image_out,
+                        const unsigned char* target, long long* target_out, long B, int C, long HW, void* stream);
+/* zero-fill (gradient buffers, accumulators): hipMemsetAsync, i.e. a memset node when captured in a graph */
+int tss_zero(void* p, long bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,46 @@
+"""Worker of tests/test_gpu_models.py::test_syncbn_step_is_captured_in_a_hip_graph_with_rccl: one rank, RCCL backend,
+TSS_SYNCBN_FORCE=1.  Trains FastSCNN for a few steps twice -- convert_syncbn_model + Trainer(use_graph=True), and plain
+BatchNorm un-captured -- and saves both loss curves and whether the SyncBatchNorm step really ran as a HIP graph."""
+import os
+import sys
+import warnings
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if __name__ == '__main__':
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd import ops
+    from torch_semantic_segmentation_amd.models.fastscnn import fastscnn
+    from oracle.recipe import synthetic_batch
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', init_method='env://')
+    dev = torch.device('cuda', 0)
+    x, y = synthetic_batch(2, 64, 128)
+    x, y = x.to(dev), y.to(dev)
+    curves, captured, warning, n_sync = {}, False, '', 0
+    for mode in ('sync', 'local'):
+        torch.manual_seed(0)
+        m = fastscnn(3, 19).to(dev)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        if mode == 'sync':
+            tssa.convert_syncbn_model(m)
+            n_sync = sum(ops._sync_group(b, any_mode=True) is not None for b in m.modules()
+                         if isinstance(b, torch.nn.modules.batchnorm._BatchNorm))
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter('always')
+            tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=(mode == 'sync'))
+            curves[mode] = [tr.step_async(x, y).item() for _ in range(4)]
+        if mode == 'sync':
+            captured = tr._graph is not None and tr.use_graph
+            warning = '; '.join(str(w.message) for w in caught)
+    torch.save({'losses_sync': curves['sync'], 'losses_local': curves['local'], 'captured': captured, 'warning': warning,
+                'sync_layers': n_sync}, sys.argv[1])
+    dist.barrier()
+    dist.destroy_process_group()

@@ -278,19 +278,47 @@ def test_syncbn_two_ranks_equal_one_big_batch(tmp_path):
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-3000:]
     got = torch.load(out_path)
-    model = W.build().to(DEV)                       # same weights, ordinary (local) BatchNorm, the whole batch at once
+    # the ORACLE (plain torch modules of oracle/nets.py, CPU, ordinary BatchNorm) on the whole batch at once: what apex
+    # SyncBatchNorm promises -- and what VERDICT r01 asked for instead of a HIP-vs-HIP comparison
+    ref = nn.Sequential(O.unit(16, 32, 1), O._FastResidual(32, 32, expansion=6), O.separable(32, 48, stride=2))
+    ref.load_state_dict(W.build().state_dict(), strict=True)
     x, cot = W.batch()
-    ref_out = W.run(model, x.to(DEV), cot.to(DEV)).cpu()
-    assert cases.rel_err(got['out'].numpy(), ref_out[:2].numpy()) < 2e-5
-    for n, b in model.named_buffers():
+    ref.train()
+    out_r = ref(x)
+    (out_r * cot).sum().backward()
+    assert cases.rel_err(got['out'].numpy(), out_r[:2].detach().numpy()) < 2e-5
+    for n, b in ref.named_buffers():
         if b.dtype.is_floating_point:
-            assert cases.rel_err(got['buffers'][n].numpy(), b.detach().cpu().numpy()) < 2e-5, n
+            assert cases.rel_err(got['buffers'][n].numpy(), b.detach().numpy()) < 2e-5, n
         else:
             assert int(got['buffers'][n]) == int(b), n
-    for n, p in model.named_parameters():
-        a, b = got['grads'][n].double(), p.grad.detach().cpu().double()
+    for n, p in ref.named_parameters():
+        a, b = got['grads'][n].double(), p.grad.detach().double()
         # BatchNorm biases in front of another BatchNorm have analytically zero gradients: absolute floor
         assert float((a - b).abs().max() / max(float(b.abs().max()), 1e-2)) < 5e-4, n
+
+
+def test_syncbn_step_is_captured_in_a_hip_graph_with_rccl(tmp_path):
+    """SURVEY.md section 8f N1 / VERDICT r01 #8b: a SyncBatchNorm training step (2 small collectives per BatchNorm layer)
+    inside Trainer(use_graph=True).  One rank, backend nccl (= RCCL), TSS_SYNCBN_FORCE=1 so the cross-replica path is taken:
+    the captured step must replay and give the trajectory of the local-BatchNorm model (with one rank they are the same
+    numbers).  What this cannot show -- multi-rank RCCL inside a graph -- needs a multi-GPU node."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_path = str(tmp_path / 'sync_graph.pt')
+    env = dict(os.environ, TSS_SYNCBN_FORCE='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29573', os.path.join(root, 'tests', 'syncbn_graph_worker.py'), out_path]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    got = torch.load(out_path)
+    assert got['sync_layers'] == 44
+    print('SyncBatchNorm step: captured =', got['captured'], ' losses', got['losses_sync'], got['losses_local'])
+    assert np.allclose(got['losses_sync'], got['losses_local'], rtol=2e-3)
+    assert got['captured'], 'the SyncBatchNorm step fell back to un-captured launches: ' + got['warning']
 
 
 def test_reference_training_recipe_runs_on_the_hip_path():
@@ -367,3 +395,63 @@ def test_graphed_inference_and_benchmark_model_match_eager_eval():
         g(torch.randn(1, 3, 128, 256, device='cuda'))
     r = tssa.benchmark_model(m, x, iterations=3, warmup=1, use_graph=True)
     assert set(r) == {'fps', 'min', 'max', 'mean', 'std'} and r['fps'] > 0 and r['min'] <= r['mean'] <= r['max']
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_host_batch_pipeline_overlaps_h2d_and_decodes_uint8(use_graph):
+    """VERDICT r01 #10 / TSS/engine.py:27: engine.HostBatchPipeline -- batches staged over PCIe on a copy stream while the
+    previous step runs.  f32 wire: the same losses as feeding the device batch directly.  u8 wire: tss_decode_batch_u8
+    (HWC and CHW) equals albumentations.Normalize + ToTensor arithmetic, targets keep 255."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd import _native as N
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 64, 128
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    batches = []
+    for _ in range(4):
+        img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+        tgt = torch.randint(0, 19, (B, H, W), generator=g, dtype=torch.uint8)
+        tgt[torch.rand(B, H, W, generator=g) < 0.05] = 255
+        batches.append((img, tgt))
+
+    def normalize(img):      # what the reference's transform pipeline produces on the host
+        x = img.permute(0, 3, 1, 2).float() / 255.0
+        return (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+
+    def make():
+        torch.manual_seed(0)
+        m = cases.product_model('fastscnn').to(DEV)
+        cases.zero_dropout(m)
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        return E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=use_graph)
+    tr = make()
+    want = [tr.step_async(normalize(i).to(DEV), t.long().to(DEV)).item() for i, t in batches]
+    for wire in ('f32', 'u8_hwc', 'u8_chw'):
+        tr = make()
+        ex, ey = normalize(batches[0][0]), batches[0][1].long()
+        if wire == 'f32':
+            pipe = E.HostBatchPipeline(tr, ex, ey, wire='f32', device=DEV)
+            feed = [(normalize(i).pin_memory(), t.long().pin_memory()) for i, t in batches]
+        else:
+            hwc = wire == 'u8_hwc'
+            pipe = E.HostBatchPipeline(tr, ex, ey, wire='u8', mean=mean, std=std, image_hwc=hwc, device=DEV)
+            feed = [((i if hwc else i.permute(0, 3, 1, 2).contiguous()).pin_memory(), t.pin_memory()) for i, t in batches]
+        got = []
+        pipe.put(*feed[0])
+        for nxt in feed[1:]:
+            pipe.put(*nxt)
+            got.append(pipe.step().item())
+        got.append(pipe.step().item())
+        assert np.allclose(got, want, rtol=2e-4), (wire, got, want)
+        with pytest.raises(RuntimeError):
+            pipe.step()
+    # the decode kernel itself, bit for bit against the same f32 formula (x * 1/(255 std) - mean/std)
+    img, tgt = batches[0]
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=DEV)
+    tout = torch.empty((B, H, W), dtype=torch.int64, device=DEV)
+    import ctypes
+    N.call('tss_decode_batch_u8', N.ptr(img.to(DEV)), 1, (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std), N.ptr(out),
+           N.ptr(tgt.to(DEV)), N.ptr(tout), B, 3, H * W, N.stream())
+    assert cases.rel_err(out.cpu().numpy(), normalize(img).numpy()) < 1e-6
+    assert torch.equal(tout.cpu(), tgt.long())

@@ -62,7 +62,10 @@ class FlatAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()
+        if self.flat_grad.is_cuda:      # hipMemsetAsync: a memset node of the captured step instead of a fill kernel
+            N.call('tss_zero', N.ptr(self.flat_grad), self.flat_grad.numel() * 4, N.stream())
+        else:
+            self.flat_grad.zero_()
 
     def _check_aliases(self):
         """Every p.grad must still be its slice of flat_grad (model.zero_grad(set_to_none=True) or an optimizer-external
@@ -246,11 +249,25 @@ class Trainer:
         """One training iteration; returns the loss as a device tensor (no host sync)."""
         if self.use_graph and self._graph is None and any(ops._sync_group(m, any_mode=True) is not None for m in self.model.modules()
                                                           if isinstance(m, nn.modules.batchnorm._BatchNorm)):
-            # cross-replica BatchNorm puts ~88 tiny collectives inside the step; capturing them in a HIP graph has not been
-            # validated on a multi-GPU node, so such a model runs un-captured (correct, higher launch overhead)
+            # cross-replica BatchNorm puts 2 small collectives per BatchNorm layer inside the step.  RCCL collectives on the
+            # capturing stream are recorded into the HIP graph like kernels (validated with a one-rank RCCL group on one
+            # MI355X, tests/test_gpu_models.py; a multi-GPU node was not available); collectives of a host-side backend
+            # (gloo) cannot be captured, and if the capture fails for any reason the step runs un-captured (correct,
+            # ~10^3 host launches per step).
             import warnings
-            warnings.warn('SyncBatchNorm is active: the training step is not captured in a HIP graph')
-            self.use_graph = False
+            backend = dist.get_backend() if dist.is_initialized() else None
+            if backend != 'nccl':
+                warnings.warn('SyncBatchNorm over the %s backend: the training step is not captured in a HIP graph' % backend)
+                self.use_graph = False
+            else:
+                try:
+                    self._capture(x, y)
+                except Exception as exc:      # noqa: BLE001 -- any capture failure: fall back, loudly
+                    warnings.warn('SyncBatchNorm: HIP-graph capture of the step failed (%s: %s); running un-captured'
+                                  % (type(exc).__name__, exc))
+                    self._graph = None
+                    self.use_graph = False
+                    torch.cuda.synchronize()
         if self.use_graph:
             if self._graph is None:
                 self._capture(x, y)
@@ -279,6 +296,97 @@ class Trainer:
             for batch in data:
                 history.append(self.update(batch))
         return history
+
+
+class HostBatchPipeline:
+    """The host side of `update_fn` under load (TSS/engine.py:27: `x.to(device, non_blocking=True)` every iteration): the
+    batch of step i+1 crosses PCIe on a copy stream while step i computes, through `depth` device staging slots, and lands
+    in the buffers the (captured) step reads with one device-side pass at the top of its step.
+
+    wire = 'f32': float32 NCHW image + int64 target, as the reference's DataLoader delivers them (335 MB per 8 x 3 x 1024 x
+           2048 batch -- 6.1 ms over PCIe Gen5, as long as the step itself; hidden, but only just);
+    wire = 'u8' : uint8 image (CHW, or HWC as decoded: image_hwc=True) + uint8 target (67 MB); `mean` / `std` are the
+           albumentations.Normalize constants (scripts/train_fastscnn.py:62-68), applied on the device by tss_decode_batch_u8.
+
+        pipe = HostBatchPipeline(trainer, example_x_f32, example_y_i64, wire='u8', mean=..., std=...)
+        pipe.put(x0, y0)
+        for next_batch in loader:          # pinned host tensors (DataLoader(pin_memory=True)); others are pinned by a copy
+            pipe.put(*next_batch)          # H2D of the next batch starts now, on the copy stream
+            loss = pipe.step()             # waits for the oldest staged batch only, runs the step on it
+    """
+
+    def __init__(self, trainer, example_x, example_y, wire='f32', mean=None, std=None, image_hwc=False, depth=2, device=None):
+        if wire not in ('f32', 'u8'):
+            raise ValueError("wire must be 'f32' or 'u8'")
+        self.trainer, self.wire, self.image_hwc, self.depth = trainer, wire, bool(image_hwc), int(depth)
+        dev = device if device is not None else (trainer.device if trainer.device is not None else torch.device('cuda', torch.cuda.current_device()))
+        self.device = torch.device(dev)
+        B, C, H, W = example_x.shape
+        self.geom = (B, C, H, W)
+        self.static = trainer.static_batch(torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
+                                           torch.empty((B, H, W), dtype=torch.int64, device=self.device)) \
+            if trainer.use_graph else None
+        if wire == 'u8':
+            xs = (B, H, W, C) if image_hwc else (B, C, H, W)
+            self.stage = [(torch.empty(xs, dtype=torch.uint8, device=self.device), torch.empty((B, H, W), dtype=torch.uint8, device=self.device))
+                          for _ in range(depth)]
+            import ctypes
+            self._mean = (ctypes.c_float * 3)(*([float(v) for v in mean] + [0.0] * 3)[:3]) if mean is not None else None
+            self._std = (ctypes.c_float * 3)(*([float(v) for v in std] + [1.0] * 3)[:3]) if std is not None else None
+        else:
+            self.stage = [(torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
+                           torch.empty((B, H, W), dtype=torch.int64, device=self.device)) for _ in range(depth)]
+        if self.static is None:    # un-captured trainer: decode / copy into private buffers
+            self.static = (torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
+                           torch.empty((B, H, W), dtype=torch.int64, device=self.device))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.ready = [torch.cuda.Event() for _ in range(depth)]
+        self.consumed = [torch.cuda.Event() for _ in range(depth)]
+        self._keep = [None] * depth          # host tensors stay referenced until their copy has been consumed
+        self._head = self._count = 0
+
+    def put(self, x, y):
+        """Start the H2D copy of one batch.  Blocks (on the host) only when all `depth` slots are still in use."""
+        if self._count == self.depth:
+            raise RuntimeError('HostBatchPipeline: %d batches already staged; call step() first' % self.depth)
+        slot = (self._head + self._count) % self.depth
+        sx, sy = self.stage[slot]
+        if tuple(x.shape) != tuple(sx.shape) or x.dtype != sx.dtype or tuple(y.shape) != tuple(sy.shape) or y.dtype != sy.dtype:
+            raise ValueError('HostBatchPipeline(wire=%r): expected image %s %s and target %s %s, got %s %s / %s %s'
+                             % (self.wire, tuple(sx.shape), sx.dtype, tuple(sy.shape), sy.dtype, tuple(x.shape), x.dtype,
+                                tuple(y.shape), y.dtype))
+        if not x.is_cuda and not x.is_pinned():
+            x = x.pin_memory()
+        if not y.is_cuda and not y.is_pinned():
+            y = y.pin_memory()
+        self._keep[slot] = (x, y)
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed[slot])      # the step that read this slot last has consumed it
+            sx.copy_(x, non_blocking=True)
+            sy.copy_(y, non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        self._count += 1
+
+    def step(self):
+        """Run one training step on the oldest staged batch; returns the loss as a device tensor."""
+        if self._count == 0:
+            raise RuntimeError('HostBatchPipeline.step(): nothing staged; call put() first')
+        slot = self._head
+        sx, sy = self.stage[slot]
+        dx, dy = self.static
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self.ready[slot])
+        B, C, H, W = self.geom
+        if self.wire == 'u8':
+            N.call('tss_decode_batch_u8', N.ptr(sx), int(self.image_hwc), self._mean, self._std, N.ptr(dx), N.ptr(sy), N.ptr(dy),
+                   B, C, H * W, main.cuda_stream)
+        else:
+            dx.copy_(sx, non_blocking=True)
+            dy.copy_(sy, non_blocking=True)
+        self.consumed[slot].record(main)
+        self._head = (self._head + 1) % self.depth
+        self._count -= 1
+        return self.trainer.step_async(dx, dy)
 
 
 def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False, logging=True,

@@ -316,7 +316,9 @@ def _sync_group(bn, any_mode=False):
     if not (dist.is_available() and dist.is_initialized()):
         return None
     group = getattr(bn, 'process_group', None) or dist.group.WORLD
-    return group if dist.get_world_size(group) > 1 else None
+    # TSS_SYNCBN_FORCE=1: take the cross-replica path even in a one-rank group (exercises the collectives, their HIP-graph
+    # capture and their cost on a single GPU; the result equals local BatchNorm)
+    return group if (dist.get_world_size(group) > 1 or os.environ.get('TSS_SYNCBN_FORCE') == '1') else None
 
 
 def _allreduce_stats(slabs, count, C, group, st):
@@ -1150,7 +1152,8 @@ class UpsampleCrossEntropyFn(Function):
         target = target.contiguous()
         # one zero-fill for both accumulators: [loss sum, #valid] as f64 in front (16 bytes), the f32 low-res gradient behind
         n = B * h * w * ld(low)
-        zbuf = torch.zeros(4 + n, dtype=torch.float32, device=dev)
+        zbuf = torch.empty(4 + n, dtype=torch.float32, device=dev)
+        call('tss_zero', ptr(zbuf), zbuf.numel() * 4, stream())
         acc = zbuf[:4].view(torch.float64)
         dacc = zbuf[4:].view(B, h, w, ld(low))
         scal = torch.empty(2, dtype=torch.float32, device=dev)
