@@ -177,13 +177,23 @@ class Trainer:
         if self.flat:
             optimizer.grad_scale = 1.0 / world_size
         self.shadows = None
-        self._graph = None
-        self._static = None
+        # captured steps, one per input slot: slot -> (graph, loss tensor).  Slot 0 is the ordinary one; a loader that
+        # double-buffers its batches (HostBatchPipeline) captures one step per staging slot so that the step reads the
+        # staged batch in place -- no device-to-device copy between the H2D copy and the step
+        self._graphs = {}
+        self._statics = {}
         self.iteration = 0
         self.last_loss = None
 
+    @property
+    def _graph(self):
+        g = self._graphs.get(0)
+        return g[0] if g else None
+
     # -- one un-captured iteration: exactly the statements of the reference's update_fn
-    def _forward_backward(self, x, y):
+    def _forward_backward(self, x, y, prologue=None):
+        if prologue is not None:      # device-side preparation of (x, y), e.g. the uint8 decode: part of the captured step
+            prologue()
         self.model.train()
         self.optimizer.zero_grad()
         if self.shadows is None:
@@ -211,13 +221,17 @@ class Trainer:
                         p.grad.div_(self.world_size)
         self.optimizer.step()
 
-    def static_batch(self, x, y):
-        """The (image, target) device buffers the captured step reads.  A loader can fill them in place (H2D copy
-        straight into them) and pass them to step_async, which then skips its own device-to-device copy."""
-        if self._static is None:
+    def static_batch(self, x, y, slot=0, adopt=False):
+        """The (image, target) device buffers the captured step of `slot` reads.  A loader can fill them in place (H2D copy
+        straight into them) and pass them to step_async, which then skips its own device-to-device copy.  adopt=True:
+        x and y (device tensors) BECOME the static buffers of a slot that has none yet."""
+        if slot not in self._statics:
             dev = self.device if self.device is not None else x.device
-            self._static = (torch.empty(x.shape, dtype=x.dtype, device=dev), torch.empty(y.shape, dtype=y.dtype, device=dev))
-        sx, sy = self._static
+            if adopt and x.is_cuda and y.is_cuda:
+                self._statics[slot] = (x, y)
+            else:
+                self._statics[slot] = (torch.empty(x.shape, dtype=x.dtype, device=dev), torch.empty(y.shape, dtype=y.dtype, device=dev))
+        sx, sy = self._statics[slot]
         if tuple(sx.shape) != tuple(x.shape) or tuple(sy.shape) != tuple(y.shape) or sx.dtype != x.dtype or sy.dtype != y.dtype:
             raise ValueError('HIP-graph trainer: the batch shape/dtype is fixed at the first step '
                              f'({tuple(sx.shape)} {sx.dtype}); got {tuple(x.shape)} {x.dtype}')
@@ -227,8 +241,8 @@ class Trainer:
             sy.copy_(y, non_blocking=True)
         return sx, sy
 
-    def _capture(self, x, y):
-        sx, sy = self.static_batch(x, y)
+    def _capture(self, x, y, slot=0, prologue=None):
+        sx, sy = self.static_batch(x, y, slot)
         # warm-up on a side stream (lazily initialised state must exist before capture); buffers that a
         # forward pass mutates (BatchNorm running statistics) are restored so the warm-up leaves no trace
         saved = [(b, b.clone()) for b in self.model.buffers()]
@@ -236,18 +250,21 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self._forward_backward(sx, sy)
+                self._forward_backward(sx, sy, prologue)
         torch.cuda.current_stream().wait_stream(side)
         with torch.no_grad():
             for b, v in saved:
                 b.copy_(v)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._static_loss = self._forward_backward(sx, sy).detach()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self._forward_backward(sx, sy, prologue).detach()
+        self._graphs[slot] = (graph, loss)
 
-    def step_async(self, x, y):
-        """One training iteration; returns the loss as a device tensor (no host sync)."""
-        if self.use_graph and self._graph is None and any(ops._sync_group(m, any_mode=True) is not None for m in self.model.modules()
+    def step_async(self, x, y, slot=0, prologue=None):
+        """One training iteration; returns the loss as a device tensor (no host sync).  `slot` selects one of several
+        captured steps (each with its own input buffers, see static_batch); `prologue` is a callable that prepares (x, y)
+        on the device and is captured with the step."""
+        if self.use_graph and not self._graphs and any(ops._sync_group(m, any_mode=True) is not None for m in self.model.modules()
                                                           if isinstance(m, nn.modules.batchnorm._BatchNorm)):
             # cross-replica BatchNorm puts 2 small collectives per BatchNorm layer inside the step.  RCCL collectives on the
             # capturing stream are recorded into the HIP graph like kernels (validated with a one-rank RCCL group on one
@@ -261,22 +278,22 @@ class Trainer:
                 self.use_graph = False
             else:
                 try:
-                    self._capture(x, y)
+                    self._capture(x, y, slot, prologue)
                 except Exception as exc:      # noqa: BLE001 -- any capture failure: fall back, loudly
                     warnings.warn('SyncBatchNorm: HIP-graph capture of the step failed (%s: %s); running un-captured'
                                   % (type(exc).__name__, exc))
-                    self._graph = None
+                    self._graphs.pop(slot, None)
                     self.use_graph = False
                     torch.cuda.synchronize()
         if self.use_graph:
-            if self._graph is None:
-                self._capture(x, y)
+            if slot not in self._graphs:
+                self._capture(x, y, slot, prologue)
             else:
-                self.static_batch(x, y)
-            self._graph.replay()
-            loss = self._static_loss
+                self.static_batch(x, y, slot)
+            graph, loss = self._graphs[slot]
+            graph.replay()
         else:
-            loss = self._forward_backward(x, y).detach()
+            loss = self._forward_backward(x, y, prologue).detach()
         self._reduce_and_step()
         self.iteration += 1
         return loss
@@ -300,13 +317,15 @@ class Trainer:
 
 class HostBatchPipeline:
     """The host side of `update_fn` under load (TSS/engine.py:27: `x.to(device, non_blocking=True)` every iteration): the
-    batch of step i+1 crosses PCIe on a copy stream while step i computes, through `depth` device staging slots, and lands
-    in the buffers the (captured) step reads with one device-side pass at the top of its step.
+    batch of step i+1 crosses PCIe on a copy stream while step i computes, through `depth` device staging slots.  With a
+    captured trainer there is one captured step per slot, reading its slot in place: nothing but the graph replay (and the
+    optimizer) is launched per step.
 
     wire = 'f32': float32 NCHW image + int64 target, as the reference's DataLoader delivers them (335 MB per 8 x 3 x 1024 x
            2048 batch -- 6.1 ms over PCIe Gen5, as long as the step itself; hidden, but only just);
     wire = 'u8' : uint8 image (CHW, or HWC as decoded: image_hwc=True) + uint8 target (67 MB); `mean` / `std` are the
-           albumentations.Normalize constants (scripts/train_fastscnn.py:62-68), applied on the device by tss_decode_batch_u8.
+           albumentations.Normalize constants (scripts/train_fastscnn.py:62-68), applied on the device by tss_decode_batch_u8
+           at the top of the (captured) step.
 
         pipe = HostBatchPipeline(trainer, example_x_f32, example_y_i64, wire='u8', mean=..., std=...)
         pipe.put(x0, y0)
@@ -323,22 +342,20 @@ class HostBatchPipeline:
         self.device = torch.device(dev)
         B, C, H, W = example_x.shape
         self.geom = (B, C, H, W)
-        self.static = trainer.static_batch(torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
-                                           torch.empty((B, H, W), dtype=torch.int64, device=self.device)) \
-            if trainer.use_graph else None
+        f32 = lambda: (torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),      # noqa: E731
+                       torch.empty((B, H, W), dtype=torch.int64, device=self.device))
         if wire == 'u8':
+            import ctypes
             xs = (B, H, W, C) if image_hwc else (B, C, H, W)
             self.stage = [(torch.empty(xs, dtype=torch.uint8, device=self.device), torch.empty((B, H, W), dtype=torch.uint8, device=self.device))
                           for _ in range(depth)]
-            import ctypes
             self._mean = (ctypes.c_float * 3)(*([float(v) for v in mean] + [0.0] * 3)[:3]) if mean is not None else None
             self._std = (ctypes.c_float * 3)(*([float(v) for v in std] + [1.0] * 3)[:3]) if std is not None else None
+            self.decoded = f32()             # one decoded batch, shared by the slots: written and read inside one step
         else:
-            self.stage = [(torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
-                           torch.empty((B, H, W), dtype=torch.int64, device=self.device)) for _ in range(depth)]
-        if self.static is None:    # un-captured trainer: decode / copy into private buffers
-            self.static = (torch.empty((B, C, H, W), dtype=torch.float32, device=self.device),
-                           torch.empty((B, H, W), dtype=torch.int64, device=self.device))
+            self.stage = [f32() for _ in range(depth)]
+            self.decoded = None
+        self.slot0 = 1000 + id(self) % 1000 * 16      # private slot numbers of this pipeline inside the trainer
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.consumed = [torch.cuda.Event() for _ in range(depth)]
@@ -346,7 +363,7 @@ class HostBatchPipeline:
         self._head = self._count = 0
 
     def put(self, x, y):
-        """Start the H2D copy of one batch.  Blocks (on the host) only when all `depth` slots are still in use."""
+        """Start the H2D copy of one batch.  Raises when all `depth` slots are still in use."""
         if self._count == self.depth:
             raise RuntimeError('HostBatchPipeline: %d batches already staged; call step() first' % self.depth)
         slot = (self._head + self._count) % self.depth
@@ -361,32 +378,39 @@ class HostBatchPipeline:
             y = y.pin_memory()
         self._keep[slot] = (x, y)
         with torch.cuda.stream(self.copy_stream):
-            self.copy_stream.wait_event(self.consumed[slot])      # the step that read this slot last has consumed it
+            self.copy_stream.wait_event(self.consumed[slot])      # the step that read this slot last has finished with it
             sx.copy_(x, non_blocking=True)
             sy.copy_(y, non_blocking=True)
             self.ready[slot].record(self.copy_stream)
         self._count += 1
+
+    def _decode(self, slot):
+        sx, sy = self.stage[slot]
+        dx, dy = self.decoded
+        B, C, H, W = self.geom
+        N.call('tss_decode_batch_u8', N.ptr(sx), int(self.image_hwc), self._mean, self._std, N.ptr(dx), N.ptr(sy), N.ptr(dy),
+               B, C, H * W, N.stream())
 
     def step(self):
         """Run one training step on the oldest staged batch; returns the loss as a device tensor."""
         if self._count == 0:
             raise RuntimeError('HostBatchPipeline.step(): nothing staged; call put() first')
         slot = self._head
-        sx, sy = self.stage[slot]
-        dx, dy = self.static
         main = torch.cuda.current_stream(self.device)
         main.wait_event(self.ready[slot])
-        B, C, H, W = self.geom
+        tslot = self.slot0 + slot
         if self.wire == 'u8':
-            N.call('tss_decode_batch_u8', N.ptr(sx), int(self.image_hwc), self._mean, self._std, N.ptr(dx), N.ptr(sy), N.ptr(dy),
-                   B, C, H * W, main.cuda_stream)
+            dx, dy = self.decoded
+            self.trainer.static_batch(dx, dy, tslot, adopt=True)
+            loss = self.trainer.step_async(dx, dy, slot=tslot, prologue=lambda: self._decode(slot))
         else:
-            dx.copy_(sx, non_blocking=True)
-            dy.copy_(sy, non_blocking=True)
+            sx, sy = self.stage[slot]
+            self.trainer.static_batch(sx, sy, tslot, adopt=True)
+            loss = self.trainer.step_async(sx, sy, slot=tslot)
         self.consumed[slot].record(main)
         self._head = (self._head + 1) % self.depth
         self._count -= 1
-        return self.trainer.step_async(dx, dy)
+        return loss
 
 
 def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False, logging=True,
