@@ -369,6 +369,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss)
+    if final_loss != final_loss or abs(final_loss) == float('inf'):
+        raise SystemExit('bench.py: the training loss is not finite after %d steps -- the timed steps are not a valid workload' % args.steps)
 
     host_batch = None
     if args.host_batch:          # all ranks: the steps contain the gradient all-reduce

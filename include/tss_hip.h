@@ -323,8 +323,6 @@ int tss_argmax_confusion(const void* logits, const long long* target, unsigned c
  *           buffers the step reads.  mean3 / std3 are HOST arrays of C floats (NULL: 0 / 1); either tensor may be NULL. */
 int tss_decode_batch_u8(const unsigned char* image, int image_is_hwc, const float* mean3, const float* std3, float* image_out,
                         const unsigned char* target, long long* target_out, long B, int C, long HW, void* stream);
-/* zero-fill (gradient buffers, accumulators): hipMemsetAsync, i.e. a memset node when captured in a graph */
-int tss_zero(void* p, long bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -238,6 +238,29 @@ def gen_frozen():
     print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024))
 
 
+# ----------------------------------------------------------------------------- G5: PSPNet head
+
+def pspnet_cases():
+    ref_psp = importlib.import_module('torch_semantic_segmentation.models.pspnet')
+    return {
+        'psp_ppm': (lambda: ref_psp.PyramidPoolingModule(64, 64, pools=[1, 2, 3, 6]), [(2, 64, 12, 20)]),
+        'psp_net': (lambda: ref_psp.PSPNet(nn.Identity(), 19, 64), [(2, 64, 12, 20)]),
+        'psp_ppm_odd': (lambda: ref_psp.PyramidPoolingModule(32, 64, pools=[1, 2, 3, 6]), [(3, 32, 9, 14)]),
+    }
+
+
+def gen_pspnet():
+    blob = {}
+    for mode in ('train', 'eval'):
+        for name, (make, shapes) in pspnet_cases().items():
+            rec = run_block(make, shapes, training=(mode == 'train'))
+            for k, v in rec.items():
+                blob['%s/%s/%s' % (mode, name, k)] = v
+    path = os.path.join(HERE, 'pspnet.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(blob), 'arrays')
+
+
 # ----------------------------------------------------------------------------- G3c: train step, default init, f32 AND f64
 
 SEEDED_SHAPE = (2, 96, 160)
@@ -288,9 +311,11 @@ def gen_seeded():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['blocks', 'eval', 'train', 'frozen', 'seeded']
+    which = sys.argv[1:] or ['blocks', 'eval', 'train', 'frozen', 'seeded', 'pspnet']
     if 'seeded' in which:
         gen_seeded()
+    if 'pspnet' in which:
+        gen_pspnet()
     if 'blocks' in which:
         gen_blocks()
     if 'eval' in which:

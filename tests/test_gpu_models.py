@@ -444,7 +444,9 @@ def test_host_batch_pipeline_overlaps_h2d_and_decodes_uint8(use_graph):
             pipe.put(*nxt)
             got.append(pipe.step().item())
         got.append(pipe.step().item())
-        assert np.allclose(got, want, rtol=2e-4), (wire, got, want)
+        # the device decode evaluates x * 1/(255 std) - mean/std, the host (x/255 - mean)/std: 1e-7 apart, and train-mode
+        # steps amplify that (tests/test_gpu_fullsize.py): first step tight, later steps loose
+        assert abs(got[0] / want[0] - 1) < 2e-5 and np.allclose(got, want, rtol=2e-4 if wire == 'f32' else 3e-3), (wire, got, want)
         with pytest.raises(RuntimeError):
             pipe.step()
     # the decode kernel itself, bit for bit against the same f32 formula (x * 1/(255 std) - mean/std)

@@ -149,3 +149,21 @@ def test_seeded_default_init_step_bit_identical(golden_dir, name):
             for key in g:
                 if key.startswith(name + '/grad64.'):
                     assert np.array_equal(m.get_parameter(key[len(name) + 8:]).grad.numpy(), g[key]), key
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+@pytest.mark.parametrize('name', sorted(cases.PSP_SHAPES))
+def test_pspnet_head_bit_identical(golden_dir, name, mode):
+    """oracle/aspp.py PyramidPools / PSPNetOracle reproduce TSS/models/pspnet.py (imported by make_golden.py gen_pspnet)."""
+    g = cases.load_npz(os.path.join(golden_dir, 'pspnet.npz'))
+    m = cases.oracle_psp(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    m.train(mode == 'train')
+    xs = [x.requires_grad_(True) for x in cases.psp_inputs(name)]
+    out = m(*xs)
+    out.backward(cases.block_cotangent(out.shape))
+    key = '%s/%s/' % (mode, name)
+    assert np.array_equal(out.detach().numpy(), g[key + 'out'])
+    assert np.array_equal(xs[0].grad.numpy(), g[key + 'dx0'])
+    for pname, p in m.named_parameters():
+        assert np.array_equal(p.grad.numpy(), g[key + 'dw.' + pname]), pname

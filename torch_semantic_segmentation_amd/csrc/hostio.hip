@@ -76,12 +76,4 @@ int tss_decode_batch_u8(const unsigned char* image, int image_is_hwc, const floa
   return tss::check_last("decode_batch_u8");
 }
 
-/* zero `bytes` bytes at p (a memset node inside a captured graph: no kernel launch) */
-int tss_zero(void* p, long bytes, void* stream) {
-  TSS_REQUIRE(bytes >= 0, TSS_ERR_SHAPE);
-  if (bytes == 0) return TSS_OK;
-  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return TSS_ERR_HIP;
-  return tss::check_last("zero");
-}
-
 }  // extern "C"

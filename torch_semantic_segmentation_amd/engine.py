@@ -62,10 +62,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=False):
-        if self.flat_grad.is_cuda:      # hipMemsetAsync: a memset node of the captured step instead of a fill kernel
-            N.call('tss_zero', N.ptr(self.flat_grad), self.flat_grad.numel() * 4, N.stream())
-        else:
-            self.flat_grad.zero_()
+        self.flat_grad.zero_()
 
     def _check_aliases(self):
         """Every p.grad must still be its slice of flat_grad (model.zero_grad(set_to_none=True) or an optimizer-external

@@ -933,6 +933,88 @@ class ConcatUpFn(Function):
         return tuple(grads)
 
 
+def concat(tensors):
+    """torch.cat(tensors, dim=1) of equally sized activation tensors into one NHWC buffer (tss_copy_nhwc per operand; the
+    gradient is a channel slice of the incoming one, no copy).  Channel counts must be multiples of 8."""
+    ts = [to_nhwc(materialize(t)) for t in tensors]
+    if any(t.shape[1] % 8 or t.shape[0] != ts[0].shape[0] or t.shape[2:] != ts[0].shape[2:] or t.dtype != ts[0].dtype for t in ts):
+        raise RuntimeError('concat: operands must share batch / spatial size / dtype and have channel counts that are multiples of 8')
+    return ConcatFn.apply(*ts)
+
+
+class ConcatFn(Function):
+    @staticmethod
+    def forward(ctx, *ts):
+        B, _, H, W = ts[0].shape
+        out = new_nhwc(B, sum(t.shape[1] for t in ts), H, W, ts[0].dtype, ts[0].device)
+        dt, st, off = N.dtype_code(out.dtype), stream(), 0
+        for t in ts:
+            c = t.shape[1]
+            call('tss_copy_nhwc', ptr(t), ld(t), ptr(out[:, off:off + c]), ld(out), npix(t), c, dt, st)
+            off += c
+        ctx.widths = [t.shape[1] for t in ts]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = to_nhwc(dout)
+        grads, off = [], 0
+        for c in ctx.widths:
+            grads.append(dout[:, off:off + c])
+            off += c
+        return tuple(grads)
+
+
+def concat_joined(branches, relu=True):
+    """torch.cat([relu?(bn_i(branch_i)) for i], dim=1): every branch is a Deferred whose pending BatchNorm(+ReLU) is applied
+    while it is written into its channel slice of the result -- one pass per branch, no normalised copy, no concat copy (the
+    parallel branches of an ASPP module).  Backward hands each branch its masked gradient and BatchNorm-backward sums."""
+    ds = [as_deferred(b).take() for b in branches]
+    if any(d.raw.shape[1] % 8 or d.raw.shape[0] != ds[0].raw.shape[0] or d.raw.shape[2:] != ds[0].raw.shape[2:]
+           or d.raw.dtype != ds[0].raw.dtype for d in ds):
+        raise RuntimeError('concat_joined: branches must share batch / spatial size / dtype, channels multiples of 8')
+    cfg = JoinCfg()
+    cfg.links = [d.link for d in ds]
+    cfg.relus = [bool(relu) or bool(d.relu) for d in ds]
+    return ConcatJoinFn.apply(cfg, *[d.raw for d in ds])
+
+
+class ConcatJoinFn(Function):
+    @staticmethod
+    def forward(ctx, cfg, *raws):
+        B, _, H, W = raws[0].shape
+        out = new_nhwc(B, sum(r.shape[1] for r in raws), H, W, raws[0].dtype, raws[0].device)
+        dt, st, off = N.dtype_code(out.dtype), stream(), 0
+        for r, link, relu in zip(raws, cfg.links, cfg.relus):
+            c = r.shape[1]
+            call('tss_join_fwd', ptr(r), ld(r), *_aff(link), None, 0, None, None, None, ptr(out[:, off:off + c]), ld(out),
+                 int(relu), 0.0, None, npix(r), c, dt, st)
+            off += c
+        ctx.cfg = cfg
+        ctx.save_for_backward(out, *raws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, *raws = ctx.saved_tensors
+        cfg = ctx.cfg
+        dout = to_nhwc(dout)
+        dt, st, off, grads = N.dtype_code(dout.dtype), stream(), 0, []
+        for r, link, relu in zip(raws, cfg.links, cfg.relus):
+            c = r.shape[1]
+            dsl, osl = dout[:, off:off + c], out[:, off:off + c]
+            if relu or link is not None:
+                e = new_nhwc(*r.shape, dout.dtype, dout.device) if relu else None
+                call('tss_join_bwd', ptr(dsl), ld(dout), ptr(osl), ld(out), int(relu), ptr(r) if link is not None else None, ld(r),
+                     ptr(link.mean) if link is not None else None, ptr(link.bstats) if link is not None else None,
+                     None, 0, None, None, ptr(e), ld(e) if e is not None else 0, 1.0, npix(r), c, dt, st)
+                grads.append(e if e is not None else dsl)
+            else:
+                grads.append(dsl)
+            off += c
+        return (None, *grads)
+
+
 # ----------------------------------------------------------------------------- pyramid pooling, all arms per launch
 
 fuse_dropout = True    # nn.Dropout after a pending BatchNorm + ReLU rides in the join that materialises it (False: own pass)
@@ -1152,8 +1234,7 @@ class UpsampleCrossEntropyFn(Function):
         target = target.contiguous()
         # one zero-fill for both accumulators: [loss sum, #valid] as f64 in front (16 bytes), the f32 low-res gradient behind
         n = B * h * w * ld(low)
-        zbuf = torch.empty(4 + n, dtype=torch.float32, device=dev)
-        call('tss_zero', ptr(zbuf), zbuf.numel() * 4, stream())
+        zbuf = torch.zeros(4 + n, dtype=torch.float32, device=dev)
         acc = zbuf[:4].view(torch.float64)
         dacc = zbuf[4:].view(B, h, w, ld(low))
         scal = torch.empty(2, dtype=torch.float32, device=dev)
