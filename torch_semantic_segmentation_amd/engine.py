@@ -253,7 +253,10 @@ class Trainer:
             for b, v in saved:
                 b.copy_(v)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # with a live RCCL process group its watchdog thread polls events while we capture: in the default 'global' capture
+        # mode that aborts the capture (seen as a flaky crash); only this thread's calls are checked in 'thread_local' mode
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl') else 'global'
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             loss = self._forward_backward(sx, sy, prologue).detach()
         self._graphs[slot] = (graph, loss)
 

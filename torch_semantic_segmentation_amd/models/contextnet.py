@@ -4,7 +4,7 @@ TSS/models/contextnet.py; arithmetic in the HIP kernels behind include/tss_hip.h
 from torch import nn
 
 from .. import ops
-from ._fused import FusedSequential, HipModel, run
+from ._fused import FusedSequential, HipModel, has_hooks, run
 
 __all__ = ['ContextNet', 'contextnet12', 'contextnet14', 'contextnet18']
 
@@ -54,7 +54,12 @@ class BottleneckBlock(nn.Module):
 
     def forward(self, input):
         x = ops.to_nhwc(ops.materialize(input))
-        d = run(self.conv3, run(self.conv2, run(self.conv1, x)))
+        d = None
+        if not (has_hooks(self.conv1) or has_hooks(self.conv2)):
+            d = ops.expand_dw_unit(x, self.conv1, self.conv2)       # one autograd node: the backward never touches the 6x tensors
+        if d is None:
+            d = run(self.conv2, run(self.conv1, x))
+        d = run(self.conv3, d)
         same = tuple(d.shape) == tuple(x.shape)
         return ops.join(d, x if same else None, relu=True)
 
