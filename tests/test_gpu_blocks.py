@@ -444,14 +444,14 @@ def test_fused_bottleneck_backward_matches_the_layer_by_layer_backward(shape, ci
         x = torch.randn(*shape, device=DEV).to(torch.bfloat16)
         x = ops.to_nhwc(x).detach().requires_grad_(True)
         cot = torch.randn(shape[0], cout, (shape[2] - 1) // stride + 1, (shape[3] - 1) // stride + 1, device=DEV)
-        old = ops.fuse_bottleneck_backward
-        ops.fuse_bottleneck_backward = fused
+        old = ops.fuse_bottleneck_backward, ops.fuse_bottleneck_strides
+        ops.fuse_bottleneck_backward, ops.fuse_bottleneck_strides = fused, (1, 2)
         try:
             out = m(x)
             out.float().backward(cot)
             torch.cuda.synchronize()
         finally:
-            ops.fuse_bottleneck_backward = old
+            ops.fuse_bottleneck_backward, ops.fuse_bottleneck_strides = old
         return (out.detach().float().cpu(), x.grad.float().cpu(), {k: p.grad.float().cpu() for k, p in m.named_parameters()},
                 {k: b.detach().float().cpu() for k, b in m.named_buffers() if b.dtype.is_floating_point})
     o1, dx1, g1, b1 = run(True)

@@ -52,6 +52,15 @@ __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 
 __device__ __forceinline__ float bf_round(float v) { return (float)(T)v; }
 
 struct TileGeom { long b; int iy0, ix0; };
+
+// pixel order inside the 8 x 8 tile.  Stride 1: row-major.  Stride 2: the four 16-pixel MFMA fragments are the four parity
+// classes (py & 1, px & 1) -- every lane of a fragment then sees the SAME set of depthwise taps (1, 2, 2 or 4 of the 9),
+// so the stencil runs 9 tap evaluations per 4 fragments instead of 36 with per-lane selects.
+template <int S>
+__device__ __forceinline__ void pix_of(int p, int& py, int& px) {
+  if (S == 1) { py = p >> 3; px = p & 7; }
+  else { const int pf = p >> 4, fr = p & 15; py = (fr >> 2) * 2 + (pf >> 1); px = (fr & 3) * 2 + (pf & 1); }
+}
 __device__ __forceinline__ TileGeom tile_geom(const BnArgs& g, long t) {
   TileGeom tg;
   tg.b = t / g.tiles_per_img;
@@ -62,7 +71,7 @@ __device__ __forceinline__ TileGeom tile_geom(const BnArgs& g, long t) {
 }
 
 // x tile (8 x 8 pixels x Cin) -> Xs[p][k] (row pitch g.xs, zero beyond Cin up to kwp) and, for pass 1, XT[k][p]
-template <bool WITH_T>
+template <int S, bool WITH_T>
 __device__ __forceinline__ void load_x_tile(const BnArgs& g, const TileGeom& tg, T* Xs, T* XT, int tid) {
   const int nvec = g.Cin >> 3, nvecp = g.kwp >> 3;
   const int total = TP * nvecp;                    // <= 1024
@@ -72,7 +81,9 @@ __device__ __forceinline__ void load_x_tile(const BnArgs& g, const TileGeom& tg,
     const int v = tid + u * NT;
     const int p = v / nvecp, cv = v - p * nvecp;
     const bool ok = v < total && cv < nvec;
-    const long pix = ((tg.b * g.H + tg.iy0 + (ok ? (p >> 3) : 0)) * (long)g.W + tg.ix0 + (ok ? (p & 7) : 0));
+    int py, px;
+    pix_of<S>(ok ? p : 0, py, px);
+    const long pix = ((tg.b * g.H + tg.iy0 + py) * (long)g.W + tg.ix0 + px);
     r[u] = *reinterpret_cast<const uint4*>(g.x + pix * g.ldx + (ok ? cv * 8 : 0));
     if (!ok) r[u] = make_uint4(0u, 0u, 0u, 0u);
   }
@@ -241,9 +252,11 @@ __device__ __forceinline__ void lane_consts(const float* Cst, int cl, LaneC& L) 
 // times the activated input ap[q] are added to the depthwise weight-gradient accumulators accw[t][q] on the way (nothing is
 // kept alive in between: 36 fewer registers than returning the nine values).  cl = lane's first channel inside the chunk.
 template <int S, bool WG>
-__device__ __forceinline__ void stencil(const T* Gw, int py, int px, int cl, const LaneC& L, float e1[4], const float ap[4],
+__device__ __forceinline__ void stencil(const T* Gw, int pf, int fr, int cl, const LaneC& L, float e1[4], const float ap[4],
                                         float (*accw)[4]) {
   constexpr int WW = (S == 1) ? 10 : 5;
+  int py, px;
+  pix_of<S>(pf * 16 + fr, py, px);
 #pragma unroll
   for (int q = 0; q < 4; ++q) e1[q] = 0.f;
 #pragma unroll
@@ -251,21 +264,19 @@ __device__ __forceinline__ void stencil(const T* Gw, int py, int px, int cl, con
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       int wy, wx;
-      bool valid = true;
       if (S == 1) { wy = py + 2 - ky; wx = px + 2 - kx; }
       else {
-        const int dy = py + 1 - ky, dx = px + 1 - kx;          // = 2 * (output coordinate - window origin)
-        valid = ((dy | dx) & 1) == 0;
-        wy = valid ? dy >> 1 : 0; wx = valid ? dx >> 1 : 0;
+        // pf is wave-uniform, so this is a scalar branch: only the taps whose parity matches the fragment's are evaluated
+        if ((((pf >> 1) + 1 - ky) | ((pf & 1) + 1 - kx)) & 1) continue;
+        wy = (py + 1 - ky) >> 1; wx = (px + 1 - kx) >> 1;   // = output coordinate - window origin
       }
       const uint2 r = *reinterpret_cast<const uint2*>(Gw + (wy * WW + wx) * GS + cl);
       const float4 w4 = *reinterpret_cast<const float4*>(L.w9 + (ky * 3 + kx) * MC);
       const float gv[4] = {bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y)}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float gq = valid ? gv[q] : 0.f;
-        e1[q] += gq * wv[q];
-        if (WG) accw[ky * 3 + kx][q] += gq * ap[q];
+        e1[q] += gv[q] * wv[q];
+        if (WG) accw[ky * 3 + kx][q] += gv[q] * ap[q];
       }
     }
 }
@@ -308,13 +319,13 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_chunk_kernel(const BnArgs g) 
   for (long t = split; t < g.ntiles; t += g.nsplit) {
     const TileGeom tg = tile_geom(g, t);
     __syncthreads();                                   // previous tile's reads of Xs / Gw / E1T / XT are done
-    load_x_tile<PASS == 1>(g, tg, Xs, XT, tid);
+    load_x_tile<S, PASS == 1>(g, tg, Xs, XT, tid);
     stage_window<S>(g, tg, m0, Cst, Gw, tid);
     __syncthreads();
 #pragma unroll 1
     for (int pf = 0; pf < 4; ++pf) {
       const f32x4 acc = mfma_y1(g, Xs, W1s, wave, fr, fq, pf);
-      const int p = pf * 16 + fr, py = p >> 3, px = p & 7;
+      const int p = pf * 16 + fr;
       float y1[4], a1[4], ap[4], e1[4], g1v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_chunk_kernel(const BnArgs g) 
         a1[q] = y1[q] * L.s1[q] + L.sh1[q];
         ap[q] = fmaxf(a1[q], 0.f);
       }
-      stencil<S, PASS == 1>(Gw, py, px, cl, L, e1, ap, accw);
+      stencil<S, PASS == 1>(Gw, pf, fr, cl, L, e1, ap, accw);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float e = a1[q] > 0.f ? bf_round(e1[q]) : 0.f;
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_dx_kernel(const BnArgs g) {
   for (long t = blockIdx.x; t < g.ntiles; t += gridDim.x) {
     const TileGeom tg = tile_geom(g, t);
     __syncthreads();
-    load_x_tile<false>(g, tg, Xs, nullptr, tid);
+    load_x_tile<S, false>(g, tg, Xs, nullptr, tid);
     f32x4 dacc[NKF];
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) dacc[kf] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_dx_kernel(const BnArgs g) {
 #pragma unroll 1
       for (int pf = 0; pf < 4; ++pf) {
         const f32x4 acc = mfma_y1(g, Xs, W1s, wave, fr, fq, pf);
-        const int p = pf * 16 + fr, py = p >> 3, px = p & 7;
+        const int p = pf * 16 + fr;
         float e1[4];
-        stencil<S, false>(Gw, py, px, cl, L, e1, nullptr, nullptr);
+        stencil<S, false>(Gw, pf, fr, cl, L, e1, nullptr, nullptr);
         bf16x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -463,8 +474,9 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_dx_kernel(const BnArgs g) {
       }
     }
     // lane: channels k = 16 kf + 4 fq + q of pixel p = 16 wave + fr
-    const int p = wave * 16 + fr;
-    const long pix = (tg.b * g.H + tg.iy0 + (p >> 3)) * (long)g.W + tg.ix0 + (p & 7);
+    int py, px;
+    pix_of<S>(wave * 16 + fr, py, px);
+    const long pix = (tg.b * g.H + tg.iy0 + py) * (long)g.W + tg.ix0 + px;
     T* drow = g.dx + pix * g.lddx + fq * 4;
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf) {
@@ -518,7 +530,7 @@ int fill(BnArgs& g, int B, int H, int W, int Cin, int M, int stride) {
   g.kwp = (Cin + 31) & ~31; g.xs = g.kwp + 8;
   g.nchunk = (M + MC - 1) / MC;
   g.tiles_x = W / 8; g.tiles_per_img = (H / 8) * g.tiles_x; g.ntiles = (long)B * g.tiles_per_img;
-  long ns = 1024 / g.nchunk;
+  long ns = 768 / g.nchunk;            // 3 resident blocks per CU x 256 CUs: one full round of blocks, no tail
   if (ns > g.ntiles) ns = g.ntiles;
   if (ns > TSS_STAT_SLABS) ns = TSS_STAT_SLABS;
   if (ns < 1) ns = 1;
@@ -624,7 +636,7 @@ int tss_bneck_bwd_data(const void* x, long ldx, const void* w1_bf16, const void*
   g.ga1 = ga1; g.gb1 = gb1; g.gce1 = gce1; g.dx = (T*)dx; g.lddx = lddx;
   const size_t sm = smem_dx(g);
   hipStream_t st = (hipStream_t)stream;
-  long grid = g.ntiles < 1024 ? g.ntiles : 1024;
+  long grid = g.ntiles < 768 ? g.ntiles : 768;
   const double bytes = (2.0 * B * H * W * Cin + 2.0 * B * g.Ho * g.Wo * M * (stride == 1 ? 1.56 : 1.56)) * 2.0;
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, st, bytes, 4.0 * B * H * W * (double)Cin * M);
   static tss::DevOnce o1, o2;

@@ -660,7 +660,10 @@ class ConvUnitFn(Function):
 # BottleneckBlock: conv1 (1x1, Cin -> 6 Cin) + conv2 (depthwise 3x3) as ONE autograd node whose backward neither reads the
 # expanded tensor y1 nor materialises the gradient e1 between the two layers (csrc/bneck.hip: both are recomputed per tile
 # from the 6x smaller block input).  The forward is the two ordinary units; y1 is dropped as soon as conv2 has consumed it.
-fuse_bottleneck_backward = os.environ.get('TSS_FUSE_BNECK', '1') == '1'
+fuse_bottleneck_backward = os.environ.get('TSS_FUSE_BNECK', '1') != '0'
+# measured on MI355X (profiles/README.md): the fused backward wins for the stride-2 blocks (their expanded tensor is 4x the
+# depthwise output and only 9 tap evaluations per 4 pixels are needed), not yet for stride 1; TSS_FUSE_BNECK=all fuses both
+fuse_bottleneck_strides = (1, 2) if os.environ.get('TSS_FUSE_BNECK') == 'all' else (2,)
 
 
 class _Capture:
@@ -708,6 +711,8 @@ def expand_dw_unit(x, block1, block2):
         return None
     B, Cin, H, W = x.shape
     s = c2.stride[0]
+    if s not in fuse_bottleneck_strides:
+        return None
     if not N.lib().tss_bneck_bwd_supported(B, H, W, Cin, c1.out_channels, s, N.TSS_BF16):
         return None
     if (bn1.training and B * H * W <= 1):
