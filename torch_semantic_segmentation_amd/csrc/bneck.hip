@@ -70,7 +70,7 @@ __device__ __forceinline__ TileGeom tile_geom(const BnArgs& g, long t) {
   return tg;
 }
 
-// x tile (8 x 8 pixels x Cin) -> Xs[p][k] (row pitch g.xs, zero beyond Cin up to kwp) and, for pass 1, XT[k][p]
+// x tile (8 x 8 pixels x Cin) -> Xs[p][k] (row pitch g.xs, zero beyond Cin up to kwp)
 template <int S, bool WITH_T>
 __device__ __forceinline__ void load_x_tile(const BnArgs& g, const TileGeom& tg, T* Xs, T* XT, int tid) {
   const int nvec = g.Cin >> 3, nvecp = g.kwp >> 3;
@@ -93,15 +93,24 @@ __device__ __forceinline__ void load_x_tile(const BnArgs& g, const TileGeom& tg,
     if (v < total) {
       const int p = v / nvecp, cv = v - p * nvecp;
       *reinterpret_cast<uint4*>(Xs + p * g.xs + cv * 8) = r[u];
-      if (WITH_T) {
-        const uint32_t w[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
-        unsigned short* xt = reinterpret_cast<unsigned short*>(XT);
+    }
+  }
+}
+
+// XT[k][p] = Xs[p][k] (pass 1: the pixel index is the contraction of the weight gradient).  Lane = pixel, so the 2-byte
+// stores of a wave go to 64 consecutive pixels of one row: conflict-free.  (Transposing while the tile is loaded -- lanes =
+// channel vectors of a few pixels -- put 64 lanes on two LDS banks: the 1x1 weight-gradient sweep took 2.2x the statistics
+// sweep.)  Call between the barrier that publishes Xs and the barrier in front of the MFMA that reads XT.
+__device__ __forceinline__ void transpose_x(const BnArgs& g, const T* Xs, T* XT, int tid) {
+  const int p = tid & 63, nvecp = g.kwp >> 3;
+  unsigned short* xt = reinterpret_cast<unsigned short*>(XT);
+  for (int cv = tid >> 6; cv < nvecp; cv += NT / 64) {
+    const uint4 r = *reinterpret_cast<const uint4*>(Xs + p * g.xs + cv * 8);
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          xt[(cv * 8 + 2 * h) * PS + p] = (unsigned short)(w[h] & 0xffffu);
-          xt[(cv * 8 + 2 * h + 1) * PS + p] = (unsigned short)(w[h] >> 16);
-        }
-      }
+    for (int h = 0; h < 4; ++h) {
+      xt[(cv * 8 + 2 * h) * PS + p] = (unsigned short)(w[h] & 0xffffu);
+      xt[(cv * 8 + 2 * h + 1) * PS + p] = (unsigned short)(w[h] >> 16);
     }
   }
 }
@@ -322,6 +331,7 @@ __global__ __launch_bounds__(NT, 2) void bneck_bwd_chunk_kernel(const BnArgs g) 
     load_x_tile<S, PASS == 1>(g, tg, Xs, XT, tid);
     stage_window<S>(g, tg, m0, Cst, Gw, tid);
     __syncthreads();
+    if constexpr (PASS == 1) transpose_x(g, Xs, XT, tid);
 #pragma unroll 1
     for (int pf = 0; pf < 4; ++pf) {
       const f32x4 acc = mfma_y1(g, Xs, W1s, wave, fr, fq, pf);

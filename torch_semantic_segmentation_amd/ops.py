@@ -660,9 +660,10 @@ class ConvUnitFn(Function):
 # BottleneckBlock: conv1 (1x1, Cin -> 6 Cin) + conv2 (depthwise 3x3) as ONE autograd node whose backward neither reads the
 # expanded tensor y1 nor materialises the gradient e1 between the two layers (csrc/bneck.hip: both are recomputed per tile
 # from the 6x smaller block input).  The forward is the two ordinary units; y1 is dropped as soon as conv2 has consumed it.
-fuse_bottleneck_backward = os.environ.get('TSS_FUSE_BNECK', '1') != '0'
-# measured on MI355X (profiles/README.md): the fused backward wins for the stride-2 blocks (their expanded tensor is 4x the
-# depthwise output and only 9 tap evaluations per 4 pixels are needed), not yet for stride 1; TSS_FUSE_BNECK=all fuses both
+# OPT-IN (TSS_FUSE_BNECK=1: stride-2 blocks, =all: every block): numerically validated (tests/test_gpu_blocks.py), but as
+# measured on MI355X in round 2 (profiles/README.md) its three recompute sweeps are VALU / latency bound and lose to the
+# layer-by-layer kernels (features.0.0 of FastSCNN at 8 x 1024 x 2048: 140 + 250 + 277 us against 433 us), so it is off.
+fuse_bottleneck_backward = os.environ.get('TSS_FUSE_BNECK', '0') in ('1', 'all')
 fuse_bottleneck_strides = (1, 2) if os.environ.get('TSS_FUSE_BNECK') == 'all' else (2,)
 
 
