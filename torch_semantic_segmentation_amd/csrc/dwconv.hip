@@ -9,6 +9,7 @@
 //   backward-weight dW[c][tap] += sum_p g(p,c) * a(p+tap, c)
 // The producer's BatchNorm(+ReLU) is applied on load and this conv's BatchNorm backward is applied on
 // load of (e, y): neither normalised activations nor input gradients of BN ever touch HBM.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -740,6 +741,10 @@ __global__ __launch_bounds__(NT_MAX, (WG ? WG_WAVES : (D == 1 ? 2 : 1))) void dw
       // parity / border rows contribute nothing: their loads are clamped to row 0 and masked (no branch around the
       // loads, so the rows can overlap)
       const bool vy = ny >= 0 && oyr * S == ny && oyr < g.Hout;
+      // stride 2: only output rows of matching parity reach an input row -- 1 or 2 of the 3 taps rows.  The input row of a
+      // strip is (nearly always) the same for every lane of a wave, so a tap row nobody needs is skipped by a scalar branch
+      // instead of being loaded (clamped), transformed and masked: half of the work of the stride-2 layers.
+      if (!WG && S == 2 && __builtin_amdgcn_ballot_w64(vy) == 0ull) return;
       const int oy = vy ? oyr : 0;
       const long rowq = (b * g.Hout + oy) * (long)g.Wout;
       // first output column of the window: stride 1: x0 - D, then every D-th column; stride 2: x0 / 2 (x0 is a multiple of 4)
@@ -772,40 +777,51 @@ __global__ __launch_bounds__(NT_MAX, (WG ? WG_WAVES : (D == 1 ? 2 : 1))) void dw
         wv[kx][0] = w0.x; wv[kx][1] = w0.y; wv[kx][2] = w0.z; wv[kx][3] = w0.w;
         wv[kx][4] = w1.x; wv[kx][5] = w1.y; wv[kx][6] = w1.z; wv[kx][7] = w1.w;
       }
+      // interior strips (every tap of every lane inside the image: all but the border rows / columns) take a copy of the
+      // loop without the per-element validity selects -- 8 v_cndmask per loaded vector, 18 % of the kernel's vector instructions
+      bool all_ok = true;
 #pragma unroll
-      for (int c = 0; c < NCOL; ++c) {
-        float gvv[8];
-        V8<T>::unpack(re[c], gvv);
-        if (yr) {
-          float yv[8];
-          V8<T>::unpack(ry[c], yv);
+      for (int c = 0; c < NCOL; ++c) all_ok = all_ok && ok[c];
+      const bool interior = __builtin_amdgcn_ballot_w64(!all_ok) == 0ull;
+      auto columns = [&](auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float gj = FOLD ? ca[j] * gvv[j] + (cb[j] * yv[j] + kd[j]) : ca[j] * (gvv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
-            gvv[j] = ok[c] ? gj : 0.f;
+        for (int c = 0; c < NCOL; ++c) {
+          float gvv[8];
+          V8<T>::unpack(re[c], gvv);
+          if (yr) {
+            float yv[8];
+            V8<T>::unpack(ry[c], yv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float gj = FOLD ? ca[j] * gvv[j] + (cb[j] * yv[j] + kd[j]) : ca[j] * (gvv[j] - ce[j]) + cb[j] * (yv[j] - cm[j]);
+              gvv[j] = (!MASKED || ok[c]) ? gj : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gvv[j] = (!MASKED || ok[c]) ? ca[j] * gvv[j] : 0.f;
           }
-        } else {
+          // input pixel i of the strip sees output column (oc0 + c) through tap kx when
+          //   stride 1:  x0 + i*D - (kx-1)*D == x0 - D + c*D  <=>  i + (2 - kx) == c       (kx counted from the flip)
+          //   stride 2:  x0 + i - (kx-1)   == 2 * (x0/2 + c)  <=>  kx == i + 1 - 2c
 #pragma unroll
-          for (int j = 0; j < 8; ++j) gvv[j] = ok[c] ? ca[j] * gvv[j] : 0.f;
-        }
-        // input pixel i of the strip sees output column (oc0 + c) through tap kx when
-        //   stride 1:  x0 + i*D - (kx-1)*D == x0 - D + c*D  <=>  i + (2 - kx) == c       (kx counted from the flip)
-        //   stride 2:  x0 + i - (kx-1)   == 2 * (x0/2 + c)  <=>  kx == i + 1 - 2c
+          for (int i = 0; i < SWW; ++i)
 #pragma unroll
-        for (int i = 0; i < SWW; ++i)
+            for (int kx = 0; kx < 3; ++kx) {
+              const bool hit = (S == 1) ? (i + (2 - kx) == c) : (kx == i + 1 - 2 * c);
+              if (hit) {
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const bool hit = (S == 1) ? (i + (2 - kx) == c) : (kx == i + 1 - 2 * c);
-            if (hit) {
+                for (int j = 0; j < 8; ++j) acc[i][j] += gvv[j] * wv[kx][j];
+                if (WG) {
 #pragma unroll
-              for (int j = 0; j < 8; ++j) acc[i][j] += gvv[j] * wv[kx][j];
-              if (WG) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) accw[WG ? ky * 3 + kx : 0][j] += gvv[j] * av[WG ? i : 0][j];
+                  for (int j = 0; j < 8; ++j) accw[WG ? ky * 3 + kx : 0][j] += gvv[j] * av[WG ? i : 0][j];
+                }
               }
             }
-          }
-      }
+        }
+      };
+      // (stride 2 only: the stride-1 instances are at 236 registers and the second copy of the loop makes them spill)
+      if (!WG && S == 2 && interior) columns(std::false_type{}); else columns(std::true_type{});
     };
     if constexpr (WG) {      // unrolled: the accumulator index must be static
 #pragma unroll
