@@ -24,6 +24,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# sum over the convolutions of (input + output elements) at 8 x 3 x 1024 x 2048 (fastscnn_aspp: the FastSCNN trunk
+# without its classifier (1819 M - 307 M) + the ASPP head at 1/8 resolution: 4 x (128 + 128) + (640 + 128) + (128 + 128) + (128 + 19)
+# channels x 262 k pixels = 576 M)
+S_REF = {'fastscnn': 1819e6, 'contextnet14': 2086e6, 'fastscnn_aspp': 2088e6}
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the measured float4 copy rate on MI355X (79 % of spec)
 MFMA_BF16_PEAK_TF = 2500.0
@@ -34,7 +38,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18'])
+    ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18', 'fastscnn_aspp'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--mode', default='train', choices=['train', 'eval'],
                     help='eval = SURVEY config C5: eval-mode no-grad forward, default 1 x 3 x 2048 x 4096 (never the headline line)')
@@ -67,8 +71,9 @@ def build_model(name):
     import importlib
     F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
     C = importlib.import_module('torch_semantic_segmentation_amd.models.contextnet')
+    A = importlib.import_module('torch_semantic_segmentation_amd.models.aspp')
     ctor = {'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12, 'contextnet14': C.contextnet14,
-            'contextnet18': C.contextnet18}[name]
+            'contextnet18': C.contextnet18, 'fastscnn_aspp': A.fastscnn_aspp}[name]
     torch.manual_seed(0)
     return ctor(3, 19), tssa
 
@@ -83,7 +88,7 @@ def synthetic(batch, h, w, seed, device):
 
 def algorithmic_step_bytes(model_name, batch, h, w, esz):
     """A_step = 3*S*b + 4*U*b + 8*T, S scaled from the 8x1024x2048 figures."""
-    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}.get(model_name)
+    S_ref = S_REF.get(model_name)
     if S_ref is None:
         return None
     scale = batch * h * w / (8.0 * 1024 * 2048)
@@ -250,7 +255,7 @@ def extra_eval(model_name, h, w, device, steps, warmup):
             fwd(x)
         elapsed, chunks, _ = timed_steps(lambda: fwd(x), steps, device)
     ms = 1e3 * elapsed / steps
-    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}[model_name]
+    S_ref = S_REF[model_name]
     a = (S_ref * h * w / (8.0 * 1024 * 2048) + 19.0 * h * w) * 2
     res = {'workload': '%s eval-mode forward incl. x8 head, 1 x 3 x %d x %d, bf16' % (model_name, h, w),
            'ms_per_step': round(ms, 3), 'images_per_sec': round(steps / elapsed, 2), 'steps': steps, 'chunks': chunks,
@@ -292,7 +297,7 @@ def main_eval(args):
     elapsed = time.perf_counter() - t0
     esz = 2 if dtype == torch.bfloat16 else 4
     ms = 1e3 * elapsed / args.steps
-    S_ref = {'fastscnn': 1819e6, 'contextnet14': 2086e6}.get(args.model)
+    S_ref = S_REF.get(args.model)
     res = {'metric': 'images/sec (eval forward) %s %dx%d bs=%d' % (args.model, args.height, args.width, args.batch),
            'value': round(args.batch * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps,
            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -491,7 +496,7 @@ def main():
             n_extra = max(50, min(args.steps, 100))
             out['extra'] = {'contextnet14': extra_train('contextnet14', 8, 1024, 2048, device, n_extra, 5),
                             'eval_c5': extra_eval('fastscnn', 2048, 4096, device, n_extra, 5),
-                            'eval_c5_contextnet14': extra_eval('contextnet14', 2048, 4096, device, n_extra, 5)}
+                            'eval_c5_aspp': extra_eval('fastscnn_aspp', 2048, 4096, device, n_extra, 5)}
         if args.stock:
             out['stock_pytorch_rocm_images_per_sec'] = round(stock_gpu(args.model, args.batch, args.height, args.width, device), 2)
         if world == 1 and not args.no_cpu_baseline:

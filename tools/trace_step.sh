@@ -5,7 +5,7 @@ set -e
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $root/gpurun_out/trace
-rocprofv3 --kernel-trace -d $root/gpurun_out/trace --output-format csv -- python3 $root/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline "$@" > /dev/null 2>&1
+rocprofv3 --kernel-trace -d $root/gpurun_out/trace --output-format csv -- python3 $root/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-roofline --no-extras "$@" > /dev/null 2>&1
 cd $root
 f=$(ls gpurun_out/trace/*/*kernel_trace.csv | head -1)
 python3 tools/trace_gaps.py $f gpurun_out/timeline.txt > gpurun_out/gaps.txt
