@@ -126,6 +126,28 @@ int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
 int tss_im2col3x3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                   void* col, int B, int H, int W, int C, int dil, int dtype, void* stream);
 
+/* ---- factorized (1-D) dense convolution, 3 taps along one axis, padding = dilation, stride 1 ------------------------------
+ * replaces: nn.Conv2d(C, C, (1,3), padding=(0,d), dilation=(1,d)) / nn.Conv2d(C, C, (3,1), padding=(d,0), dilation=(d,1)) of
+ *           FactorizedConvBlock TSS/models/lednet.py:157-180 (SS-nbt block :95-124) and TSS/models/esnet.py:83-166.
+ * axis 0: along W (the 1x3 kernel), axis 1: along H (3x1).  fwd takes the weight as [3][N][Cin], bwd_data as [3][Cin][N]
+ * (tss_permute_wtaps with T = 3 from torch's [N][Cin][1][3] / [N][Cin][3][1]); bwd_weight accumulates into the torch layout. */
+int tss_permute_wtaps(const float* w /* [N][Cin][T] */, float* w_tnc, float* w_tcn, int N, int Cin, int T, void* stream);
+int tss_conv1d3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                    int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                           float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* channel_shuffle(x, groups) TSS/models/lednet.py:183-188: y[:, j * groups + i] = x[:, i * (C / groups) + j] (its own inverse with
+ * groups' = C / groups: the backward is the same entry) */
+int tss_channel_shuffle(const void* x, long ldx, void* y, long ldy, long P, int C, int groups, int dtype, void* stream);
+
 /* ---- stem: 3x3 stride-s conv on the NCHW image (Cin*9 <= 64), NHWC output ----------------------------
  * replaces: nn.Conv2d(in_channels,32,3,stride=2,padding=1) TSS/models/fastscnn.py:30, TSS/models/contextnet.py:38,48. */
 int tss_stem3x3_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,

@@ -83,3 +83,34 @@ class PSPNetOracle(nn.Module):
     def forward(self, x):
         feat = self.backbone(x)
         return self.classifier(torch.cat([feat, self.ppm(feat)], dim=1))
+
+
+# ----------------------------------------------------------------------------- LEDNet split-shuffle unit (TSS/models/lednet.py:95-124,157-188)
+
+def factorized(channels, dilation=1, act=True):
+    mods = [nn.Conv2d(channels, channels, (1, 3), padding=(0, dilation), dilation=(1, dilation), bias=False), nn.ReLU(inplace=True),
+            nn.Conv2d(channels, channels, (3, 1), padding=(dilation, 0), dilation=(dilation, 1), bias=False), nn.BatchNorm2d(channels)]
+    if act:
+        mods.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*mods)
+
+
+def shuffle(x, groups):
+    b, c, h, w = x.shape
+    return x.reshape(b, groups, c // groups, h, w).transpose(1, 2).reshape(b, c, h, w)
+
+
+class SSnbt(nn.Module):
+    def __init__(self, channels, dilation=1, dropout_p=0.0):
+        super().__init__()
+        half = channels // 2
+        self.left = nn.Sequential(factorized(half), factorized(half, dilation, act=False))
+        self.right = nn.Sequential(factorized(half), factorized(half, dilation, act=False))
+        self.activation = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout2d(p=dropout_p)
+
+    def forward(self, x):
+        left, right = torch.chunk(x, 2, 1)
+        y = torch.cat([self.left(left), self.right(right)], dim=1)
+        y = self.dropout(y)
+        return shuffle(self.activation(x + y), 2)

@@ -242,10 +242,15 @@ def gen_frozen():
 
 def pspnet_cases():
     ref_psp = importlib.import_module('torch_semantic_segmentation.models.pspnet')
+    ref_led = importlib.import_module('torch_semantic_segmentation.models.lednet')
     return {
         'psp_ppm': (lambda: ref_psp.PyramidPoolingModule(64, 64, pools=[1, 2, 3, 6]), [(2, 64, 12, 20)]),
         'psp_net': (lambda: ref_psp.PSPNet(nn.Identity(), 19, 64), [(2, 64, 12, 20)]),
         'psp_ppm_odd': (lambda: ref_psp.PyramidPoolingModule(32, 64, pools=[1, 2, 3, 6]), [(3, 32, 9, 14)]),
+        # LEDNet split-shuffle-non-bottleneck unit (TSS/models/lednet.py:95-124), dilations of the encoder's stages
+        'led_ssnbt_d1': (lambda: ref_led.SSnbtBlock(64, 64, dilation=1), [(2, 64, 12, 20)]),
+        'led_ssnbt_d5': (lambda: ref_led.SSnbtBlock(128, 128, dilation=5), [(2, 128, 12, 20)]),
+        'led_ssnbt_d9': (lambda: ref_led.SSnbtBlock(32, 32, dilation=9), [(2, 32, 24, 10)]),
     }
 
 

@@ -54,6 +54,7 @@ struct GemmArgs {
   const float* c0; const float* c1; const float* c2; const float* c3;
   int a_relu, a0_f32;
   int Hin, Win, Hout, Wout, stride, dil, tap_sign, Cin;
+  int tap0, tstep1;       // A_TAPS: local tap t is tap (tap0 + t * (tstep1 + 1)) of the 3x3 grid -- (0, 0): all nine; (3, 0): the 1x3 row; (1, 2): the 3x1 column
   // weights: element (n, k, tap) at w[n*wrs + k*wcs + tap*wts]
   const float* w; long wrs, wcs, wts;
   const float* bias;
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       const bool pow_map = (NT % nvec) == 0;
       const int row0 = tid / nvec, cv0 = tid - row0 * nvec, rstep = pow_map ? NT / nvec : 0;
       if (MODE != A_STEM) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+        const int tgrid = g.tap0 + tap * (g.tstep1 + 1);
+        const int ky = tgrid / 3, kx = tgrid - ky * 3;
         const T* a0 = reinterpret_cast<const T*>(g.a0);
         const T* a1 = reinterpret_cast<const T*>(g.a1);
         (void)a1;
@@ -620,6 +622,49 @@ int tss_conv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   }
   TSS_REQUIRE(w_tcn, TSS_ERR_SHAPE);
   return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, bytes);
+}
+
+// ---- factorized (1-D) dense convolutions: nn.Conv2d(C, C, (1,3) | (3,1), padding = (0,d) | (d,0), dilation = (1,d) | (d,1)) of
+// FactorizedConvBlock, TSS/models/lednet.py:157-180 (and esnet.py:83-166).  Same implicit-GEMM kernel as the dense 3x3 with three
+// of its nine taps: axis 0 = along W (the 1x3 conv: taps 3, 4, 5 of the grid), axis 1 = along H (3x1: taps 1, 4, 7).
+int tss_conv1d3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                    int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && dil >= 1 &&
+              (axis == 0 || axis == 1) && w_tnc, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = 1; g.Cin = Cin;
+  g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;
+  g.P = (long)B * H * W; g.KD = Cin; g.ND = N; g.ntaps = 3; g.mode = A_TAPS;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
+  g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin; g.bias = bias;
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)g.P * (Cin + N) * esz(dtype));
+}
+
+int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (N % 8) == 0 && (Cin % 4) == 0 && (lde % 8) == 0 && lde >= N && (ldei % 4) == 0 && ldei >= Cin &&
+              (axis == 0 || axis == 1) && w_tcn, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  GemmArgs g = {};
+  g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = -1; g.Cin = N;
+  g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;
+  g.P = (long)B * H * W; g.KD = N; g.ND = Cin; g.ntaps = 3; g.mode = A_TAPS;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr;
+  if (yraw) { g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu; } else { g.c0 = ga; }
+  g.w = w_tcn; g.wrs = N; g.wcs = 1; g.wts = (long)Cin * N;
+  g.y = e_in; g.ldy = ldei; g.stats = bstats;
+  g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream,
+                (double)g.P * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * esz(dtype));
 }
 
 int tss_get_option(int key) { return key == TSS_OPT_DISABLE_FAST_PATHS ? g_tss_disable_fast : -1; }

@@ -491,6 +491,39 @@ __global__ void permute_w3x3_kernel(const float* w, float* w_tnc, float* w_tcn, 
   }
 }
 
+__global__ void permute_wtaps_kernel(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, int T) {
+  const long total = (long)N * Cin * T;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % T);
+    const long nc = i / T;
+    const int c = (int)(nc % Cin), n = (int)(nc / Cin);
+    const float v = w[i];
+    if (w_tnc) w_tnc[((long)tap * N + n) * Cin + c] = v;
+    if (w_tcn) w_tcn[((long)tap * Cin + c) * N + n] = v;
+  }
+}
+
+// channel_shuffle(x, groups) of TSS/models/lednet.py:183-188: out[:, j * groups + i] = x[:, i * (C / groups) + j].  One lane
+// = 8 consecutive OUTPUT channels of one pixel (a 16-byte store); its 8 sources are gathered from the same pixel row.
+template <typename T>
+__global__ __launch_bounds__(NT) void channel_shuffle_kernel(const T* x, long ldx, T* y, long ldy, long P, int C, int groups) {
+  const int CV = C / 8, cpg = C / groups;
+  const long total = P * CV;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long pix = i / CV;
+    const int cv = (int)(i - pix * CV);
+    const T* row = x + pix * ldx;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int co = cv * 8 + j;                       // output channel = jj * groups + ii
+      const int ii = co % groups, jj = co / groups;
+      v[j] = (float)row[ii * cpg + jj];
+    }
+    V8<T>::store(y + pix * ldy + cv * 8, v);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ AdamW
 // state = {step, bias_correction1, bias_correction2_sqrt}; torch.optim.AdamW arithmetic, single tensor.
 __global__ void adamw_tick_kernel(float* state, float beta1, float beta2) {
@@ -699,6 +732,31 @@ int tss_permute_w3x3(const float* w, float* w_tnc, float* w_tcn, int N, int Cin,
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(permute_w3x3_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, w, w_tnc, w_tcn, N, Cin);
   return tss::check_last("permute_w3x3");
+}
+
+int tss_permute_wtaps(const float* w, float* w_tnc, float* w_tcn, int N, int Cin, int T, void* stream) {
+  TSS_REQUIRE(N > 0 && Cin > 0 && T > 0, TSS_ERR_SHAPE);
+  const long total = (long)N * Cin * T;
+  long grid = (total + NT - 1) / NT;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(permute_wtaps_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, w, w_tnc, w_tcn, N, Cin, T);
+  return tss::check_last("permute_wtaps");
+}
+
+int tss_channel_shuffle(const void* x, long ldx, void* y, long ldy, long P, int C, int groups, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && (C % 8) == 0 && groups > 0 && (C % groups) == 0 && ldx >= C && (ldy % 8) == 0 && ldy >= C, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(y), TSS_ERR_ALIGN);
+  if (P == 0) return TSS_OK;
+  const long total = P * (C / 8);
+  long grid = (total + NT - 1) / NT;
+  if (grid > 2048) grid = 2048;
+  tss::ProfScope prof(TSS_K_COPY, (hipStream_t)stream, 2.0 * P * C * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(channel_shuffle_kernel<bf16_t>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, P, C, groups);
+  else
+    hipLaunchKernelGGL(channel_shuffle_kernel<float>, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, P, C, groups);
+  return tss::check_last("channel_shuffle");
 }
 
 int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, void* stream) {

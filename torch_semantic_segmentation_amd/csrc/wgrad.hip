@@ -53,6 +53,7 @@ struct WgradArgs {
   const float* ga; const float* gb; const float* gce; const float* gmu;
   const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_f32;
   int Hin, Win, Hout, Wout, stride, dil, Cin;
+  int tap0, tstep1;               // as in convgemm.hip GemmArgs: which taps of the 3x3 grid the ntaps local taps are
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
   float* ws;                       // wgfast: partial tiles [tile][nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
@@ -145,7 +146,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
   const long HWo = (long)g.Hout * g.Wout;
-  const int ky = tap / 3, kx = tap - ky * 3;
+  const int tgrid = g.tap0 + tap * (g.tstep1 + 1);
+  const int ky = tgrid / 3, kx = tgrid - ky * 3;
 
   for (long s = s_begin; s < s_end; ++s) {
     const long p0 = s * PT;
@@ -684,6 +686,25 @@ int tss_conv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   g.dw = dw; g.drs = (long)Cin * 9; g.dcs = 9; g.dts = 1;  // torch layout [N][Cin][3][3]
   return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
                 ((double)g.P * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin) * esz(dtype));
+}
+
+int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                           float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin &&
+              (axis == 0 || axis == 1) && dil >= 1, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  WgradArgs g = {};
+  g.Hin = H; g.Win = W; g.stride = 1; g.dil = dil; g.Cin = Cin; g.Hout = H; g.Wout = W;
+  g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;
+  g.P = (long)B * H * W; g.ND = N; g.KD = Cin; g.ntaps = 3; g.mode = A_TAPS;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.dw = dw; g.drs = (long)Cin * 3; g.dcs = 3; g.dts = 1;  // torch layout [N][Cin][1][3] / [N][Cin][3][1]
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
+                ((double)g.P * N * (yraw ? 2 : 1) + (double)g.P * Cin) * esz(dtype));
 }
 
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,

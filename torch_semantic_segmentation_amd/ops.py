@@ -356,6 +356,16 @@ class UnitCfg:
 
 def _classify(conv, x_is_image):
     k = conv.kernel_size
+    if tuple(k) in ((1, 3), (3, 1)):
+        # factorized convolution (TSS/models/lednet.py:157-180): 3 taps along one axis, padding = dilation on that axis
+        ax = 0 if tuple(k) == (1, 3) else 1                 # 0: along W, 1: along H
+        d = conv.dilation[1 - ax]
+        want_pad, want_dil = ((0, d), (1, d)) if ax == 0 else ((d, 0), (d, 1))
+        if (conv.padding_mode != 'zeros' or conv.groups != 1 or tuple(conv.stride) != (1, 1) or tuple(conv.padding) != want_pad
+                or tuple(conv.dilation) != want_dil or x_is_image):
+            raise NotImplementedError('HIP path: 1x3 / 3x1 convolutions must be dense, stride 1, padding = dilation on the '
+                                      'kernel axis: %r' % conv)
+        return 'dense1d_w' if ax == 0 else 'dense1d_h', 1, d
     if conv.padding_mode != 'zeros' or k[0] != k[1] or conv.stride[0] != conv.stride[1] \
             or conv.dilation[0] != conv.dilation[1] or conv.padding[0] != conv.padding[1]:
         raise NotImplementedError('HIP path: square kernels/strides/dilations with zero padding only: %r' % conv)
@@ -491,6 +501,11 @@ class ConvUnitFn(Function):
                 call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
             call('tss_conv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(w_tnc16),
                  ptr(y), ld(y), stats, B, Hin, Win, cfg.cin, Cout, s, d, dt, st)
+        elif cfg.kind in ('dense1d_w', 'dense1d_h'):
+            w_tnc = torch.empty((3, Cout, cfg.cin), dtype=torch.float32, device=dev)
+            call('tss_permute_wtaps', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, 3, st)
+            call('tss_conv1d3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(bias), ptr(y), ld(y), stats,
+                 B, Hin, Win, cfg.cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
         else:  # stem
             if bias is not None:
                 raise NotImplementedError('HIP path: stem convolution with bias')
@@ -607,6 +622,9 @@ class ConvUnitFn(Function):
                 fused_dw = bool(defer and fuse_dw_backward and N.lib().tss_dwconv3x3_bwd_fused_supported(Cout, s, d, dt))
                 if not fused_dw:
                     call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
+            elif cfg.kind in ('dense1d_w', 'dense1d_h'):
+                call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout,
+                     0 if cfg.kind == 'dense1d_w' else 1, d, dt, wst)
             elif (e.dtype == torch.bfloat16 and s == 1 and y is not None and (Cin * 9) % 8 == 0 and Cout % 8 == 0
                   and not N.fast_paths_disabled()):
                 # unfold once (bf16 [P][Cin*9], column c*9 + tap), then the pointwise MFMA weight-gradient kernel with
@@ -632,6 +650,11 @@ class ConvUnitFn(Function):
                 elif cfg.kind == 'dw':
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, B, Hin, Win, Cout, s, d, dt, st)
+                elif cfg.kind in ('dense1d_w', 'dense1d_h'):
+                    w_tcn = torch.empty((3, Cin, Cout), dtype=torch.float32, device=dev)
+                    call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Cout, Cin, 3, st)
+                    call('tss_conv1d3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
+                         B, Hin, Win, Cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
                 else:
                     if s != 1:
                         raise NotImplementedError('HIP path: input gradient of a strided dense 3x3 convolution')
@@ -1065,6 +1088,32 @@ class ConcatUpFn(Function):
             call('tss_bilinear_nhwc_bwd', ptr(sl), ld(dout), ptr(db), ld(db), ptr(tmp), B, hb, wb, H, W, cb, dt, st)
             grads.append(db)
         return tuple(grads)
+
+
+def channel_shuffle(x, groups):
+    """channel_shuffle of TSS/models/lednet.py:183-188 on an NHWC activation (the channel index is the fastest axis, so this
+    is a permutation inside every pixel row)."""
+    x = to_nhwc(materialize(x))
+    if x.shape[1] % groups or x.shape[1] % 8:
+        raise RuntimeError('channel_shuffle: channels must be a multiple of groups and of 8')
+    return ChannelShuffleFn.apply(x, int(groups))
+
+
+class ChannelShuffleFn(Function):
+    @staticmethod
+    def forward(ctx, x, groups):
+        y = new_nhwc(*x.shape, x.dtype, x.device)
+        call('tss_channel_shuffle', ptr(x), ld(x), ptr(y), ld(y), npix(x), x.shape[1], groups, N.dtype_code(x.dtype), stream())
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = to_nhwc(dy)
+        dx = new_nhwc(*dy.shape, dy.dtype, dy.device)
+        call('tss_channel_shuffle', ptr(dy), ld(dy), ptr(dx), ld(dx), npix(dy), dy.shape[1], dy.shape[1] // ctx.groups,
+             N.dtype_code(dy.dtype), stream())
+        return dx, None
 
 
 def concat(tensors):
