@@ -77,8 +77,9 @@ def product_chain(spec):
             d = kw.get('dilation', 1)
             blocks.append(F.DWConv2dBlock(cin, cout, kernel_size=3, padding=d, stride=kw.get('stride', 1), dilation=d,
                                           use_activation=act))
-        else:   # dense 3x3 / stem
-            blocks.append(F.Conv2dBlock(cin, cout, kernel_size=3, padding=1, stride=kw.get('stride', 1), use_activation=act))
+        else:   # dense 3x3 (dilated: the ASPP branches) / stem
+            d = kw.get('dilation', 1)
+            blocks.append(F.Conv2dBlock(cin, cout, kernel_size=3, padding=d, dilation=d, stride=kw.get('stride', 1), use_activation=act))
     return FusedSequential(*blocks)
 
 
@@ -91,7 +92,7 @@ def oracle_chain(spec):
         elif kind == 'dw':
             blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), dilation=kw.get('dilation', 1), depthwise=True, act=act))
         else:
-            blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), act=act))
+            blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), dilation=kw.get('dilation', 1), act=act))
     return nn.Sequential(*blocks)
 
 
@@ -260,6 +261,10 @@ DENSE = [
     # ContextNet context.7: ConvBlock(128, 128, 3) between two 1x1 units: conv3x3_lean fwd / bwd-data + im2col wgrad
     ('dense3x3_128', [('pw', 96, 128, {}), ('dense', 128, 128, {}), ('pw', 128, 128, {'act': False})], (2, 96, 20, 70)),
     ('dense3x3_64_32', [('pw', 32, 64, {}), ('dense', 64, 32, {}), ('pw', 32, 32, {})], (2, 32, 9, 130)),
+    # atrous branches of the ASPP head (rates 6, 12, 18): the same LDS-halo kernel with a 3 x (64 + 2 D)-pixel halo
+    ('dense3x3_128_d6', [('pw', 64, 128, {}), ('dense', 128, 128, {'dilation': 6}), ('pw', 128, 64, {'act': False})], (2, 64, 30, 70)),
+    ('dense3x3_128_d18', [('pw', 64, 128, {}), ('dense', 128, 128, {'dilation': 18}), ('pw', 128, 64, {'act': False})], (1, 64, 40, 150)),
+    ('dense3x3_64_d12', [('pw', 32, 64, {}), ('dense', 64, 64, {'dilation': 12}), ('pw', 64, 32, {})], (2, 32, 26, 64)),
     # the 3 -> 32 stride-2 stem from the f32 NCHW image (MFMA forward + weight gradient), then dw + pw as in downsample
     ('stem_dw_pw', [('stem', 3, 32, {'stride': 2}), ('dw', 32, 32, {'stride': 2, 'act': False}), ('pw', 32, 48, {})], (2, 3, 96, 160)),
 ]

@@ -1,5 +1,6 @@
-// Lean bf16 dense 3x3 convolution (stride 1, dilation 1, padding 1): forward and backward-data of
-// ConvBlock(128, 128, 3, padding=1) at the end of ContextNet's context branch (TSS/models/contextnet.py:55).
+// Lean bf16 dense 3x3 convolution (stride 1, padding = dilation <= 18): forward and backward-data of
+// ConvBlock(128, 128, 3, padding=1) at the end of ContextNet's context branch (TSS/models/contextnet.py:55) and of the
+// atrous branches (rates 6 / 12 / 18) of the ASPP head of BASELINE config 5 (models/aspp.py).
 //
 // The generic implicit-GEMM kernel (convgemm.hip, A_TAPS) walks the 9 taps as 9 dependent chunks: per tap it gathers a
 // shifted 128-pixel tile from global memory, restages 64 KB of f32 weights and meets at three barriers -- ~11 us per
@@ -16,11 +17,13 @@
 namespace {
 
 typedef bf16_t T;
-constexpr int NT = 256, TW = 64, HC = TW + 2, HP = 3 * HC, RS = 128 + 8, NCH = 128;
-constexpr int HALFPASS = 7;   // halo passes at 16 pixels per pass (K = 128): ceil(198 / 16) = 13 <= 2 * 7
+constexpr int NT = 256, TW = 64, RS = 128 + 8, NCH = 128;
+constexpr int HALFPASS = 7;   // halo passes per batch at 16 pixels per pass (K = 128): dilation 1: ceil(198 / 16) = 13 <= 2 * 7;
+                              // dilation D <= 18 (the ASPP rates 6 / 12 / 18): 3 (64 + 2 D) <= 300 pixels = 19 passes <= 3 * 7
+constexpr int MAXDIL = 18;    // 3 x 100 halo pixels + two 128 x 128 weight taps = 152.7 KB of the 160 KB of LDS
 
 struct C3Args {
-  int B, H, W, K, N;
+  int B, H, W, K, N, D;                              // D = dilation (padding = dilation)
   const T* a0; long lda0; const T* a1; long lda1;    // fwd: x (a1 unused)   bwd: e, yraw
   const float* c0; const float* c1; const float* c2; const float* c3; int a_relu;
   const T* w9;                                       // [9][N][K]
@@ -32,9 +35,10 @@ struct C3Args {
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ float bits_lo(uint32_t u) { return __uint_as_float(u << 16); }
 
-template <bool BWD>
+template <bool BWD, int NB>
 __global__ __launch_bounds__(NT, 1) void conv3x3_lean_kernel(const C3Args g) {
   extern __shared__ __align__(16) unsigned char smem[];
+  const int D = g.D, HC = TW + 2 * D, HP = 3 * HC;           // halo: 3 rows (y - D, y, y + D) x (64 + 2 D) pixels
   T* Xs = reinterpret_cast<T*>(smem);                        // [HP][RS]
   T* Ws = Xs + HP * RS;                                      // [2][NCH][RS]
   float* Ec = reinterpret_cast<float*>(Ws + 2 * NCH * RS);   // [3][NCH]
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_lean_kernel(const C3Args g) {
       }
     }
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NB; ++half) {
       uint4 ra[HALFPASS], rb[BWD ? HALFPASS : 1];
       bool okp[HALFPASS];
 #pragma unroll
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_lean_kernel(const C3Args g) {
         if (ps < npass) {
           const int hp = ps * rpp + r;
           const int hr = hp / HC, hc = hp - hr * HC;
-          const int iy = y + hr - 1, ix = x0 + hc - 1;
+          const int iy = y + (hr - 1) * D, ix = x0 + hc - D;
           const bool ok = hp < HP && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
           okp[u] = ok;
           const long q = ok ? (brow + iy) * g.W + ix : pc;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_lean_kernel(const C3Args g) {
       if (tap < 8) load_tap(tap + 1);                        // lands under this tap's MFMAs
       const int dy = g.tap_sign * (tap / 3 - 1), dx = g.tap_sign * (tap % 3 - 1);
       if (nfr > 0) {
-        const T* xrow = Xs + ((dy + 1) * HC + wm * 32 + fr + dx + 1) * RS + fq * 8;
+        const T* xrow = Xs + ((dy + 1) * HC + wm * 32 + fr + (dx + 1) * D) * RS + fq * 8;
         const T* wrow = Ws + (tap & 1) * NCH * RS + (wn * 64 + fr) * RS + fq * 8;
         for (int ks = 0; ks < nks; ++ks) {
           bf16x8 xf[2];
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_lean_kernel(const C3Args g) {
   }
 }
 
-constexpr size_t SMEM = (size_t)(HP + 2 * NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
+inline size_t smem_bytes(int dil) { return (size_t)(3 * (TW + 2 * dil) + 2 * NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float); }
 
 __global__ __launch_bounds__(256) void permute_w3x3_bf16_kernel(const float* w, T* w_tnc, T* w_tcn, int N, int Cin) {
   const long total = (long)N * Cin * 9;
@@ -333,20 +337,25 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* x, long ldx, co
   }
 }
 
-template <bool BWD>
-void launch_lean(const C3Args& g, hipStream_t stream) {
+template <bool BWD, int NB>
+void launch_lean_nb(const C3Args& g, hipStream_t stream) {
   static tss::DevOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_lean_kernel<BWD>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_lean_kernel<BWD, NB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes(NB == 2 ? 1 : MAXDIL));
   }
   const long ntiles = (long)g.B * g.H * ((g.W + TW - 1) / TW);
   const int grid = (int)(ntiles < TSS_STAT_SLABS ? ntiles : TSS_STAT_SLABS);
-  hipLaunchKernelGGL((conv3x3_lean_kernel<BWD>), dim3(grid), dim3(NT), SMEM, stream, g);
+  hipLaunchKernelGGL((conv3x3_lean_kernel<BWD, NB>), dim3(grid), dim3(NT), smem_bytes(g.D), stream, g);
+}
+
+template <bool BWD>
+void launch_lean(const C3Args& g, hipStream_t stream) {
+  if (g.D == 1) launch_lean_nb<BWD, 2>(g, stream); else launch_lean_nb<BWD, 3>(g, stream);
 }
 
 bool shape_ok(int K, int N, int stride, int dil) {
-  return stride == 1 && dil == 1 && (K == 32 || K == 64 || K == 128) && N >= 16 && N <= NCH && (N % 16) == 0;
+  return stride == 1 && dil >= 1 && dil <= MAXDIL && (K == 32 || K == 64 || K == 128) && N >= 16 && N <= NCH && (N % 16) == 0;
 }
 
 }  // namespace
@@ -358,7 +367,7 @@ bool tss_conv3x3_lean_fwd(const void* x, long ldx, const float* in_mean, const f
                           int stride, int dil, hipStream_t stream) {
   if (!shape_ok(Cin, N, stride, dil) || (ldx % 8) != 0 || (ldy % 4) != 0 || (long)B * H * W == 0) return false;
   C3Args g = {};
-  g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = N;
+  g.B = B; g.H = H; g.W = W; g.K = Cin; g.N = N; g.D = dil;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w9 = (const T*)w9; g.tap_sign = 1; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
   launch_lean<false>(g, stream);
@@ -375,7 +384,7 @@ bool tss_conv3x3_lean_bwd_data(const void* e, long lde, const void* yraw, long l
       (xraw && (ldx % 4) != 0) || (long)B * H * W == 0)
     return false;
   C3Args g = {};
-  g.B = B; g.H = H; g.W = W; g.K = N; g.N = Cin;
+  g.B = B; g.H = H; g.W = W; g.K = N; g.N = Cin; g.D = dil;
   g.a0 = (const T*)e; g.lda0 = lde; g.a1 = (const T*)yraw; g.lda1 = ldyr;
   g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu;
   g.w9 = (const T*)w9t; g.tap_sign = -1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;

@@ -174,7 +174,7 @@ class EvalAffines:
 
 def _conv3x3_lean(dtype, k, n, stride, dil):
     """Domain of the LDS-halo dense 3x3 kernel (conv3x3.hip): contraction k, outputs n."""
-    return (dtype == torch.bfloat16 and stride == 1 and dil == 1 and k in (32, 64, 128) and n % 16 == 0 and 16 <= n <= 128
+    return (dtype == torch.bfloat16 and stride == 1 and 1 <= dil <= 18 and k in (32, 64, 128) and n % 16 == 0 and 16 <= n <= 128
             and not N.fast_paths_disabled())
 
 
