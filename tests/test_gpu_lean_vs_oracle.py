@@ -272,8 +272,14 @@ DENSE = [
 
 @pytest.mark.parametrize('case', DENSE, ids=[c[0] for c in DENSE])
 def test_dense3x3_and_stem_lean_kernels_vs_f64_oracle(case):
+    from torch_semantic_segmentation_amd import ops
     name, spec, shape = case
-    bad = check(name, *run_case(spec, shape))
+    old = ops.conv3x3_lean_max_dilation
+    ops.conv3x3_lean_max_dilation = 18          # the dilated instances are opt-in in the product (slower on large maps): test them anyway
+    try:
+        bad = check(name, *run_case(spec, shape))
+    finally:
+        ops.conv3x3_lean_max_dilation = old
     assert not bad, bad
 
 

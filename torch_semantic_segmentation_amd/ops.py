@@ -172,9 +172,16 @@ class EvalAffines:
         return False
 
 
+# The LDS-halo dense 3x3 kernel handles dilation <= 18, but it restages its nine 32 KB weight taps for every 64-pixel tile: on
+# the 131 k-pixel map of BASELINE config 5 the three atrous branches of the ASPP head were 0.25 ms SLOWER through it than through
+# the implicit-GEMM tap loop (3.41 vs 3.15 ms per image, profiles/README.md), so dilated convolutions stay on the general kernel
+# unless this is raised (A/B: TSS_CONV3X3_LEAN_MAXDIL=18).
+conv3x3_lean_max_dilation = int(os.environ.get('TSS_CONV3X3_LEAN_MAXDIL', '1'))
+
+
 def _conv3x3_lean(dtype, k, n, stride, dil):
     """Domain of the LDS-halo dense 3x3 kernel (conv3x3.hip): contraction k, outputs n."""
-    return (dtype == torch.bfloat16 and stride == 1 and 1 <= dil <= 18 and k in (32, 64, 128) and n % 16 == 0 and 16 <= n <= 128
+    return (dtype == torch.bfloat16 and stride == 1 and 1 <= dil <= conv3x3_lean_max_dilation and k in (32, 64, 128) and n % 16 == 0 and 16 <= n <= 128
             and not N.fast_paths_disabled())
 
 
