@@ -4,6 +4,7 @@
 //   * join backward: e = dout * relu'(out) plus the per-channel sums the two BN-backwards need
 //   * dropout (counter-based Philox, mask recomputed in backward), bias gradient, 3x3 weight
 //     re-layout, fused flat AdamW
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -412,13 +413,13 @@ __global__ __launch_bounds__(NT) void join_bwd_kernel(const JoinArgs g) {
   }
 }
 
-int join_geometry(JoinArgs& g, int* threads, int* grid) {
+int join_geometry(JoinArgs& g, int* threads, int* grid, long max_blocks = TSS_STAT_SLABS) {
   if (g.C <= 0 || (g.C % 8) != 0 || g.C > NT * 8) return TSS_ERR_SHAPE;
   g.CV = g.C / 8;
   g.NPL = NT / g.CV;
   *threads = (g.CV * g.NPL + 63) / 64 * 64;
   const long tiles = (g.P + g.NPL - 1) / g.NPL;
-  long gsz = tiles < TSS_STAT_SLABS ? tiles : TSS_STAT_SLABS;  // one statistics slab row per block
+  long gsz = tiles < max_blocks ? tiles : max_blocks;          // backward: one statistics slab row per block
   if (gsz < 1) gsz = 1;
   *grid = (int)gsz;
   return TSS_OK;
@@ -652,7 +653,9 @@ int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, cons
   g.out = out; g.ldo = ldo; g.relu = relu; g.P = P; g.C = C;
   g.drop_p = seed_slot ? drop_p : 0.f; g.seed_slot = seed_slot; g.dscale = 1.f;
   int threads, grid;
-  const int rc = join_geometry(g, &threads, &grid);
+  // the forward writes no slab rows, so its grid is not tied to their count: 2048 blocks = 8 per CU keep twice the bytes in flight
+  static const long fwd_blocks = getenv("TSS_JOIN_FWD_BLOCKS") ? atol(getenv("TSS_JOIN_FWD_BLOCKS")) : 2048;
+  const int rc = join_geometry(g, &threads, &grid, fwd_blocks);
   if (rc) return rc;
   if (P == 0) return TSS_OK;
   tss::ProfScope prof(TSS_K_JOIN_FWD, (hipStream_t)stream, (double)P * C * (b ? 3 : 2) * esz(dtype), 0);
