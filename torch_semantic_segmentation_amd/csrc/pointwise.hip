@@ -653,8 +653,9 @@ int tss_join_fwd(const void* a, long lda, const float* ma, const float* sa, cons
   g.out = out; g.ldo = ldo; g.relu = relu; g.P = P; g.C = C;
   g.drop_p = seed_slot ? drop_p : 0.f; g.seed_slot = seed_slot; g.dscale = 1.f;
   int threads, grid;
-  // the forward writes no slab rows, so its grid is not tied to their count: 2048 blocks = 8 per CU keep twice the bytes in flight
-  static const long fwd_blocks = getenv("TSS_JOIN_FWD_BLOCKS") ? atol(getenv("TSS_JOIN_FWD_BLOCKS")) : 2048;
+  // the forward writes no slab rows, so its grid is not tied to their count -- but more blocks are not faster (A/B in round 2:
+  // 512 / 1024 / 2048 / 4096 blocks -> 6.315 / 6.330 / 6.340 / 6.352 ms per step)
+  static const long fwd_blocks = getenv("TSS_JOIN_FWD_BLOCKS") ? atol(getenv("TSS_JOIN_FWD_BLOCKS")) : 512;
   const int rc = join_geometry(g, &threads, &grid, fwd_blocks);
   if (rc) return rc;
   if (P == 0) return TSS_OK;
