@@ -36,3 +36,19 @@ for (B, C, H, W) in ((8, 128, 128, 256), (8, 128, 256, 512), (8, 32, 512, 1024),
     print('tss_copy_nhwc  %dx%dx%dx%d  %6.0f MB/tensor  %7.1f us  %6.0f GB/s' % (B, C, H, W, mb, t, 2 * mb / t * 1e3))
     del a, b, out, dout, e
     torch.cuda.empty_cache()
+
+# the same join on a ROTATING working set (many distinct buffers, as inside a training step where every kernel touches tensors
+# nobody has touched for milliseconds): separates "cold TLB / cold cache" from the kernel itself
+B, C, H, W = 8, 128, 128, 256
+for nsets in (1, 4, 16, 48):
+    sets = [[ops.new_nhwc(B, C, H, W, torch.bfloat16, dev).normal_() for _ in range(3)] for _ in range(nsets)]
+    mean = torch.zeros(C, device=dev); sc = torch.ones(C, device=dev)
+    P, st = B * H * W, N.stream()
+    mb = sets[0][0].numel() * 2 / 1e6
+    def sweep():
+        for a, b, out in sets:
+            N.call('tss_join_fwd', N.ptr(a), C, N.ptr(mean), N.ptr(sc), N.ptr(mean), N.ptr(b), C, N.ptr(mean), N.ptr(sc), N.ptr(mean), N.ptr(out), C, 1, 0.0, None, P, C, 1, st)
+    t = timeit(sweep, n=5) / nsets
+    print('join_fwd 2 in, %2d rotating sets (%5.0f MB working set): %7.1f us per launch  %6.0f GB/s' % (nsets, 3 * mb * nsets, t, 3 * mb / t * 1e3))
+    del sets
+    torch.cuda.empty_cache()
