@@ -47,11 +47,12 @@ class direct_grads:
 
 
 # Launch a layer's weight gradient on a side stream, concurrently with its input gradient (ConvUnitFn.backward).
-overlap_wgrad = False   # measured: no gain on MI355X once the kernels are pipelined (9.88 ms off vs 9.84-9.95 ms on)
+overlap_wgrad = os.environ.get('TSS_OVERLAP_WGRAD', '0') == '1'   # measured: no gain on MI355X once the kernels are pipelined (9.88 ms off vs 9.84-9.95 ms on)
 # depthwise layers: input gradient and weight gradient from one kernel (tss_dwconv3x3_bwd_fused) instead of two launches.
 # Opt-in: correct, reads e / y / x once, but measured slower on MI355X (1 wave/SIMD, see dwconv.hip): 7.28 vs 7.05 ms/step.
 fuse_dw_backward = os.environ.get('TSS_FUSE_DW_BWD', '0') == '1'
-overlap_max_elems = 48 << 20   # only layers too small to fill the chip on their own (large ones just contend)
+overlap_max_elems = int(os.environ.get('TSS_OVERLAP_MAX', str(48 << 20)))   # only layers too small to fill the chip on their own (large ones just contend)
+overlap_min_elems = int(os.environ.get('TSS_OVERLAP_MIN', '0'))
 _side_streams = {}
 
 
@@ -603,7 +604,7 @@ class ConvUnitFn(Function):
         # and a HIP-graph capture sees two parallel branches)
         main = torch.cuda.current_stream(dev)
         side = _side_stream(dev) if (overlap_wgrad and need_dx and cfg.kind != 'stem'
-                                    and P * (Cin + Cout) <= overlap_max_elems) else None
+                                    and overlap_min_elems <= P * (Cin + Cout) <= overlap_max_elems) else None
         wst = st
         if side is not None:
             side.wait_stream(main)
