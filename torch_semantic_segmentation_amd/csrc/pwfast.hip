@@ -195,12 +195,16 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   // trip runs under tile t's MFMA + epilogue instead of being exposed at the top of every tile (counters: 76 % of the
   // wave cycles were waits at 2 waves/SIMD).  ra/rb are dead between the LDS store and the next tile: no extra VGPRs.
   uint4 ra[NP], rb[NP];
+  // bwd: the producer's raw output under this lane's outputs (ReLU mask + statistics in the epilogue) travels with the same
+  // prefetch, one tile ahead: issued at the top of the tile that needs it, it was 0.5 us old when the epilogue wanted it
+  // (LDS store + barrier + 32 MFMAs) against a memory latency of 1.5-2 us -- every tile stalled on it.
+  uint2 rxn[4][MF];
   auto issue_loads = [&](long tile_) {
+    const long q0 = tile_ * TM;
+    const bool full_ = q0 + TM <= g.P;
     if (lane_on) {
       // tile base + this lane's channel vector; rows outside the tile / the tensor re-read row 0 of the tile (always
       // valid) and are zeroed after the load, so no load is ever out of bounds and none is predicated
-      const long q0 = tile_ * TM;
-      const bool full_ = q0 + TM <= g.P;
       const T* pa = g.a0 + q0 * g.lda0 + (cv_real ? cv * 8 : 0);
       const T* pb = BWD ? g.a1 + q0 * g.lda1 + (cv_real ? cv * 8 : 0) : nullptr;
       const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
@@ -212,6 +216,20 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
           const int rr = ok ? row : 0;
           ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
           if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
+        }
+      }
+    }
+    if (BWD && g.xm) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nfr) {
+          const int nn = nlane + i * 16;
+          const T* px = g.xm + q0 * g.ldxm + (nn < g.N ? nn : n0);
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const int row = wm * (TM / 2) + m * 16 + fr;
+            rxn[i][m] = *reinterpret_cast<const uint2*>(px + (long)((full_ || q0 + row < g.P) ? row : 0) * g.ldxm);
+          }
         }
       }
     }
@@ -262,23 +280,13 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     const bool full = p0 + TM <= g.P;
     __syncthreads();  // previous tile's MFMA reads of Xs are done
 
-    // bwd: the producer's raw output under this lane's outputs, needed by the epilogue (ReLU mask, statistics).
-    // Issued here, behind the A-tile loads already in flight and ahead of the next tile's prefetch: loads return in
-    // order, so the transform below waits only for the A tile and the epilogue only for these.
+    // bwd: the producer's raw output under this lane's outputs for THIS tile: prefetched with the tile (issue_loads)
     uint2 rxm[4][MF];
     if (BWD && g.xm) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < nfr) {
-          const int nn = nlane + i * 16;
-          const T* px = g.xm + p0 * g.ldxm + (nn < g.N ? nn : n0);
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int m = 0; m < MF; ++m) {
-            const int row = wm * (TM / 2) + m * 16 + fr;
-            rxm[i][m] = *reinterpret_cast<const uint2*>(px + (long)((full || p0 + row < g.P) ? row : 0) * g.ldxm);
-          }
-        }
-      }
+        for (int m = 0; m < MF; ++m) rxm[i][m] = rxn[i][m];
     }
 
     // ---- normalise + store the A tile whose loads are in flight
@@ -513,6 +521,25 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     for (int m = 0; m < MF; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bwd: the producer's raw output under this lane's outputs (epilogue: ReLU mask + statistics), requested before the chunk
+    // loop so that it arrives under the contraction instead of stalling every store of the epilogue
+    constexpr bool PREX = TM <= 64;    // 128-pixel tiles: 32 more registers spill (212 B); they keep the load in the epilogue
+    uint2 rxm[PREX ? 4 : 1][PREX ? MF : 1];
+    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm + nlane : nullptr;
+    if (PREX && BWD && g.xm) {
+      const T* xrow_p = g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i < nfr) {
+          const int nn = nlane + i * 16;
+#pragma unroll
+          for (int m = 0; m < MF; ++m) {
+            const bool pin = full || (p0 + wm * (TM / 2) + m * 16 + fr < g.P);
+            rxm[PREX ? i : 0][PREX ? m : 0] = *reinterpret_cast<const uint2*>(xrow_p + (pin ? (long)m * 16 * g.ldxm : -(long)(wm * (TM / 2) + fr) * g.ldxm) + (nn < g.N ? nn : n0));
+          }
+        }
+      }
+    }
 
     for (int kc = 0; kc < nkc; ++kc) {
       const int kb = kc * KMAX;
@@ -601,7 +628,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
 
     // ---- epilogue (identical to pwfast_kernel)
     T* yrow = g.y + (p0 + wm * (TM / 2) + fr) * g.ldy + nlane;
-    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm + nlane : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nfr) {
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : acc[m][i][q] + bs[q];
             if (BWD && g.xm) {
-              const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
+              const uint2 xr = PREX ? rxm[PREX ? i : 0][PREX ? m : 0] : *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
               if (g.m_relu) {
 #pragma unroll
