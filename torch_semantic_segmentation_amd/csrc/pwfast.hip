@@ -513,6 +513,34 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
   const int nlane = n0 + wn * 64 + fq * 4;
 
+  constexpr bool PIPE = TM <= 64;
+  uint4 ra[NP], rb[NP];
+  auto issue_a = [&](int kc_, long p0_, bool full_) {     // A tile of chunk kc_ of the tile at p0_ -> ra / rb
+    const int kb_ = kc_ * KMAX;
+    const int kw_ = (K - kb_ < KMAX) ? (K - kb_) : KMAX;
+    const int kwp_ = (kw_ + 31) & ~31;
+    const int nvec_ = kw_ >> 3, nvecp_ = kwp_ >> 3;
+    const int rpp_ = NT / nvecp_, npass_ = (TM + rpp_ - 1) / rpp_;
+    const int cv_ = tid % nvecp_, r_ = tid / nvecp_;
+    if (r_ < rpp_) {
+      const bool cvr = cv_ < nvec_;
+      const T* pa = g.a0 + p0_ * g.lda0 + kb_ + (cvr ? cv_ * 8 : 0);
+      const T* pb = BWD ? g.a1 + p0_ * g.lda1 + kb_ + (cvr ? cv_ * 8 : 0) : nullptr;
+      const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        if (ps < npass_) {
+          const int row = ps * rpp_ + r_;
+          const bool ok = row < TM && (full_ || p0_ + row < g.P);
+          const int rr = ok ? row : 0;
+          ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
+          if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
+        }
+      }
+    }
+  };
+  if (PIPE && t_begin < t_end) issue_a(0, t_begin * TM, t_begin * TM + TM <= g.P);
+
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * TM;
     const bool full = p0 + TM <= g.P;
@@ -551,23 +579,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       const bool lane_on = r < rpp, cv_real = cv < nvec;
       __syncthreads();  // previous chunk's MFMA reads are done (and Ck is visible on the first pass)
 
-      // A-tile loads first (the HBM round trip), then the weight chunk from L2, then normalise + store
-      uint4 ra[NP], rb[NP];
-      if (lane_on) {
-        const T* pa = g.a0 + p0 * g.lda0 + kb + (cv_real ? cv * 8 : 0);
-        const T* pb = BWD ? g.a1 + p0 * g.lda1 + kb + (cv_real ? cv * 8 : 0) : nullptr;
-        const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
-#pragma unroll
-        for (int ps = 0; ps < NP; ++ps) {
-          if (ps < npass) {
-            const int row = ps * rpp + r;
-            const bool ok = row < TM && (full || p0 + row < g.P);
-            const int rr = ok ? row : 0;
-            ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
-            if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
-          }
-        }
-      }
+      // ra / rb hold THIS chunk's A tile: requested one chunk ahead (PIPE: tiles of <= 64 pixels, where the registers are
+      // free), right after the previous chunk's tile went to LDS, so the HBM round trip ran under its MFMAs; otherwise here.
+      if (!PIPE) issue_a(kc, p0, full);
       if (g.wb) stage_weights_bf16(Ws, g.wb, g.ldwb, n0, ncw, nrows, kb, kw, kwp, tid);
       else stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, kb, kw, kwp, tid);
       if (lane_on) {
@@ -603,6 +617,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
             }
           }
         }
+      }
+      if (PIPE) {      // the next chunk's (or the next tile's first) A tile: in flight under this chunk's MFMAs
+        if (kc + 1 < nkc) issue_a(kc + 1, p0, full);
+        else if (tile + g.gslots < t_end) issue_a(0, (tile + g.gslots) * TM, (tile + g.gslots) * TM + TM <= g.P);
       }
       __syncthreads();
 
