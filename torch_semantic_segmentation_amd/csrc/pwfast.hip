@@ -441,6 +441,8 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 // backward-data of the "expand" convs, contraction over N = 192..768).  Same tiles and epilogue; the contraction is
 // walked in 128-channel chunks with the accumulators kept in registers, each chunk's weights restaged from L2 and
 // the folded BatchNorm constants of all K channels resident in LDS.
+// (Round 2: requesting the epilogue's x values before the chunk loop, and the next chunk's A tile under the current chunk's
+// MFMAs, cost 18-37 registers, the third wave per SIMD of the 32-pixel instance and 2-5 us per launch: measured, reverted.)
 constexpr int KTOT = 768;
 // TM = pixels per tile: 128, or 64 when a layer has fewer than 256 tiles of 128 (the 1/32-resolution project / expand
 // layers: 128 blocks of 128 pixels left half the CUs idle behind a five-chunk serial chain).
@@ -513,34 +515,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
   const int nlane = n0 + wn * 64 + fq * 4;
 
-  constexpr bool PIPE = TM <= 64;
-  uint4 ra[NP], rb[NP];
-  auto issue_a = [&](int kc_, long p0_, bool full_) {     // A tile of chunk kc_ of the tile at p0_ -> ra / rb
-    const int kb_ = kc_ * KMAX;
-    const int kw_ = (K - kb_ < KMAX) ? (K - kb_) : KMAX;
-    const int kwp_ = (kw_ + 31) & ~31;
-    const int nvec_ = kw_ >> 3, nvecp_ = kwp_ >> 3;
-    const int rpp_ = NT / nvecp_, npass_ = (TM + rpp_ - 1) / rpp_;
-    const int cv_ = tid % nvecp_, r_ = tid / nvecp_;
-    if (r_ < rpp_) {
-      const bool cvr = cv_ < nvec_;
-      const T* pa = g.a0 + p0_ * g.lda0 + kb_ + (cvr ? cv_ * 8 : 0);
-      const T* pb = BWD ? g.a1 + p0_ * g.lda1 + kb_ + (cvr ? cv_ * 8 : 0) : nullptr;
-      const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
-#pragma unroll
-      for (int ps = 0; ps < NP; ++ps) {
-        if (ps < npass_) {
-          const int row = ps * rpp_ + r_;
-          const bool ok = row < TM && (full_ || p0_ + row < g.P);
-          const int rr = ok ? row : 0;
-          ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
-          if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
-        }
-      }
-    }
-  };
-  if (PIPE && t_begin < t_end) issue_a(0, t_begin * TM, t_begin * TM + TM <= g.P);
-
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * TM;
     const bool full = p0 + TM <= g.P;
@@ -549,25 +523,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     for (int m = 0; m < MF; ++m)
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // bwd: the producer's raw output under this lane's outputs (epilogue: ReLU mask + statistics), requested before the chunk
-    // loop so that it arrives under the contraction instead of stalling every store of the epilogue
-    constexpr bool PREX = TM <= 64;    // 128-pixel tiles: 32 more registers spill (212 B); they keep the load in the epilogue
-    uint2 rxm[PREX ? 4 : 1][PREX ? MF : 1];
-    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm + nlane : nullptr;
-    if (PREX && BWD && g.xm) {
-      const T* xrow_p = g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (i < nfr) {
-          const int nn = nlane + i * 16;
-#pragma unroll
-          for (int m = 0; m < MF; ++m) {
-            const bool pin = full || (p0 + wm * (TM / 2) + m * 16 + fr < g.P);
-            rxm[PREX ? i : 0][PREX ? m : 0] = *reinterpret_cast<const uint2*>(xrow_p + (pin ? (long)m * 16 * g.ldxm : -(long)(wm * (TM / 2) + fr) * g.ldxm) + (nn < g.N ? nn : n0));
-          }
-        }
-      }
-    }
 
     for (int kc = 0; kc < nkc; ++kc) {
       const int kb = kc * KMAX;
@@ -579,9 +534,23 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       const bool lane_on = r < rpp, cv_real = cv < nvec;
       __syncthreads();  // previous chunk's MFMA reads are done (and Ck is visible on the first pass)
 
-      // ra / rb hold THIS chunk's A tile: requested one chunk ahead (PIPE: tiles of <= 64 pixels, where the registers are
-      // free), right after the previous chunk's tile went to LDS, so the HBM round trip ran under its MFMAs; otherwise here.
-      if (!PIPE) issue_a(kc, p0, full);
+      // A-tile loads first (the HBM round trip), then the weight chunk from L2, then normalise + store
+      uint4 ra[NP], rb[NP];
+      if (lane_on) {
+        const T* pa = g.a0 + p0 * g.lda0 + kb + (cv_real ? cv * 8 : 0);
+        const T* pb = BWD ? g.a1 + p0 * g.lda1 + kb + (cv_real ? cv * 8 : 0) : nullptr;
+        const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+          if (ps < npass) {
+            const int row = ps * rpp + r;
+            const bool ok = row < TM && (full || p0 + row < g.P);
+            const int rr = ok ? row : 0;
+            ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
+            if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
+          }
+        }
+      }
       if (g.wb) stage_weights_bf16(Ws, g.wb, g.ldwb, n0, ncw, nrows, kb, kw, kwp, tid);
       else stage_weights(Ws, g.w, g.w_trans, g.w_trans ? (long)g.N : (long)K, n0, ncw, nrows, kb, kw, kwp, tid);
       if (lane_on) {
@@ -618,10 +587,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
           }
         }
       }
-      if (PIPE) {      // the next chunk's (or the next tile's first) A tile: in flight under this chunk's MFMAs
-        if (kc + 1 < nkc) issue_a(kc + 1, p0, full);
-        else if (tile + g.gslots < t_end) issue_a(0, (tile + g.gslots) * TM, (tile + g.gslots) * TM + TM <= g.P);
-      }
       __syncthreads();
 
       if (nfr > 0) {
@@ -646,6 +611,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
 
     // ---- epilogue (identical to pwfast_kernel)
     T* yrow = g.y + (p0 + wm * (TM / 2) + fr) * g.ldy + nlane;
+    const T* xrow_m = BWD && g.xm ? g.xm + (p0 + wm * (TM / 2) + fr) * g.ldxm + nlane : nullptr;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nfr) {
@@ -668,7 +634,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : acc[m][i][q] + bs[q];
             if (BWD && g.xm) {
-              const uint2 xr = PREX ? rxm[PREX ? i : 0][PREX ? m : 0] : *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
+              const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
               if (g.m_relu) {
 #pragma unroll
