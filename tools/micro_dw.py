@@ -1,42 +1,78 @@
 #!/usr/bin/env python
-"""Microbenchmark (GPU box): time individual C-ABI kernels over a size sweep to separate fixed cost from bandwidth."""
-import os, sys, time
+"""Microbenchmark (GPU box): the depthwise 3x3 entry points on the benchmark's own layer shapes, stand-alone, on a rotating
+set of buffers (cold caches, as inside a step).  Prints time, algorithmic GB/s and a checksum of every result so two builds /
+two settings of an A/B switch (TSS_DW_ROLL=0|1) can be compared line by line: the outputs must agree bit for bit."""
+import hashlib
+import os
+import sys
+
 import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from torch_semantic_segmentation_amd import _native as N, ops
+from torch_semantic_segmentation_amd import _native as N, ops  # noqa: E402
 
 dev = 'cuda:0'
-def timeit(fn, n=30):
-    for _ in range(5): fn()
+which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+
+
+def timeit(fn, n=10):
+    for _ in range(2):
+        fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(n): fn()
-    b.record(); torch.cuda.synchronize()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
+
+def digest(t):
+    return hashlib.sha1(t.detach().contiguous().cpu().view(torch.uint8).numpy().tobytes()).hexdigest()[:12]
+
+
 S = N.stat_slabs()
-for C in (32, 128, 384, 576):
-    for (B, H, W) in ((8, 32, 64), (8, 64, 128), (8, 128, 256), (8, 256, 512)):
-        if C * B * H * W > 4e8: continue
-        for stride in (1, 2):
-            x = ops.new_nhwc(B, C, H, W, torch.bfloat16, dev); x.normal_()
-            Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-            y = ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev)
-            w = torch.randn(C, 1, 3, 3, device=dev)
-            stats = torch.empty(S, 2 * C, dtype=torch.float64, device=dev)
-            mean = torch.zeros(C, device=dev); sc = torch.ones(C, device=dev)
-            st = N.stream()
-            f = lambda: N.call('tss_dwconv3x3_fwd', N.ptr(x), C, N.ptr(mean), N.ptr(sc), N.ptr(mean), 1, N.ptr(w), N.ptr(y), C, N.ptr(stats), B, H, W, C, stride, 1, 1, st)
-            f_nostats = lambda: N.call('tss_dwconv3x3_fwd', N.ptr(x), C, None, None, None, 0, N.ptr(w), N.ptr(y), C, None, B, H, W, C, stride, 1, 1, st)
-            t1, t2 = timeit(f), timeit(f_nostats)
-            mb = (x.numel() + y.numel()) * 2 / 1e6
-            print('dw_fwd C=%3d %dx%3dx%3d s%d  %7.1f MB  %7.1f us (%6.0f GB/s)   no-stats/no-affine %7.1f us (%6.0f GB/s)' % (C, B, H, W, stride, mb, t1, mb / t1 * 1e3, t2, mb / t2 * 1e3))
-# copy kernel as the achievable-bandwidth yardstick
-for n in (2**22, 2**24, 2**26, 2**28):
-    a = torch.empty(n, dtype=torch.bfloat16, device=dev); b = torch.empty_like(a)
-    t = timeit(lambda: b.copy_(a))
-    print('torch copy %6.1f MB  %7.1f us  %6.0f GB/s' % (2 * n * 2 / 1e6, t, 2 * n * 2 / 1e6 / t * 1e3))
-    xa = a.view(1, -1, 1, 128).permute(0, 3, 1, 2)
-    t = timeit(lambda: N.call('tss_copy_nhwc', N.ptr(a), 128, N.ptr(b), 128, n // 128, 128, 1, N.stream()))
-    print('tss_copy   %6.1f MB  %7.1f us  %6.0f GB/s' % (2 * n * 2 / 1e6, t, 2 * n * 2 / 1e6 / t * 1e3))
+# (B, C, Hin, Win, stride): FastSCNN's depthwise layers at 8 x 3 x 1024 x 2048, then odd shapes
+LAYERS = ((8, 32, 512, 1024, 2), (8, 48, 256, 512, 2), (8, 384, 128, 256, 2), (8, 384, 64, 128, 1), (8, 384, 64, 128, 2),
+          (8, 576, 32, 64, 1), (8, 768, 32, 64, 1), (8, 128, 128, 256, 1), (2, 24, 37, 53, 1), (2, 200, 37, 53, 2), (1, 8, 5, 7, 1))
+torch.manual_seed(0)
+for (B, C, H, W, s) in LAYERS:
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    nset = max(1, min(8, int(600e6 // (B * C * H * W * 2))))
+    xs = [ops.new_nhwc(B, C, H, W, torch.bfloat16, dev).normal_() for _ in range(nset)]
+    ys = [ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev) for _ in range(nset)]
+    w = torch.randn(C, 9, device=dev) * 0.3
+    mean = torch.randn(C, device=dev) * 0.1
+    sc = torch.rand(C, device=dev) + 0.5
+    bias = torch.randn(C, device=dev) * 0.1
+    stats = torch.empty(S, 2 * C, dtype=torch.float64, device=dev)
+    st = N.stream()
+    if which == 'fwd':
+        def run():
+            for x, y in zip(xs, ys):
+                N.call('tss_dwconv3x3_fwd', N.ptr(x), ops.ld(x), N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(w), N.ptr(y), ops.ld(y),
+                       N.ptr(stats), B, H, W, C, s, 1, N.TSS_BF16, st)
+        os.environ['TSS_DW_ROLL'] = '0'
+        run(); torch.cuda.synchronize()
+        y_ref, st_ref = ys[0].clone(), stats.sum(0)
+        t_ref = timeit(run) / nset
+        os.environ['TSS_DW_ROLL'] = '1'
+        run(); torch.cuda.synchronize()
+        d = (ys[0].float() - y_ref.float()).abs()
+        nz = ((ys[0].view(torch.int16) != y_ref.view(torch.int16)) & (d == 0)).sum().item()
+        print('   vs strip kernel: %d of %d values differ (max abs %.3e), %d differ only in the sign of zero; stats rel %.2e; strip %.1f us' % (
+            (d > 0).sum().item(), d.numel(), d.max().item(), nz, ((stats.sum(0) - st_ref).abs().max() / st_ref.abs().max()).item(), t_ref))
+        if B * C * H * W <= 30e6:     # both against an f64 evaluation of the same layer (rounded to bf16 once)
+            a64 = torch.relu(xs[0].double() * sc.double()[None, :, None, None] + torch.addcmul(bias, mean, sc, value=-1).double()[None, :, None, None])
+            y64 = torch.nn.functional.conv2d(a64, w.double().view(C, 1, 3, 3), stride=s, padding=1, groups=C)
+            r = y64.to(torch.bfloat16)
+            print('   against f64: strip differs in %d values, row-pipelined in %d' % (
+                (y_ref.float() != r.float()).sum().item(), (ys[0].float() != r.float()).sum().item()))
+            del a64, y64, r
+        t = timeit(run) / nset
+        alg = (B * C * H * W + B * C * Ho * Wo) * 2
+        print('dw fwd  %dx%dx%dx%d s%d  %7.1f us  %6.0f GB/s   y %s  stats %s  sum %.6e' % (
+            B, C, H, W, s, t, alg / t / 1e3, digest(ys[0]), digest(stats.sum(0).float()), stats.sum(0)[:C].sum().item()))
+    del xs, ys
+    torch.cuda.empty_cache()

@@ -11,6 +11,7 @@
 // load of (e, y): neither normalised activations nor input gradients of BN ever touch HBM.
 #include <type_traits>
 #include "common.h"
+#include "dwroll.h"
 
 namespace {
 
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(NT_MAX, ((D == 1 && sizeof(T) == 2) ? 3 : 2)) void 
   constexpr bool FOLD = sizeof(T) == 2;
   if (FOLD) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sh[j] -= mu[j] * sc[j];
+    for (int j = 0; j < 8; ++j) sh[j] = __builtin_fmaf(-mu[j], sc[j], sh[j]);
   }
   __syncthreads();
   const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
@@ -963,6 +964,10 @@ int tss_dwconv3x3_fwd(const void* x, long ldx, const float* in_mean, const float
   const long U = (long)B * g.Hout * ((g.Wout + SW - 1) / SW);
   tss::ProfScope prof(TSS_K_DWCONV_FWD, (hipStream_t)stream,
                       ((double)B * Hin * Win + (double)P) * C * esz(dtype), 18.0 * P * C);
+  if (tss::dwroll_supported(C, stride, dil, dtype)) {   // bf16, dilation 1: row-pipelined through LDS (dwroll.hip)
+    tss::dwroll_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, y, ldy, stats, B, Hin, Win, C, stride, (hipStream_t)stream);
+    return tss::check_last("dwconv_fwd");
+  }
   const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   const bool strip = dtype == TSS_BF16 ? launch_strip<bf16_t>(0, g, sgrid, threads, (hipStream_t)stream)
                                        : launch_strip<float>(0, g, sgrid, threads, (hipStream_t)stream);

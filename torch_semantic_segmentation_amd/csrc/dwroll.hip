@@ -1,0 +1,399 @@
+// Depthwise 3x3 convolution, bf16, dilation 1, stride 1 / 2: row-pipelined through LDS.
+//
+// The strip kernels of dwconv.hip load every input vector 4.5 times (a 3 x 6 window per 4 outputs) and normalise it
+// as often; the re-reads hit L1 / L2, but each one still occupies a load slot of the lane for a full round trip, and
+// those kernels are bound by exactly that (2.7 TB/s algorithmic against 5-6 TB/s for a plain streaming kernel).
+// Here every input element is requested ONCE per block:
+//   * a block owns one SLICE of <= 8 channel vectors (64 channels = one 128-byte line per pixel) and walks down a
+//     column strip of PXL = 256 / CVS pixels, one input row (stride 2: two) per step ("job");
+//   * the lanes of the block load the row (one 16-byte vector each, + the two halo columns by the edge lanes), PF
+//     jobs ahead, apply the producer's BatchNorm (+ReLU) ONCE and park the f32 result in a two-slot LDS ring;
+//   * after one barrier each lane reads its three horizontal neighbours from LDS and updates the partial sums of the
+//     three output rows the input row touches (registers): an output row leaves when its last input row has passed.
+// Statistics, rounding and the summation order of the taps are those of dw_fwd_strip_kernel (measured: the two agree with an
+// f64 evaluation of the layer equally often -- all but 4e-5 of the bf16 outputs -- and with each other in all but 1e-5).
+#include "dwroll.h"
+
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int ENT = NT + 16;     // vectors of one LDS row array: PXL * CVS <= 256 plus two halo pixels (2 * CVS <= 16)
+
+struct RollArgs {
+  const bf16_t* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu;
+  const float* w; bf16_t* y; long ldy; double* stats;
+  int B, Hin, Win, C, CV, Hout, Wout;
+  int CVS, PXL, nsl, nstrips, RS, nseg, rows_used;
+  int dseg, dstrip, db;   // rows_used split into (segment, strip, image) steps
+  long units;
+};
+
+// position of a block in its job stream: unit (image b, column strip, row segment), step `it` inside it.  A block visits
+// units brow, brow + rows_used, ...: the step is pre-split on the host (dseg, dstrip, db) so that moving on is three adds with
+// carries, no division inside the loop.  b >= B <=> past the last unit.
+struct Cursor { int it, b, strip, seg, x0, o0; };
+
+__device__ __forceinline__ void advance(Cursor& c, const RollArgs& g, int n_iter) {
+  if (++c.it == n_iter) {
+    c.it = 0;
+    c.seg += g.dseg;
+    int carry = c.seg >= g.nseg ? 1 : 0;
+    c.seg -= carry * g.nseg;
+    c.strip += g.dstrip + carry;
+    carry = c.strip >= g.nstrips ? 1 : 0;
+    c.strip -= carry * g.nstrips;
+    c.b += g.db + carry;
+    c.x0 = c.strip * g.PXL;
+    c.o0 = c.seg * g.RS;
+  }
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// The row requests are inline assembly with hand-placed waits.  Left to the compiler, the prefetch does not survive: its
+// wait-count pass loses track of the requests in flight at the loop's back edge (conditional stores in between) and puts
+// s_waitcnt vmcnt(0) -- "everything" -- in front of the first use, which drains the whole PF-deep pipeline every time.
+// The compiler does not see these loads at all; a use is ordered behind its wait through the "+v" operands, and the
+// count passed to the wait is the number of REQUESTS OF THIS KIND issued after the one needed (memory operations retire
+// in order, so younger stores in between only make the wait more conservative, never too short).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void request(u32x4& dst, const bf16_t* uniform_base, int elem_offset) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(elem_offset * 2), "s"(uniform_base));
+}
+template <int N> __device__ __forceinline__ void arrived(u32x4& a, u32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+template <int N> __device__ __forceinline__ void arrived(u32x4& a, u32x4& b, u32x4& c, u32x4& d, u32x4& e, u32x4& f) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
+}
+
+// raw bf16 vector -> producer's BatchNorm (+ReLU), zero outside the image -> the two float4 halves of an LDS entry
+__device__ __forceinline__ void park(float4* lo4, float4* hi4, int e, const u32x4& raw, bool valid, const float sc[8],
+                                     const float sh[8], float relu_lo) {
+  float v[8];
+  V8<bf16_t>::unpack(make_uint4(raw[0], raw[1], raw[2], raw[3]), v);
+  const float lo = valid ? relu_lo : 0.f, hi = valid ? TSS_INF : 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = clamp3(v[j] * sc[j] + sh[j], lo, hi);
+  lo4[e] = make_float4(v[0], v[1], v[2], v[3]);
+  hi4[e] = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void fetch(const float4* lo4, const float4* hi4, int e, float v[8]) {
+  const float4 a = lo4[e], b = hi4[e];
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <int S> struct RollCfg;
+template <> struct RollCfg<1> { static constexpr int PF = 6, NRAW = 2, ROWS = 1, ARRS = 1; };   // raw: main, halo
+template <> struct RollCfg<2> { static constexpr int PF = 3, NRAW = 6, ROWS = 2, ARRS = 2; };   // raw: per row main0, main1, halo
+
+template <int S>
+__global__ __launch_bounds__(NT, 2) void dw_fwd_roll_kernel(const RollArgs g) {
+  typedef RollCfg<S> K;
+  constexpr int PF = K::PF;
+  extern __shared__ __align__(16) unsigned char dyn_smem[];
+  typedef float4 (*Ring)[K::ROWS][K::ARRS][2][ENT];                     // [slot][row][column parity][half][entry]
+  Ring ring = reinterpret_cast<Ring>(dyn_smem);
+  const int tid = threadIdx.x;
+  const int p = tid / g.CVS, cg = tid - p * g.CVS;
+  const int sl = (int)blockIdx.x % g.nsl, brow = (int)blockIdx.x / g.nsl;
+  const int cv = sl * 8 + cg;
+  const bool lane_on = p < g.PXL && cv < g.CV;
+  const int c0 = lane_on ? cv * 8 : 0;
+  const bool halo_l = lane_on && p == 0, halo_r = lane_on && p == g.PXL - 1;
+  const int ldx = (int)g.ldx;   // one input row of a layer stays below 2^31 elements (checked by the caller)
+
+  const int n_iter = (S == 1) ? g.RS + 2 : g.RS + 1;
+  Cursor ci, cc;
+  ci.it = 0;
+  ci.seg = brow % g.nseg;
+  ci.strip = (brow / g.nseg) % g.nstrips;
+  ci.b = brow / (g.nseg * g.nstrips);
+  ci.x0 = ci.strip * g.PXL;
+  ci.o0 = ci.seg * g.RS;
+  cc = ci;
+
+  u32x4 raw[PF][K::NRAW];
+  // request the input row(s) of the job at cursor c.  Every lane issues every load, unconditionally (a lane without a halo
+  // column re-requests its own vector, a cursor past the last unit re-reads the last image): with a load under a branch
+  // the compiler can no longer count the requests in flight and waits for ALL of them (s_waitcnt vmcnt(0)) before each use,
+  // which turns the PF-deep prefetch into a one-deep one.
+  const int halo_dx = halo_l ? -1 : (halo_r ? g.PXL : p);          // stride 1: window column of the second request
+  auto issue = [&](const Cursor& c, u32x4 (&r)[K::NRAW]) {
+    const int b = c.b < g.B ? c.b : g.B - 1;
+    if (S == 1) {
+      const int iy = clampi(c.o0 - 1 + c.it, 0, g.Hin - 1);
+      const bf16_t* row = g.x + ((long)b * g.Hin + iy) * g.Win * g.ldx;      // uniform: scalar base + 32-bit lane offset
+      request(r[0], row, clampi(c.x0 + p, 0, g.Win - 1) * ldx + c0);
+      request(r[1], row, clampi(c.x0 + halo_dx, 0, g.Win - 1) * ldx + c0);
+    } else {
+#pragma unroll
+      for (int ry = 0; ry < 2; ++ry) {
+        const int iy = clampi(2 * (c.o0 + c.it) - 1 + ry, 0, g.Hin - 1);
+        const bf16_t* row = g.x + ((long)b * g.Hin + iy) * g.Win * g.ldx;
+        const int ix = 2 * (c.x0 + p);
+        request(r[3 * ry + 0], row, clampi(ix, 0, g.Win - 1) * ldx + c0);
+        request(r[3 * ry + 1], row, clampi(ix + 1, 0, g.Win - 1) * ldx + c0);
+        request(r[3 * ry + 2], row, clampi(halo_l ? 2 * c.x0 - 1 : ix, 0, g.Win - 1) * ldx + c0);
+      }
+    }
+  };
+  // the first PF jobs are requested before the per-channel constants and the weights: one round trip for all of them
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    issue(ci, raw[k]);
+    advance(ci, g, n_iter);
+  }
+
+  float sc[8], sh[8];
+  {
+    float mu[8];
+    const bool has = g.xs != nullptr, has_b = has && g.xb != nullptr, has_m = has && g.xm != nullptr;
+    const float* safe = g.w;   // any readable 32 bytes
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float a[4], b[4], m[4];
+      V4<float>::load(has ? g.xs + c0 + 4 * h : safe, a);
+      V4<float>::load(has_b ? g.xb + c0 + 4 * h : safe, b);
+      V4<float>::load(has_m ? g.xm + c0 + 4 * h : safe, m);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[4 * h + j] = has ? a[j] : 1.f;
+        sh[4 * h + j] = has_b ? b[j] : 0.f;
+        mu[4 * h + j] = has_m ? m[j] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] = __builtin_fmaf(-mu[j], sc[j], sh[j]);   // (x-mu)*s+b as x*s + (b-mu*s), as in the strip kernel
+  }
+  float wr[9][8];     // the lane's 8 x 9 weights: 288 contiguous bytes of [C][9], 18 16-byte loads
+  {
+    float wf[72];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) V4<float>::load(g.w + (long)c0 * 9 + 4 * q, wf + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[t][j] = wf[j * 9 + t];
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+  // normalise the arrived row(s) of the job at cursor c into ring slot `slot`
+  auto write = [&](const Cursor& c, const u32x4 (&r)[K::NRAW], int slot) {
+    if (S == 1) {
+      const int iy = c.o0 - 1 + c.it;
+      const bool vy = iy >= 0 && iy < g.Hin;
+      float4* lo4 = ring[slot][0][0][0];
+      float4* hi4 = ring[slot][0][0][1];
+      if (p < g.PXL) park(lo4, hi4, tid + g.CVS, r[0], vy && c.x0 + p < g.Win, sc, sh, relu_lo);
+      if (halo_l) park(lo4, hi4, tid, r[1], vy && c.x0 - 1 >= 0, sc, sh, relu_lo);
+      if (halo_r) park(lo4, hi4, tid + 2 * g.CVS, r[1], vy && c.x0 + g.PXL < g.Win, sc, sh, relu_lo);
+    } else {
+#pragma unroll
+      for (int ry = 0; ry < 2; ++ry) {
+        const int iy = 2 * (c.o0 + c.it) - 1 + ry;
+        const bool vy = iy >= 0 && iy < g.Hin;
+        const int ix = 2 * (c.x0 + p);
+        // window column j <-> input column 2*x0 - 1 + j; even j in array 0 (entry j/2), odd j in array 1
+        if (p < g.PXL) {
+          park(ring[slot][ry][1][0], ring[slot][ry][1][1], tid, r[3 * ry + 0], vy && ix < g.Win, sc, sh, relu_lo);                // j = 2p+1
+          park(ring[slot][ry][0][0], ring[slot][ry][0][1], tid + g.CVS, r[3 * ry + 1], vy && ix + 1 < g.Win, sc, sh, relu_lo);   // j = 2p+2
+        }
+        if (halo_l) park(ring[slot][ry][0][0], ring[slot][ry][0][1], tid, r[3 * ry + 2], vy && 2 * c.x0 - 1 >= 0, sc, sh, relu_lo);   // j = 0
+      }
+    }
+  };
+
+  float accA[8], accB[8];   // stride 1: output rows iy-1 and iy under construction; stride 2: accA only
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+
+  auto emit = [&](const Cursor& c, int orow, float (&acc)[8]) {
+    if (lane_on && orow < g.Hout && c.x0 + p < g.Wout) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        acc[j] = V8<bf16_t>::round(acc[j]);
+        s1[j] += acc[j];
+        s2[j] += acc[j] * acc[j];
+      }
+      V8<bf16_t>::store(g.y + (((long)c.b * g.Hout + orow) * g.Wout + c.x0 + p) * g.ldy + c0, acc);
+    }
+  };
+  auto compute = [&](const Cursor& c, int slot) {
+    if (!lane_on) return;
+    if (S == 1) {
+      float accC[8];
+      if (c.it == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        float a[8];
+        fetch(ring[slot][0][0][0], ring[slot][0][0][1], tid + kx * g.CVS, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          accA[j] += a[j] * wr[6 + kx][j];
+          accB[j] += a[j] * wr[3 + kx][j];
+          accC[j] = kx == 0 ? a[j] * wr[0][j] : accC[j] + a[j] * wr[kx][j];
+        }
+      }
+      if (c.it >= 2) emit(c, c.o0 + c.it - 2, accA);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { accA[j] = accB[j]; accB[j] = accC[j]; }
+    } else {
+      // window column j = 2p + kx: even j -> array 0 (entry p, p + 1), odd j -> array 1 (entry p)
+      if (c.it == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accA[j] = 0.f;
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {    // input row 2o-1: last tap row of output row o-1, first of output row o
+        float a[8];
+        fetch(ring[slot][0][kx & 1][0], ring[slot][0][kx & 1][1], tid + (kx >> 1) * g.CVS, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          accA[j] += a[j] * wr[6 + kx][j];
+          accB[j] = kx == 0 ? a[j] * wr[0][j] : accB[j] + a[j] * wr[kx][j];
+        }
+      }
+      if (c.it >= 1) emit(c, c.o0 + c.it - 1, accA);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {    // input row 2o: middle tap row of output row o
+        float a[8];
+        fetch(ring[slot][1][kx & 1][0], ring[slot][1][kx & 1][1], tid + (kx >> 1) * g.CVS, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) accB[j] += a[j] * wr[3 + kx][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) accA[j] = accB[j];
+    }
+  };
+
+  int slot = 0;
+  while (cc.b < g.B) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      if (cc.b >= g.B) break;
+      if (S == 1) arrived<K::NRAW * (PF - 1)>(raw[k][0], raw[k][1]);
+      else arrived<K::NRAW * (PF - 1)>(raw[k][0], raw[k][1], raw[k][2], raw[k][3 % K::NRAW], raw[k][4 % K::NRAW], raw[k][5 % K::NRAW]);
+      write(cc, raw[k], slot);
+      issue(ci, raw[k]);
+      advance(ci, g, n_iter);
+      __syncthreads();
+      compute(cc, slot);
+      advance(cc, g, n_iter);
+      slot ^= 1;
+    }
+  }
+  // The last PF requests (issued past the end of the job stream so that the counts above stay exact) are never used, but
+  // they MUST land before this point: the compiler considers their destination registers free from here on and reuses
+  // them in the statistics tail, and a row arriving late would overwrite whatever lives there by then.
+#pragma unroll
+  for (int k = 0; k < PF; ++k) {
+    if (S == 1) arrived<0>(raw[k][0], raw[k][1]);
+    else arrived<0>(raw[k][0], raw[k][1], raw[k][2], raw[k][3 % K::NRAW], raw[k][4 % K::NRAW], raw[k][5 % K::NRAW]);
+  }
+
+  // ---- statistics: the block's slab row (columns of its slice); rows no block owns are zeroed here
+  if (g.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(dyn_smem);   // [p][2][CVS * 8]
+    const int cw = g.CVS * 8;
+    if (p < g.PXL) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(p * 2 + 0) * cw + cg * 8 + j] = lane_on ? s1[j] : 0.f;
+        red[(p * 2 + 1) * cw + cg * 8 + j] = lane_on ? s2[j] : 0.f;
+      }
+    }
+    __syncthreads();
+    // 2 * cw columns x PXL rows: NT / (2 * cw) threads share a column (interleaved rows), then one thread adds their partials
+    const int ncol = 2 * cw, share = NT / ncol;
+    float part = 0.f;
+    const int col = tid % ncol, sub = tid / ncol;
+    if (sub < share) {
+#pragma unroll 8
+      for (int q = sub; q < g.PXL; q += share) part += red[(q * 2 + col / cw) * cw + col % cw];
+    }
+    float* part_s = red + NT * 16;      // behind the [PXL][2][cw] block (<= 4096 floats); NT floats fit in the smallest ring
+    if (sub < share) part_s[sub * ncol + col] = part;
+    __syncthreads();
+    if (tid < ncol) {
+      const int which = tid / cw, c = tid - which * cw;
+      const int ch = sl * 64 + c;
+      if (ch < g.C) {
+        double a = 0.0;
+        for (int q = 0; q < share; ++q) a += (double)part_s[q * ncol + tid];
+        g.stats[(long)brow * 2 * g.C + which * g.C + ch] = a;
+        for (int r = brow + g.rows_used; r < TSS_STAT_SLABS; r += g.rows_used) g.stats[(long)r * 2 * g.C + which * g.C + ch] = 0.0;
+      }
+    }
+  }
+}
+
+// column strips x row segments: the segment height that minimises the longest block (k units of RS + halo rows)
+void plan(RollArgs& g, int S) {
+  g.CV = g.C / 8;
+  g.nsl = (g.CV + 7) / 8;
+  g.CVS = g.CV < 8 ? g.CV : 8;
+  g.PXL = NT / g.CVS;
+  g.nstrips = (g.Wout + g.PXL - 1) / g.PXL;
+  const int cap = TSS_STAT_SLABS / g.nsl > 0 ? TSS_STAT_SLABS / g.nsl : 1;   // 2 blocks per CU over all slices
+  const int halo = S == 1 ? 2 : 1;
+  long best_cost = -1;
+  for (int nseg = 1; nseg <= g.Hout; ++nseg) {
+    const int RS = (g.Hout + nseg - 1) / nseg;
+    if (RS < 4 && nseg > 1) break;
+    const int segs = (g.Hout + RS - 1) / RS;
+    const long units = (long)g.B * g.nstrips * segs;
+    const long k = (units + cap - 1) / cap;
+    const long cost = k * (RS + halo) + 6;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      g.RS = RS; g.nseg = segs; g.units = units;
+      g.rows_used = (int)((units + k - 1) / k);
+    }
+  }
+  g.dseg = g.rows_used % g.nseg;
+  g.dstrip = (g.rows_used / g.nseg) % g.nstrips;
+  g.db = g.rows_used / (g.nseg * g.nstrips);
+}
+
+inline size_t ring_bytes(int S) { return (size_t)2 * S * S * 2 * ENT * sizeof(float4); }
+
+}  // namespace
+
+namespace tss {
+
+bool dwroll_supported(int C, int stride, int dil, int dtype) {
+  const char* sw = getenv("TSS_DW_ROLL");      // A/B switch, read per call so one process can compare the two paths
+  const bool on = !(sw && atoi(sw) == 0);
+  return on && dtype == TSS_BF16 && dil == 1 && (stride == 1 || stride == 2) && C >= 8 && (C % 8) == 0 && C <= 768;
+}
+
+void dwroll_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                const float* w, void* y, long ldy, double* stats,
+                int B, int Hin, int Win, int C, int stride, hipStream_t stream) {
+  RollArgs g = {};
+  g.x = (const bf16_t*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.w = w; g.y = (bf16_t*)y; g.ldy = ldy; g.stats = stats;
+  g.B = B; g.Hin = Hin; g.Win = Win; g.C = C;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  plan(g, stride);
+  const int grid = g.nsl * g.rows_used;
+  static tss::DevOnce once;
+  if (once.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_fwd_roll_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes(2));
+  if (stride == 1) hipLaunchKernelGGL(dw_fwd_roll_kernel<1>, dim3(grid), dim3(NT), ring_bytes(1), stream, g);
+  else hipLaunchKernelGGL(dw_fwd_roll_kernel<2>, dim3(grid), dim3(NT), ring_bytes(2), stream, g);
+}
+
+}  // namespace tss
