@@ -176,6 +176,8 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
  * sums, added to dw ([C][1][3][3]) by a second small launch.  tss_dwconv3x3_bwd_fused_supported: 1 when this entry
  * covers the shape. */
 int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype);
+/* 1 when the one-sweep backward is also the faster choice for this layer (row-pipelined kernels, csrc/dwroll.hip) */
+int tss_dwconv3x3_bwd_fused_preferred(int C, int stride, int dil, int dtype);
 int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr,
                             const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                             const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

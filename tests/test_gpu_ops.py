@@ -101,6 +101,46 @@ def test_depthwise_fused_backward_matches_two_launches(stride, dil, c, h, w, pen
             assert rel(g1[k], g0[k]) < 2e-2, k
 
 
+@pytest.mark.parametrize('c,h,w', [(48, 9, 21), (8, 5, 7), (200, 37, 53), (384, 24, 40), (64, 70, 33)])
+@pytest.mark.parametrize('pending', [True, False])
+def test_depthwise_row_pipelined_backward_matches_two_launches(c, h, w, pending):
+    """The default stride-1 bf16 backward (csrc/dwroll.hip: input gradient + weight gradient in one row-pipelined sweep, 4
+    channels per lane) against the pair of strip kernels (TSS_DW_ROLL_BWD=0) on the same operands: ragged strips and
+    segments, one to several channel slices, with the input BatchNorm pending or materialised."""
+    import importlib
+    import os
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+
+    def run(roll):
+        torch.manual_seed(23)
+        layers = [F_.Conv2dBlock(c, c, 1)] if pending else []
+        layers += [F_.DWConv2dBlock(c, c, kernel_size=3, padding=1, stride=1), F_.Conv2dBlock(c, c, 1)]
+        m = nn.Sequential(*layers).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = torch.randn(3, c, h, w, device=DEV).requires_grad_(True)
+        old = os.environ.get('TSS_DW_ROLL_BWD')
+        os.environ['TSS_DW_ROLL_BWD'] = '1' if roll else '0'
+        try:
+            out = m(x)
+            out.float().backward(torch.randn_like(out, dtype=torch.float32))
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                del os.environ['TSS_DW_ROLL_BWD']
+            else:
+                os.environ['TSS_DW_ROLL_BWD'] = old
+        return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+    dx1, g1 = run(True)
+    dx0, g0 = run(False)
+    assert rel(dx1, dx0) < 1e-2
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert rel(g1[k], g0[k]) < 1e-2, k
+
+
 def test_resize_image_matches_interpolate():
     from torch_semantic_segmentation_amd import ops
     x = torch.randn(2, 3, 64, 128, device=DEV)

@@ -74,5 +74,39 @@ for (B, C, H, W, s) in LAYERS:
         alg = (B * C * H * W + B * C * Ho * Wo) * 2
         print('dw fwd  %dx%dx%dx%d s%d  %7.1f us  %6.0f GB/s   y %s  stats %s  sum %.6e' % (
             B, C, H, W, s, t, alg / t / 1e3, digest(ys[0]), digest(stats.sum(0).float()), stats.sum(0)[:C].sum().item()))
+    if which == 'bwd' and s == 1:
+        es = [ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev).normal_() for _ in range(nset)]
+        yr = [ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev).normal_() for _ in range(nset)]
+        eins = [ops.new_nhwc(B, C, H, W, torch.bfloat16, dev) for _ in range(nset)]
+        ga = torch.rand(C, device=dev) + 0.5; gb = torch.randn(C, device=dev) * 0.05; gce = torch.randn(C, device=dev) * 0.01
+        gmu = torch.randn(C, device=dev) * 0.1
+        ws = torch.empty(S, C * 9, device=dev)
+        dwt = torch.zeros(C, 9, device=dev)
+        bst = torch.empty(S, 2 * C, dtype=torch.float64, device=dev)
+
+        def fused():
+            for x, e, y, ei in zip(xs, es, yr, eins):
+                N.call('tss_dwconv3x3_bwd_fused', N.ptr(e), ops.ld(e), N.ptr(y), ops.ld(y), N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+                       N.ptr(w), N.ptr(x), ops.ld(x), N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, 1, N.ptr(ei), ops.ld(ei), N.ptr(bst),
+                       N.ptr(ws), N.ptr(dwt), B, H, W, C, s, 1, N.TSS_BF16, st)
+
+        def pair():
+            for x, e, y, ei in zip(xs, es, yr, eins):
+                N.call('tss_dwconv3x3_bwd_weight', N.ptr(e), ops.ld(e), N.ptr(y), ops.ld(y), N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+                       N.ptr(x), ops.ld(x), N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(dwt), N.ptr(ws), 1, B, H, W, C, s, 1, N.TSS_BF16, st)
+                N.call('tss_dwconv3x3_bwd_data', N.ptr(e), ops.ld(e), N.ptr(y), ops.ld(y), N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+                       N.ptr(w), N.ptr(x), ops.ld(x), N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(ei), ops.ld(ei), N.ptr(bst),
+                       N.ptr(ws), N.ptr(dwt), B, H, W, C, s, 1, N.TSS_BF16, st)
+        dwt.zero_(); pair(); torch.cuda.synchronize()
+        ei0, dw0, st0 = eins[0].float().clone(), dwt.clone() / nset, bst.sum(0)
+        t0 = timeit(pair) / nset
+        dwt.zero_(); fused(); torch.cuda.synchronize()
+        ei1, dw1, st1 = eins[0].float().clone(), dwt.clone() / nset, bst.sum(0)
+        t1 = timeit(fused) / nset
+        rl = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+        alg = 4 * B * C * H * W * 2
+        print('dw bwd  %dx%dx%dx%d s%d  one sweep %7.1f us (%5.0f GB/s on 4 passes)  pair %7.1f us   e_in rel %.2e  dW rel %.2e  stats rel %.2e' % (
+            B, C, H, W, s, t1, alg / t1 / 1e3, t0, rl(ei1, ei0), rl(dw1, dw0), rl(st1, st0)))
+        del es, yr, eins
     del xs, ys
     torch.cuda.empty_cache()

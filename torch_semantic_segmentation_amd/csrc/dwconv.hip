@@ -1023,6 +1023,12 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   return tss::check_last("dwconv_bwd_data");
 }
 
+// 1 when the one-sweep backward is also the FASTER choice for the layer (the row-pipelined stride-1 kernel); the 8-channel
+// strip variant behind tss_dwconv3x3_bwd_fused stays opt-in
+int tss_dwconv3x3_bwd_fused_preferred(int C, int stride, int dil, int dtype) {
+  return tss::dwroll_bwd_fused_supported(C, stride, dil, dtype) ? 1 : 0;
+}
+
 int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype) {
   return dtype == TSS_BF16 && strip_supported(stride, dil) && C > 0 && (C % 8) == 0 && C <= 768;
 }
@@ -1049,6 +1055,17 @@ int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr
   const long P = (long)B * Hin * Win;
   if (P == 0) return TSS_OK;
   const long Po = (long)B * g.Hout * g.Wout;
+  if (tss::dwroll_bwd_fused_supported(C, stride, dil, dtype)) {   // row-pipelined, 4 channels per lane (dwroll.hip)
+    int rows;
+    {
+      tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
+                          ((double)Po * (yraw ? 2 : 1) + (double)P * 2) * C * esz(dtype), 36.0 * Po * C);
+      rows = tss::dwroll_bwd_fused(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, x, ldx, in_mean, in_scale, in_bias, in_relu, x_pending,
+                                   e_in, ldei, bstats, ws, B, Hin, Win, C, (hipStream_t)stream);
+    }
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
+    return tss::check_last("dwconv_bwd_fused");
+  }
   const long U = (long)B * Hin * ((Win + WG_SW - 1) / WG_SW);
   const int sgrid = tss::persistent_blocks((U + g.NPL - 1) / g.NPL, TSS_STAT_SLABS);
   {

@@ -87,6 +87,44 @@ __device__ __forceinline__ void fetch(const float4* lo4, const float4* hi4, int 
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
+// Per-channel sums of a block -> its slab row.  Lanes hold NC channels of one pixel lane p; red: >= (NT * 16 + NT) floats of
+// LDS no longer in use.  [PXL][2][cw] partials, NT / (2 cw) threads share a column (interleaved rows), one thread adds them.
+template <int NC>
+__device__ __forceinline__ void flush_slab(const float (&s1)[NC], const float (&s2)[NC], double* stats, int C, int CVS, int PXL,
+                                           int sl, int brow, int rows_used, int p, int cg, bool lane_on, float* red) {
+  const int tid = threadIdx.x;
+  const int cw = CVS * NC;
+  __syncthreads();
+  if (p < PXL) {
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      red[(p * 2 + 0) * cw + cg * NC + j] = lane_on ? s1[j] : 0.f;
+      red[(p * 2 + 1) * cw + cg * NC + j] = lane_on ? s2[j] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int ncol = 2 * cw, share = NT / ncol;
+  float part = 0.f;
+  const int col = tid % ncol, sub = tid / ncol;
+  if (sub < share) {
+#pragma unroll 8
+    for (int q = sub; q < PXL; q += share) part += red[(q * 2 + col / cw) * cw + col % cw];
+  }
+  float* part_s = red + NT * 16;      // behind the [PXL][2][cw] block (<= 4096 floats)
+  if (sub < share) part_s[sub * ncol + col] = part;
+  __syncthreads();
+  if (tid < ncol) {
+    const int which = tid / cw, c = tid - which * cw;
+    const int ch = sl * 64 + c;
+    if (ch < C) {
+      double a = 0.0;
+      for (int q = 0; q < share; ++q) a += (double)part_s[q * ncol + tid];
+      stats[(long)brow * 2 * C + which * C + ch] = a;
+      for (int r = brow + rows_used; r < TSS_STAT_SLABS; r += rows_used) stats[(long)r * 2 * C + which * C + ch] = 0.0;
+    }
+  }
+}
+
 template <int S> struct RollCfg;
 template <> struct RollCfg<1> { static constexpr int PF = 6, NRAW = 2, ROWS = 1, ARRS = 1; };   // raw: main, halo
 template <> struct RollCfg<2> { static constexpr int PF = 3, NRAW = 6, ROWS = 2, ARRS = 2; };   // raw: per row main0, main1, halo
@@ -303,40 +341,7 @@ __global__ __launch_bounds__(NT, 2) void dw_fwd_roll_kernel(const RollArgs g) {
   }
 
   // ---- statistics: the block's slab row (columns of its slice); rows no block owns are zeroed here
-  if (g.stats) {
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(dyn_smem);   // [p][2][CVS * 8]
-    const int cw = g.CVS * 8;
-    if (p < g.PXL) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        red[(p * 2 + 0) * cw + cg * 8 + j] = lane_on ? s1[j] : 0.f;
-        red[(p * 2 + 1) * cw + cg * 8 + j] = lane_on ? s2[j] : 0.f;
-      }
-    }
-    __syncthreads();
-    // 2 * cw columns x PXL rows: NT / (2 * cw) threads share a column (interleaved rows), then one thread adds their partials
-    const int ncol = 2 * cw, share = NT / ncol;
-    float part = 0.f;
-    const int col = tid % ncol, sub = tid / ncol;
-    if (sub < share) {
-#pragma unroll 8
-      for (int q = sub; q < g.PXL; q += share) part += red[(q * 2 + col / cw) * cw + col % cw];
-    }
-    float* part_s = red + NT * 16;      // behind the [PXL][2][cw] block (<= 4096 floats); NT floats fit in the smallest ring
-    if (sub < share) part_s[sub * ncol + col] = part;
-    __syncthreads();
-    if (tid < ncol) {
-      const int which = tid / cw, c = tid - which * cw;
-      const int ch = sl * 64 + c;
-      if (ch < g.C) {
-        double a = 0.0;
-        for (int q = 0; q < share; ++q) a += (double)part_s[q * ncol + tid];
-        g.stats[(long)brow * 2 * g.C + which * g.C + ch] = a;
-        for (int r = brow + g.rows_used; r < TSS_STAT_SLABS; r += g.rows_used) g.stats[(long)r * 2 * g.C + which * g.C + ch] = 0.0;
-      }
-    }
-  }
+  if (g.stats) flush_slab<8>(s1, s2, g.stats, g.C, g.CVS, g.PXL, sl, brow, g.rows_used, p, cg, lane_on, reinterpret_cast<float*>(dyn_smem));
 }
 
 // column strips x row segments: the segment height that minimises the longest block (k units of RS + halo rows)
@@ -362,6 +367,313 @@ void plan(RollArgs& g, int S) {
       g.rows_used = (int)((units + k - 1) / k);
     }
   }
+  g.dseg = g.rows_used % g.nseg;
+  g.dstrip = (g.rows_used / g.nseg) % g.nstrips;
+  g.db = g.rows_used / (g.nseg * g.nstrips);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of a stride-1 layer in ONE sweep: input gradient AND weight gradient from a single pass over (e, y, x).
+//
+// The two strip kernels of dwconv.hip read e, y and x once each for the input gradient and once more for the weight
+// gradient: 7 tensor passes.  Here a lane owns FOUR channels of one pixel (a 64-channel slice is 16 lanes), which
+// halves every per-lane array -- the 9 x 4 weights AND the 9 x 4 weight-gradient accumulators fit next to each other at
+// two waves per SIMD, which the 8-channel layout could not do (its fused variant in dwconv.hip runs at one wave per SIMD and
+// loses to the pair) -- and the row pipeline of the forward kernel does the rest: per step one row of e, y, x is requested
+// (PF steps ahead), g = BN'(e, y) and a = relu(BN(x)) are evaluated once and parked in LDS, and after the barrier a lane
+// reads its three horizontal neighbours of both:
+//   e_in[q] = relu'(x[q]) * sum_{ky,kx} w[ky][kx] * g[q - ky + 1][p - kx + 1]     three rows under construction, as forward
+//   dW[ky][kx] += g[o][p] * a[o + ky - 1][p + kx - 1]                              o = rows OWNED by the unit only
+// 4 tensor passes instead of 7.  A unit's halo rows feed its e_in rows but not its dW sums (their g belongs to the
+// vertical neighbour), so every (o, p) pair is counted exactly once over the grid.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void request2(u32x2& dst, const bf16_t* uniform_base, int elem_offset) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(elem_offset * 2), "s"(uniform_base));
+}
+template <int N> __device__ __forceinline__ void arrived2(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
+}
+__device__ __forceinline__ void unpack4(const u32x2& r, float v[4]) {
+  v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
+  v[2] = __uint_as_float(r[1] << 16); v[3] = __uint_as_float(r[1] & 0xffff0000u);
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct RollBwdArgs {
+  const bf16_t* e; long lde; const bf16_t* yr; long ldyr; const float* ga; const float* gb; const float* gce; const float* gmu;
+  const float* w;
+  const bf16_t* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_mask;
+  bf16_t* ein; long ldei; double* stats; float* ws;
+  int B, H, W, C;
+  int CVS, PXL, nsl, nstrips, RS, nseg, rows_used, dseg, dstrip, db;
+};
+constexpr int BENT = NT + 32;      // LDS row: PXL * CVS <= 256 entries + two halo pixels (2 * CVS <= 32)
+constexpr int BPF = 4;             // steps in flight
+
+struct BCursor { int it, b, strip, seg, x0, o0; };
+__device__ __forceinline__ void advance(BCursor& c, const RollBwdArgs& g, int n_iter) {
+  if (++c.it == n_iter) {
+    c.it = 0;
+    c.seg += g.dseg;
+    int carry = c.seg >= g.nseg ? 1 : 0;
+    c.seg -= carry * g.nseg;
+    c.strip += g.dstrip + carry;
+    carry = c.strip >= g.nstrips ? 1 : 0;
+    c.strip -= carry * g.nstrips;
+    c.b += g.db + carry;
+    c.x0 = c.strip * g.PXL;
+    c.o0 = c.seg * g.RS;
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs g) {
+  __shared__ __align__(16) float4 rows_s[4][BENT];   // [slot] g rows, [2 + slot] activated input rows; entry = window column * CVS + lane
+  float4 (*Gs)[BENT] = rows_s;
+  float4 (*As)[BENT] = rows_s + 2;
+  static_assert(sizeof(float4) * 4 * BENT >= sizeof(float) * (NT * 16 + NT), "flush_slab scratch");
+  const int tid = threadIdx.x;
+  const int p = tid / g.CVS, cg = tid - p * g.CVS;
+  const int sl = (int)blockIdx.x % g.nsl, brow = (int)blockIdx.x / g.nsl;
+  const int ch = sl * 64 + cg * 4;
+  const bool lane_on = p < g.PXL && ch < g.C;
+  const int c0 = lane_on ? ch : 0;
+  const bool halo_l = lane_on && p == 0, halo_r = lane_on && p == g.PXL - 1;
+  const int halo_dx = halo_l ? -1 : (halo_r ? g.PXL : p);
+  const int lde = (int)g.lde, ldy = (int)g.ldyr, ldx = (int)g.ldx;
+  const bf16_t* ysrc = g.yr ? g.yr : g.e;           // no BatchNorm behind this layer: the y requests re-read e (cb = 0)
+
+  const int n_iter = g.RS + 2;
+  BCursor ci, cc;
+  ci.it = 0;
+  ci.seg = brow % g.nseg;
+  ci.strip = (brow / g.nseg) % g.nstrips;
+  ci.b = brow / (g.nseg * g.nstrips);
+  ci.x0 = ci.strip * g.PXL;
+  ci.o0 = ci.seg * g.RS;
+  cc = ci;
+
+  u32x2 raw[BPF][6];      // e, y, x under the lane's pixel; e, y, x of its halo column (edge lanes; the others re-request)
+  auto issue = [&](const BCursor& c, u32x2 (&r)[6]) {
+    const int b = c.b < g.B ? c.b : g.B - 1;
+    const int iy = clampi(c.o0 - 1 + c.it, 0, g.H - 1);
+    const long rowpix = ((long)b * g.H + iy) * g.W;
+    const int xm_ = clampi(c.x0 + p, 0, g.W - 1), xh_ = clampi(c.x0 + halo_dx, 0, g.W - 1);
+    const bf16_t* re = g.e + rowpix * g.lde;
+    const bf16_t* ry = ysrc + rowpix * (g.yr ? g.ldyr : g.lde);
+    const bf16_t* rx = g.x + rowpix * g.ldx;
+    const int ldyy = g.yr ? ldy : lde;
+    request2(r[0], re, xm_ * lde + c0);
+    request2(r[1], ry, xm_ * ldyy + c0);
+    request2(r[2], rx, xm_ * ldx + c0);
+    request2(r[3], re, xh_ * lde + c0);
+    request2(r[4], ry, xh_ * ldyy + c0);
+    request2(r[5], rx, xh_ * ldx + c0);
+  };
+#pragma unroll
+  for (int k = 0; k < BPF; ++k) {
+    issue(ci, raw[k]);
+    advance(ci, g, n_iter);
+  }
+
+  // per-channel constants: g = ca * e + (cb * y + kd), a = relu?(x * sc + sh'), xc = x - mu
+  float ca[4], cb[4], kd[4], sc[4], sh[4], mu[4];
+  {
+    const float* safe = g.w;
+    float t0[4], t1[4], t2[4], t3[4];
+    V4<float>::load(g.ga ? g.ga + c0 : safe, t0);
+    V4<float>::load(g.yr ? g.gb + c0 : safe, t1);
+    V4<float>::load(g.yr ? g.gce + c0 : safe, t2);
+    V4<float>::load(g.yr ? g.gmu + c0 : safe, t3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ca[j] = g.ga ? t0[j] : 1.f;
+      cb[j] = g.yr ? t1[j] : 0.f;
+      kd[j] = g.yr ? -(ca[j] * t2[j]) - cb[j] * t3[j] : 0.f;
+    }
+    const bool has = g.xs != nullptr;
+    V4<float>::load(has ? g.xs + c0 : safe, t0);
+    V4<float>::load(has && g.xb ? g.xb + c0 : safe, t1);
+    V4<float>::load(g.xm ? g.xm + c0 : safe, t2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = has ? t0[j] : 1.f;
+      mu[j] = g.xm ? t2[j] : 0.f;
+      sh[j] = __builtin_fmaf(-(has ? mu[j] : 0.f), sc[j], (has && g.xb) ? t1[j] : 0.f);
+    }
+  }
+  float wr[9][4];
+  {
+    float wf[36];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) V4<float>::load(g.w + (long)c0 * 9 + 4 * q, wf + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[t][j] = wf[j * 9 + t];
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+  float dwa[9][4], accA[4], accB[4], gprev[4], aprev[3][4], s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    accA[j] = accB[j] = gprev[j] = s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t][j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) aprev[t][j] = 0.f;
+  }
+  u32x2 xprev = {0u, 0u};
+
+  // g and a of one (row, column) from its raw vectors; zero outside the image
+  auto ga_of = [&](const u32x2& re, const u32x2& ry, const u32x2& rx, bool valid, float4& gv, float4& av) {
+    float ev[4], yv[4], xv[4], go[4], ao[4];
+    unpack4(re, ev); unpack4(ry, yv); unpack4(rx, xv);
+    const float lo = valid ? relu_lo : 0.f, hi = valid ? TSS_INF : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = ca[j] * ev[j] + (cb[j] * yv[j] + kd[j]);
+      go[j] = valid ? gj : 0.f;
+      ao[j] = clamp3(xv[j] * sc[j] + sh[j], lo, hi);
+    }
+    gv = make_float4(go[0], go[1], go[2], go[3]);
+    av = make_float4(ao[0], ao[1], ao[2], ao[3]);
+  };
+
+  int slot = 0;
+  while (cc.b < g.B) {
+#pragma unroll
+    for (int k = 0; k < BPF; ++k) {
+      if (cc.b >= g.B) break;
+      arrived2<6 * (BPF - 1)>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
+      const int r = cc.o0 - 1 + cc.it;
+      const bool vy = r >= 0 && r < g.H;
+      float4 gown, aown;
+      ga_of(raw[k][0], raw[k][1], raw[k][2], vy && cc.x0 + p < g.W, gown, aown);
+      if (p < g.PXL) { Gs[slot][tid + g.CVS] = gown; As[slot][tid + g.CVS] = aown; }
+      if (halo_l || halo_r) {
+        float4 gh, ah;
+        ga_of(raw[k][3], raw[k][4], raw[k][5], vy && (halo_l ? cc.x0 - 1 >= 0 : cc.x0 + g.PXL < g.W), gh, ah);
+        const int eh = halo_l ? tid : tid + 2 * g.CVS;
+        Gs[slot][eh] = gh; As[slot][eh] = ah;
+      }
+      const u32x2 xcur = raw[k][2];
+      issue(ci, raw[k]);
+      advance(ci, g, n_iter);
+      __syncthreads();
+      if (lane_on) {
+        float G[3][4], A[3][4];     // window columns p-1, p, p+1
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const float4 gq = Gs[slot][tid + q * g.CVS], aq = As[slot][tid + q * g.CVS];
+          G[q][0] = gq.x; G[q][1] = gq.y; G[q][2] = gq.z; G[q][3] = gq.w;
+          A[q][0] = aq.x; A[q][1] = aq.y; A[q][2] = aq.z; A[q][3] = aq.w;
+        }
+        if (cc.it == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
+        }
+        // input gradient: g row r is tap row 0 of e_in row r-1, tap row 1 of row r, tap row 2 of row r+1; tap column kx
+        // reads g column p + 1 - kx = window column 2 - kx
+        float accC[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          accA[j] += wr[0][j] * G[2][j]; accA[j] += wr[1][j] * G[1][j]; accA[j] += wr[2][j] * G[0][j];
+          accB[j] += wr[3][j] * G[2][j]; accB[j] += wr[4][j] * G[1][j]; accB[j] += wr[5][j] * G[0][j];
+          accC[j] = wr[6][j] * G[2][j]; accC[j] += wr[7][j] * G[1][j]; accC[j] += wr[8][j] * G[0][j];
+        }
+        const int q = r - 1;     // finished e_in row
+        if (cc.it >= 2 && q < g.H && cc.x0 + p < g.W) {
+          float out[4];
+          if (g.x_mask) {
+            float xv[4];
+            unpack4(xprev, xv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool dead = g.x_relu && !(xv[j] * sc[j] + sh[j] > 0.f);
+              out[j] = V8<bf16_t>::round(dead ? 0.f : accA[j]);
+              s1[j] += out[j];
+              s2[j] += out[j] * (xv[j] - mu[j]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[j] = accA[j];
+          }
+          V4<bf16_t>::store(g.ein + (((long)cc.b * g.H + q) * g.W + cc.x0 + p) * g.ldei + c0, out);
+        }
+        // weight gradient over the rows this unit owns (it = 1 .. RS for row r, it = 2 .. RS + 1 for row r - 1)
+        const bool own_cur = cc.it >= 1 && cc.it <= g.RS, own_prev = cc.it >= 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gc = own_cur ? G[1][j] : 0.f, gp = own_prev ? gprev[j] : 0.f;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            dwa[6 + kx][j] += gp * A[kx][j];          // o = r - 1, tap row 2: a[o + 1]
+            dwa[3 + kx][j] += gc * A[kx][j];          // o = r,     tap row 1
+            dwa[0 + kx][j] += gc * aprev[kx][j];      // o = r,     tap row 0: a[o - 1]
+          }
+          gprev[j] = G[1][j];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) aprev[kx][j] = A[kx][j];
+          accA[j] = accB[j]; accB[j] = accC[j];
+        }
+        xprev = xcur;
+      }
+      advance(cc, g, n_iter);
+      slot ^= 1;
+    }
+  }
+  // the last BPF requests are never used but must land before their registers are reused (see the forward kernel)
+#pragma unroll
+  for (int k = 0; k < BPF; ++k) arrived2<0>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
+
+  float* red = reinterpret_cast<float*>(&rows_s[0][0]);
+  if (g.stats) flush_slab<4>(s1, s2, g.stats, g.C, g.CVS, g.PXL, sl, brow, g.rows_used, p, cg, lane_on, red);
+  // weight-gradient partial sums of the block -> its workspace row: three taps at a time through [thread][12] floats
+  float* wrow = g.ws + (long)brow * g.C * 9;
+  const int cw = g.CVS * 4;
+#pragma unroll
+  for (int t0 = 0; t0 < 9; t0 += 3) {
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+      *reinterpret_cast<float4*>(red + tid * 12 + tt * 4) =
+          lane_on ? make_float4(dwa[t0 + tt][0], dwa[t0 + tt][1], dwa[t0 + tt][2], dwa[t0 + tt][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < cw * 3; i += NT) {
+      const int c = i / 3, tt = i - c * 3;
+      const int cgc = c >> 2, j = c & 3;
+      if (sl * 64 + c < g.C) {
+        float sum = 0.f;
+        for (int q = 0; q < g.PXL; ++q) sum += red[(q * g.CVS + cgc) * 12 + tt * 4 + j];
+        wrow[(long)(sl * 64 + c) * 9 + t0 + tt] = sum;
+      }
+    }
+  }
+}
+
+void plan_bwd(RollBwdArgs& g) {
+  const int cv4 = g.C / 4;
+  g.nsl = (g.C + 63) / 64;
+  g.CVS = cv4 < 16 ? cv4 : 16;
+  g.PXL = NT / g.CVS;
+  g.nstrips = (g.W + g.PXL - 1) / g.PXL;
+  const int cap = TSS_STAT_SLABS / g.nsl > 0 ? TSS_STAT_SLABS / g.nsl : 1;
+  long best_cost = -1;
+  long units_best = 0;
+  for (int nseg = 1; nseg <= g.H; ++nseg) {
+    const int RS = (g.H + nseg - 1) / nseg;
+    if (RS < 4 && nseg > 1) break;
+    const int segs = (g.H + RS - 1) / RS;
+    const long units = (long)g.B * g.nstrips * segs;
+    const long k = (units + cap - 1) / cap;
+    const long cost = k * (RS + 2) + 6;
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      g.RS = RS; g.nseg = segs; units_best = units;
+      g.rows_used = (int)((units + k - 1) / k);
+    }
+  }
+  (void)units_best;
   g.dseg = g.rows_used % g.nseg;
   g.dstrip = (g.rows_used / g.nseg) % g.nstrips;
   g.db = g.rows_used / (g.nseg * g.nstrips);
@@ -394,6 +706,27 @@ void dwroll_fwd(const void* x, long ldx, const float* in_mean, const float* in_s
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dw_fwd_roll_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes(2));
   if (stride == 1) hipLaunchKernelGGL(dw_fwd_roll_kernel<1>, dim3(grid), dim3(NT), ring_bytes(1), stream, g);
   else hipLaunchKernelGGL(dw_fwd_roll_kernel<2>, dim3(grid), dim3(NT), ring_bytes(2), stream, g);
+}
+
+
+bool dwroll_bwd_fused_supported(int C, int stride, int dil, int dtype) {
+  const char* sw = getenv("TSS_DW_ROLL_BWD");
+  const bool on = !(sw && atoi(sw) == 0);
+  return on && dtype == TSS_BF16 && dil == 1 && stride == 1 && C >= 8 && (C % 8) == 0 && C <= 768;
+}
+
+int dwroll_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                     const float* gmu, const float* w, const void* x, long ldx, const float* in_mean, const float* in_scale,
+                     const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei, double* bstats, float* ws,
+                     int B, int H, int W, int C, hipStream_t stream) {
+  RollBwdArgs g = {};
+  g.e = (const bf16_t*)e; g.lde = lde; g.yr = (const bf16_t*)yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.w = w; g.x = (const bf16_t*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.x_mask = x_pending; g.ein = (bf16_t*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
+  g.B = B; g.H = H; g.W = W; g.C = C;
+  plan_bwd(g);
+  hipLaunchKernelGGL(dw_bwd_roll_s1_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
+  return g.rows_used;
 }
 
 }  // namespace tss

@@ -627,7 +627,8 @@ class ConvUnitFn(Function):
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
                 defer = 1 if (need_dx and side is None) else 0      # backward-data carries the row reduction
                 # input gradient and weight gradient in ONE sweep when the shape allows (e, y, x read once)
-                fused_dw = bool(defer and fuse_dw_backward and N.lib().tss_dwconv3x3_bwd_fused_supported(Cout, s, d, dt))
+                fused_dw = bool(defer and ((fuse_dw_backward and N.lib().tss_dwconv3x3_bwd_fused_supported(Cout, s, d, dt))
+                                          or N.lib().tss_dwconv3x3_bwd_fused_preferred(Cout, s, d, dt)))
                 if not fused_dw:
                     call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
             elif cfg.kind in ('dense1d_w', 'dense1d_h'):
