@@ -101,10 +101,11 @@ def test_depthwise_fused_backward_matches_two_launches(stride, dil, c, h, w, pen
             assert rel(g1[k], g0[k]) < 2e-2, k
 
 
-@pytest.mark.parametrize('c,h,w', [(48, 9, 21), (8, 5, 7), (200, 37, 53), (384, 24, 40), (64, 70, 33)])
+@pytest.mark.parametrize('c,h,w', [(48, 9, 21), (8, 5, 7), (200, 37, 53), (384, 24, 40), (64, 70, 33), (32, 38, 36)])
+@pytest.mark.parametrize('stride', [1, 2])
 @pytest.mark.parametrize('pending', [True, False])
-def test_depthwise_row_pipelined_backward_matches_two_launches(c, h, w, pending):
-    """The default stride-1 bf16 backward (csrc/dwroll.hip: input gradient + weight gradient in one row-pipelined sweep, 4
+def test_depthwise_row_pipelined_backward_matches_two_launches(c, h, w, stride, pending):
+    """The default bf16 backward (csrc/dwroll.hip: input gradient + weight gradient in one row-pipelined sweep, 4
     channels per lane) against the pair of strip kernels (TSS_DW_ROLL_BWD=0) on the same operands: ragged strips and
     segments, one to several channel slices, with the input BatchNorm pending or materialised."""
     import importlib
@@ -116,7 +117,7 @@ def test_depthwise_row_pipelined_backward_matches_two_launches(c, h, w, pending)
     def run(roll):
         torch.manual_seed(23)
         layers = [F_.Conv2dBlock(c, c, 1)] if pending else []
-        layers += [F_.DWConv2dBlock(c, c, kernel_size=3, padding=1, stride=1), F_.Conv2dBlock(c, c, 1)]
+        layers += [F_.DWConv2dBlock(c, c, kernel_size=3, padding=1, stride=stride), F_.Conv2dBlock(c, c, 1)]
         m = nn.Sequential(*layers).to(DEV)
         tssa.set_compute_dtype(m, torch.bfloat16)
         m.train()

@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Static check of csrc/dwroll.hip's ISA (no GPU needed): the row requests of the row-pipelined depthwise kernels are inline
+assembly (global_load into registers the compiler does not know to be pending), so NO compiler-generated instruction may read
+a request's destination registers between the request and the hand-placed s_waitcnt that covers it.  The one way the compiler
+does that on its own is a register copy hoisted in front of the (tied-operand) wait statement; this script compiles the file to
+assembly and fails if any v_mov / v_accvgpr / scratch store outside the ASM blocks reads a request destination register."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'torch_semantic_segmentation_amd', 'csrc')
+
+
+def regs(tok):
+    m = re.match(r'v\[(\d+):(\d+)\]', tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'v(\d+)$', tok)
+    return {int(m.group(1))} if m else set()
+
+
+def check(asm_text):
+    problems = []
+    for name, body in re.findall(r'^(_ZN[^\n:]*roll[^\n:]*):.*?\n(.*?)s_endpgm', asm_text, flags=re.S | re.M):
+        lines = body.split('\n')
+        # up to the final drain (the last hand-placed s_waitcnt vmcnt(0)): behind it the registers are ordinary again
+        last = max([i for i, ln in enumerate(lines) if 's_waitcnt vmcnt(0)' in ln and i > 0 and 'ASMSTART' in lines[i - 1]] or [len(lines)])
+        lines = lines[:last]
+        pending, in_asm = set(), False
+        for ln in lines:
+            t = ln.strip()
+            if t.startswith(';;#ASMSTART'):
+                in_asm = True
+                continue
+            if t.startswith(';;#ASMEND'):
+                in_asm = False
+                continue
+            if in_asm and t.startswith('global_load_dword'):
+                pending |= regs(t.split()[1].rstrip(','))
+        # every asm request destination is "pending-capable" for the whole kernel: a compiler-made copy FROM one is suspicious
+        in_asm = False
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith(';;#ASMSTART'):
+                in_asm = True
+            elif t.startswith(';;#ASMEND'):
+                in_asm = False
+            elif not in_asm and re.match(r'(v_mov_b32|v_mov_b64|v_pk_mov_b32|v_swap_b32|v_accvgpr_write|scratch_store|buffer_store)', t):
+                ops = [o.strip() for o in t.split(None, 1)[1].split(',')]
+                srcs = set()
+                for o in ops[1:]:
+                    srcs |= regs(o)
+                if srcs & pending:
+                    problems.append('%s: line %d: %s' % (name, i, t))
+    return problems
+
+
+def main():
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'dwroll.s')
+        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-S',
+                        '--cuda-device-only', os.path.join(CSRC, 'dwroll.hip'), '-o', out], check=True, capture_output=True)
+        problems = check(open(out).read())
+    for pr in problems:
+        print(pr)
+    print('%d compiler-made reads of request destination registers' % len(problems))
+    return 1 if problems else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

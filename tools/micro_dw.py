@@ -74,7 +74,7 @@ for (B, C, H, W, s) in LAYERS:
         alg = (B * C * H * W + B * C * Ho * Wo) * 2
         print('dw fwd  %dx%dx%dx%d s%d  %7.1f us  %6.0f GB/s   y %s  stats %s  sum %.6e' % (
             B, C, H, W, s, t, alg / t / 1e3, digest(ys[0]), digest(stats.sum(0).float()), stats.sum(0)[:C].sum().item()))
-    if which == 'bwd' and s == 1:
+    if which == 'bwd':
         es = [ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev).normal_() for _ in range(nset)]
         yr = [ops.new_nhwc(B, C, Ho, Wo, torch.bfloat16, dev).normal_() for _ in range(nset)]
         eins = [ops.new_nhwc(B, C, H, W, torch.bfloat16, dev) for _ in range(nset)]
@@ -104,8 +104,8 @@ for (B, C, H, W, s) in LAYERS:
         ei1, dw1, st1 = eins[0].float().clone(), dwt.clone() / nset, bst.sum(0)
         t1 = timeit(fused) / nset
         rl = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
-        alg = 4 * B * C * H * W * 2
-        print('dw bwd  %dx%dx%dx%d s%d  one sweep %7.1f us (%5.0f GB/s on 4 passes)  pair %7.1f us   e_in rel %.2e  dW rel %.2e  stats rel %.2e' % (
+        alg = (2 * B * C * H * W + 2 * B * C * Ho * Wo) * 2
+        print('dw bwd  %dx%dx%dx%d s%d  one sweep %7.1f us (%5.0f GB/s on e, y, x, e_in once)  pair %7.1f us   e_in rel %.2e  dW rel %.2e  stats rel %.2e' % (
             B, C, H, W, s, t1, alg / t1 / 1e3, t0, rl(ei1, ei0), rl(dw1, dw0), rl(st1, st0)))
         del es, yr, eins
     del xs, ys

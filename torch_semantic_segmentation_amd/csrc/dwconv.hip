@@ -1061,7 +1061,7 @@ int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr
       tss::ProfScope prof(TSS_K_DWCONV_BWD_DATA, (hipStream_t)stream,
                           ((double)Po * (yraw ? 2 : 1) + (double)P * 2) * C * esz(dtype), 36.0 * Po * C);
       rows = tss::dwroll_bwd_fused(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, x, ldx, in_mean, in_scale, in_bias, in_relu, x_pending,
-                                   e_in, ldei, bstats, ws, B, Hin, Win, C, (hipStream_t)stream);
+                                   e_in, ldei, bstats, ws, B, Hin, Win, C, stride, (hipStream_t)stream);
     }
     hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
     return tss::check_last("dwconv_bwd_fused");

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(NT, 2) void dw_fwd_roll_kernel(const RollArgs g) {
       if (S == 1) arrived<K::NRAW * (PF - 1)>(raw[k][0], raw[k][1]);
       else arrived<K::NRAW * (PF - 1)>(raw[k][0], raw[k][1], raw[k][2], raw[k][3 % K::NRAW], raw[k][4 % K::NRAW], raw[k][5 % K::NRAW]);
       write(cc, raw[k], slot);
+      asm volatile("" ::: "memory");      // every use of the slot's vectors (the LDS stores) stays in front of its re-request
       issue(ci, raw[k]);
       advance(ci, g, n_iter);
       __syncthreads();
@@ -393,6 +394,22 @@ __device__ __forceinline__ void request2(u32x2& dst, const bf16_t* uniform_base,
 }
 template <int N> __device__ __forceinline__ void arrived2(u32x2& a, u32x2& b, u32x2& c, u32x2& d, u32x2& e, u32x2& f) {
   asm volatile("s_waitcnt vmcnt(%6)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f) : "n"(N));
+}
+// A raw vector that has to outlive the re-request of its slot is moved out HERE, by an instruction of its own placed after
+// the wait.  A plain C++ copy does not do: the wait's "+v" operands are tied, and to keep the old value alive across the next
+// request into the same registers the compiler puts the copy in FRONT of the tied statement -- before the wait, i.e. possibly
+// before the row has arrived (seen in the ISA of the first version of these kernels: v_mov ahead of s_waitcnt, and statistics
+// that were off by 1e-3 whenever a row was late).  tools/check_pending_regs.py scans the ISA for that pattern.
+// The same hazard from the other side: the compiler may SINK a computation on a raw vector below the re-request of its slot
+// (to shorten a live range) -- the raw value then outlives the request, and the relocation copy again lands in front of the
+// wait.  settle() pins values derived from raw vectors before the point where it stands (an empty volatile statement is not
+// reordered against the volatile requests), so every raw vector is dead when its slot is requested again.
+__device__ __forceinline__ void settle(float (&a)[4]) { asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+__device__ __forceinline__ void settle(float4& a) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w)); }
+__device__ __forceinline__ u32x2 keep2(const u32x2& r) {
+  u32x2 o;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=&v"(o[0]), "=&v"(o[1]) : "v"(r[0]), "v"(r[1]));
+  return o;
 }
 __device__ __forceinline__ void unpack4(const u32x2& r, float v[4]) {
   v[0] = __uint_as_float(r[0] << 16); v[1] = __uint_as_float(r[0] & 0xffff0000u);
@@ -556,7 +573,9 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
         const int eh = halo_l ? tid : tid + 2 * g.CVS;
         Gs[slot][eh] = gh; As[slot][eh] = ah;
       }
-      const u32x2 xcur = raw[k][2];
+      const u32x2 xcur = keep2(raw[k][2]);
+      settle(gown); settle(aown);
+      asm volatile("" ::: "memory");      // the LDS stores above are issued (they hold the halo values) before the slot is re-requested
       issue(ci, raw[k]);
       advance(ci, g, n_iter);
       __syncthreads();
@@ -651,29 +670,305 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
   }
 }
 
-void plan_bwd(RollBwdArgs& g) {
+// ------------------------------------------------------------------------------------------------------------------
+// Stride-2 backward in one sweep.  A lane owns 4 channels of ONE output pixel (row o, column po) and of the 2 x 2 input
+// pixels under it (rows 2o-1 and 2o of the step, columns 2po and 2po+1).  Per step: one row of e, y (output resolution) and
+// two rows of x are requested; g and the ODD-column activations go to LDS (an input gradient at an odd column also needs
+// the g of the right neighbour, the weight gradient's left tap the odd column of the left neighbour), the even columns
+// stay in registers.
+//   rows 2o   : e_in[2o][2po]    = w11 g[o][po]                       e_in[2o][2po+1]   = w12 g[o][po] + w10 g[o][po+1]
+//   rows 2o-1 : e_in[2o-1][2po]  = w21 g[o-1][po] + w01 g[o][po]      e_in[2o-1][2po+1] = w22 g[o-1][po] + w20 g[o-1][po+1]
+//                                                                                         + w02 g[o][po] + w00 g[o][po+1]
+//   dW[ky][kx] += g[o'][po] * a[2o'+ky-1][2po+kx-1]   with (o', ky) = (o, 0), (o, 1) on rows 2o-1, 2o and (o-1, 2) on row 2o-1
+// e, y: 1/4 pass each, x and e_in one pass each: 2.5 passes instead of the 4 of the two strip kernels.
+constexpr int B2PF = 2;
+
+struct B2Cursor { int it, b, strip, seg, x0, o0; };
+__device__ __forceinline__ void advance(B2Cursor& c, const RollBwdArgs& g, int n_iter) {
+  if (++c.it == n_iter) {
+    c.it = 0;
+    c.seg += g.dseg;
+    int carry = c.seg >= g.nseg ? 1 : 0;
+    c.seg -= carry * g.nseg;
+    c.strip += g.dstrip + carry;
+    carry = c.strip >= g.nstrips ? 1 : 0;
+    c.strip -= carry * g.nstrips;
+    c.b += g.db + carry;
+    c.x0 = c.strip * g.PXL;
+    c.o0 = c.seg * g.RS;
+  }
+}
+template <int N>
+__device__ __forceinline__ void arrived10(u32x2 (&r)[10]) {
+  asm volatile("s_waitcnt vmcnt(%10)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9])
+               : "n"(N));
+}
+
+// here g.H, g.W are the INPUT extent; the output extent is (Ho, Wo)
+__global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s2_kernel(const RollBwdArgs g, const int Ho, const int Wo) {
+  __shared__ __align__(16) float4 rows_s[6][BENT];   // [slot] g, [2 + 2 * slot + row] odd-column activations of the two input rows
+  static_assert(sizeof(float4) * 6 * BENT >= sizeof(float) * (NT * 16 + NT), "flush_slab scratch");
+  const int tid = threadIdx.x;
+  const int p = tid / g.CVS, cg = tid - p * g.CVS;
+  const int sl = (int)blockIdx.x % g.nsl, brow = (int)blockIdx.x / g.nsl;
+  const int ch = sl * 64 + cg * 4;
+  const bool lane_on = p < g.PXL && ch < g.C;
+  const int c0 = lane_on ? ch : 0;
+  const bool halo_l = lane_on && p == 0, halo_r = lane_on && p == g.PXL - 1;
+  const int lde = (int)g.lde, ldx = (int)g.ldx;
+  const bf16_t* ysrc = g.yr ? g.yr : g.e;
+  const int ldyy = g.yr ? (int)g.ldyr : lde;
+  const long ldyl = g.yr ? g.ldyr : g.lde;
+
+  const int n_iter = g.RS + 1;
+  B2Cursor ci, cc;
+  ci.it = 0;
+  ci.seg = brow % g.nseg;
+  ci.strip = (brow / g.nseg) % g.nstrips;
+  ci.b = brow / (g.nseg * g.nstrips);
+  ci.x0 = ci.strip * g.PXL;
+  ci.o0 = ci.seg * g.RS;
+  cc = ci;
+
+  // raw[.][0..3]: e, y under the lane's output pixel and of its right neighbour column (edge lane; others re-request their own)
+  // raw[.][4..9]: x rows 2o-1 / 2o: columns 2po, 2po+1 and the column left of the strip (edge lane; others re-request 2po)
+  u32x2 raw[B2PF][10];
+  auto issue = [&](const B2Cursor& c, u32x2 (&r)[10]) {
+    const int b = c.b < g.B ? c.b : g.B - 1;
+    const int o = c.o0 + c.it;
+    const long orow = ((long)b * Ho + clampi(o, 0, Ho - 1)) * Wo;
+    const bf16_t* re = g.e + orow * g.lde;
+    const bf16_t* ry = ysrc + orow * ldyl;
+    const int po = clampi(c.x0 + p, 0, Wo - 1), pr = clampi(c.x0 + (halo_r ? p + 1 : p), 0, Wo - 1);
+    request2(r[0], re, po * lde + c0);
+    request2(r[1], ry, po * ldyy + c0);
+    request2(r[2], re, pr * lde + c0);
+    request2(r[3], ry, pr * ldyy + c0);
+    const int ix = 2 * (c.x0 + p);
+    const int x0c = clampi(ix, 0, g.W - 1), x1c = clampi(ix + 1, 0, g.W - 1), xlc = clampi(halo_l ? ix - 1 : ix, 0, g.W - 1);
+#pragma unroll
+    for (int ry2 = 0; ry2 < 2; ++ry2) {
+      const int iy = clampi(2 * o - 1 + ry2, 0, g.H - 1);
+      const bf16_t* rx = g.x + ((long)b * g.H + iy) * g.W * g.ldx;
+      request2(r[4 + 3 * ry2], rx, x0c * ldx + c0);
+      request2(r[5 + 3 * ry2], rx, x1c * ldx + c0);
+      request2(r[6 + 3 * ry2], rx, xlc * ldx + c0);
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < B2PF; ++k) {
+    issue(ci, raw[k]);
+    advance(ci, g, n_iter);
+  }
+
+  float ca[4], cb[4], kd[4], sc[4], sh[4], mu[4];
+  {
+    const float* safe = g.w;
+    float t0[4], t1[4], t2[4], t3[4];
+    V4<float>::load(g.ga ? g.ga + c0 : safe, t0);
+    V4<float>::load(g.yr ? g.gb + c0 : safe, t1);
+    V4<float>::load(g.yr ? g.gce + c0 : safe, t2);
+    V4<float>::load(g.yr ? g.gmu + c0 : safe, t3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ca[j] = g.ga ? t0[j] : 1.f;
+      cb[j] = g.yr ? t1[j] : 0.f;
+      kd[j] = g.yr ? -(ca[j] * t2[j]) - cb[j] * t3[j] : 0.f;
+    }
+    const bool has = g.xs != nullptr;
+    V4<float>::load(has ? g.xs + c0 : safe, t0);
+    V4<float>::load(has && g.xb ? g.xb + c0 : safe, t1);
+    V4<float>::load(g.xm ? g.xm + c0 : safe, t2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sc[j] = has ? t0[j] : 1.f;
+      mu[j] = g.xm ? t2[j] : 0.f;
+      sh[j] = __builtin_fmaf(-(has ? mu[j] : 0.f), sc[j], (has && g.xb) ? t1[j] : 0.f);
+    }
+  }
+  float wr[9][4];
+  {
+    float wf[36];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) V4<float>::load(g.w + (long)c0 * 9 + 4 * q, wf + 4 * q);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wr[t][j] = wf[j * 9 + t];
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+  float dwa[9][4], gprev[4], gprev_r[4], s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    gprev[j] = gprev_r[j] = s1[j] = s2[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dwa[t][j] = 0.f;
+  }
+
+  auto g_of = [&](const u32x2& re, const u32x2& ry, bool valid, float (&go)[4]) {
+    float ev[4], yv[4];
+    unpack4(re, ev); unpack4(ry, yv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) go[j] = valid ? ca[j] * ev[j] + (cb[j] * yv[j] + kd[j]) : 0.f;
+  };
+  auto a_of = [&](const u32x2& rx, bool valid, float (&ao)[4]) {
+    float xv[4];
+    unpack4(rx, xv);
+    const float lo = valid ? relu_lo : 0.f, hi = valid ? TSS_INF : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ao[j] = clamp3(xv[j] * sc[j] + sh[j], lo, hi);
+  };
+  auto put4 = [&](float4* row, int e, const float (&v)[4]) { row[e] = make_float4(v[0], v[1], v[2], v[3]); };
+  auto get4 = [&](const float4* row, int e, float (&v)[4]) { const float4 t = row[e]; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; };
+  // finished input-gradient vector at (row q, column px): ReLU mask of the producer, statistics, store
+  auto emit = [&](const B2Cursor& c, int q, int px, const u32x2& xraw, float (&acc)[4]) {
+    if (q >= 0 && q < g.H && px < g.W) {
+      float out[4];
+      if (g.x_mask) {
+        float xv[4];
+        unpack4(xraw, xv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool dead = g.x_relu && !(xv[j] * sc[j] + sh[j] > 0.f);
+          out[j] = V8<bf16_t>::round(dead ? 0.f : acc[j]);
+          s1[j] += out[j];
+          s2[j] += out[j] * (xv[j] - mu[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = acc[j];
+      }
+      V4<bf16_t>::store(g.ein + (((long)c.b * g.H + q) * g.W + px) * g.ldei + c0, out);
+    }
+  };
+
+  int slot = 0;
+  while (cc.b < g.B) {
+#pragma unroll
+    for (int k = 0; k < B2PF; ++k) {
+      if (cc.b >= g.B) break;
+      arrived10<10 * (B2PF - 1)>(raw[k]);
+      const int o = cc.o0 + cc.it;
+      const bool vo = o < Ho;                       // o >= 0 always
+      const int r0 = 2 * o - 1, r1 = 2 * o;
+      const bool v0 = r0 >= 0 && r0 < g.H, v1 = r1 < g.H;
+      const int ix = 2 * (cc.x0 + p);
+      float gown[4], a00[4], a01[4], a10[4], a11[4];     // a[row 0/1][even/odd column]
+      g_of(raw[k][0], raw[k][1], vo && cc.x0 + p < Wo, gown);
+      a_of(raw[k][4], v0 && ix < g.W, a00);
+      a_of(raw[k][5], v0 && ix + 1 < g.W, a01);
+      a_of(raw[k][7], v1 && ix < g.W, a10);
+      a_of(raw[k][8], v1 && ix + 1 < g.W, a11);
+      float4* Gs = rows_s[slot];
+      float4* A0 = rows_s[2 + 2 * slot];
+      float4* A1 = rows_s[3 + 2 * slot];
+      if (p < g.PXL) { put4(Gs, tid, gown); put4(A0, tid + g.CVS, a01); put4(A1, tid + g.CVS, a11); }
+      if (halo_r) {
+        float gh[4];
+        g_of(raw[k][2], raw[k][3], vo && cc.x0 + g.PXL < Wo, gh);
+        put4(Gs, tid + g.CVS, gh);
+      }
+      if (halo_l) {
+        float ah[4];
+        a_of(raw[k][6], v0 && ix - 1 >= 0, ah);
+        put4(A0, tid, ah);
+        a_of(raw[k][9], v1 && ix - 1 >= 0, ah);
+        put4(A1, tid, ah);
+      }
+      const u32x2 x00 = keep2(raw[k][4]), x01 = keep2(raw[k][5]), x10 = keep2(raw[k][7]), x11 = keep2(raw[k][8]);
+      settle(gown); settle(a00); settle(a01); settle(a10); settle(a11);
+      asm volatile("" ::: "memory");
+      issue(ci, raw[k]);
+      advance(ci, g, n_iter);
+      __syncthreads();
+      if (lane_on) {
+        float gr[4], al0[4], al1[4];       // g of the right neighbour, odd-column activations of the left neighbour
+        get4(Gs, tid + g.CVS, gr);
+        get4(A0, tid, al0);
+        get4(A1, tid, al1);
+        const bool first = cc.it == 0, last = cc.it == g.RS;
+        float e0[4], e1[4];
+        if (!first) {          // row 2o-1 belongs to this unit from its second step on
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            e0[j] = wr[7][j] * gprev[j]; e0[j] += wr[1][j] * gown[j];
+            e1[j] = wr[8][j] * gprev[j]; e1[j] += wr[6][j] * gprev_r[j]; e1[j] += wr[2][j] * gown[j]; e1[j] += wr[0][j] * gr[j];
+          }
+          emit(cc, r0, ix, x00, e0);
+          emit(cc, r0, ix + 1, x01, e1);
+        }
+        if (!last) {           // row 2o
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            e0[j] = wr[4][j] * gown[j];
+            e1[j] = wr[5][j] * gown[j]; e1[j] += wr[3][j] * gr[j];
+          }
+          emit(cc, r1, ix, x10, e0);
+          emit(cc, r1, ix + 1, x11, e1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gc = last ? 0.f : gown[j], gp = first ? 0.f : gprev[j];
+          dwa[0][j] += gc * al0[j]; dwa[1][j] += gc * a00[j]; dwa[2][j] += gc * a01[j];     // (o, ky 0): row 2o-1
+          dwa[3][j] += gc * al1[j]; dwa[4][j] += gc * a10[j]; dwa[5][j] += gc * a11[j];     // (o, ky 1): row 2o
+          dwa[6][j] += gp * al0[j]; dwa[7][j] += gp * a00[j]; dwa[8][j] += gp * a01[j];     // (o-1, ky 2): row 2o-1
+          gprev[j] = gown[j]; gprev_r[j] = gr[j];
+        }
+      }
+      advance(cc, g, n_iter);
+      slot ^= 1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < B2PF; ++k) arrived10<0>(raw[k]);
+
+  float* red = reinterpret_cast<float*>(&rows_s[0][0]);
+  if (g.stats) flush_slab<4>(s1, s2, g.stats, g.C, g.CVS, g.PXL, sl, brow, g.rows_used, p, cg, lane_on, red);
+  float* wrow = g.ws + (long)brow * g.C * 9;
+  const int cw = g.CVS * 4;
+#pragma unroll
+  for (int t0 = 0; t0 < 9; t0 += 3) {
+    __syncthreads();
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt)
+      *reinterpret_cast<float4*>(red + tid * 12 + tt * 4) =
+          lane_on ? make_float4(dwa[t0 + tt][0], dwa[t0 + tt][1], dwa[t0 + tt][2], dwa[t0 + tt][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (int i = tid; i < cw * 3; i += NT) {
+      const int c = i / 3, tt = i - c * 3;
+      const int cgc = c >> 2, j = c & 3;
+      if (sl * 64 + c < g.C) {
+        float sum = 0.f;
+        for (int q = 0; q < g.PXL; ++q) sum += red[(q * g.CVS + cgc) * 12 + tt * 4 + j];
+        wrow[(long)(sl * 64 + c) * 9 + t0 + tt] = sum;
+      }
+    }
+  }
+}
+
+void plan_bwd(RollBwdArgs& g, int S, int Ho, int Wo) {
   const int cv4 = g.C / 4;
   g.nsl = (g.C + 63) / 64;
   g.CVS = cv4 < 16 ? cv4 : 16;
   g.PXL = NT / g.CVS;
-  g.nstrips = (g.W + g.PXL - 1) / g.PXL;
+  g.nstrips = (Wo + g.PXL - 1) / g.PXL;              // strips and segments partition the OUTPUT pixels
   const int cap = TSS_STAT_SLABS / g.nsl > 0 ? TSS_STAT_SLABS / g.nsl : 1;
+  const int halo = S == 1 ? 2 : 1;
   long best_cost = -1;
-  long units_best = 0;
-  for (int nseg = 1; nseg <= g.H; ++nseg) {
-    const int RS = (g.H + nseg - 1) / nseg;
+  for (int nseg = 1; nseg <= Ho; ++nseg) {
+    const int RS = (Ho + nseg - 1) / nseg;
     if (RS < 4 && nseg > 1) break;
-    const int segs = (g.H + RS - 1) / RS;
+    const int segs = (Ho + RS - 1) / RS;
     const long units = (long)g.B * g.nstrips * segs;
     const long k = (units + cap - 1) / cap;
-    const long cost = k * (RS + 2) + 6;
+    const long cost = k * (RS + halo) + 6;
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
-      g.RS = RS; g.nseg = segs; units_best = units;
+      g.RS = RS; g.nseg = segs;
       g.rows_used = (int)((units + k - 1) / k);
     }
   }
-  (void)units_best;
   g.dseg = g.rows_used % g.nseg;
   g.dstrip = (g.rows_used / g.nseg) % g.nstrips;
   g.db = g.rows_used / (g.nseg * g.nstrips);
@@ -712,20 +1007,22 @@ void dwroll_fwd(const void* x, long ldx, const float* in_mean, const float* in_s
 bool dwroll_bwd_fused_supported(int C, int stride, int dil, int dtype) {
   const char* sw = getenv("TSS_DW_ROLL_BWD");
   const bool on = !(sw && atoi(sw) == 0);
-  return on && dtype == TSS_BF16 && dil == 1 && stride == 1 && C >= 8 && (C % 8) == 0 && C <= 768;
+  return on && dtype == TSS_BF16 && dil == 1 && (stride == 1 || stride == 2) && C >= 8 && (C % 8) == 0 && C <= 768;
 }
 
 int dwroll_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
                      const float* gmu, const float* w, const void* x, long ldx, const float* in_mean, const float* in_scale,
                      const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei, double* bstats, float* ws,
-                     int B, int H, int W, int C, hipStream_t stream) {
+                     int B, int H, int W, int C, int stride, hipStream_t stream) {
   RollBwdArgs g = {};
   g.e = (const bf16_t*)e; g.lde = lde; g.yr = (const bf16_t*)yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
   g.w = w; g.x = (const bf16_t*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.x_mask = x_pending; g.ein = (bf16_t*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
   g.B = B; g.H = H; g.W = W; g.C = C;
-  plan_bwd(g);
-  hipLaunchKernelGGL(dw_bwd_roll_s1_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  plan_bwd(g, stride, Ho, Wo);
+  if (stride == 1) hipLaunchKernelGGL(dw_bwd_roll_s1_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
+  else hipLaunchKernelGGL(dw_bwd_roll_s2_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g, Ho, Wo);
   return g.rows_used;
 }
 
