@@ -17,7 +17,8 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     {"pwconv_bwd_weight", "wgfast_kernel|wgrad_kernel"},
     {"conv3x3_fwd", "conv3x3_lean_kernel<false>|convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "conv3x3_lean_kernel<true>|convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
     {"stem3x3_fwd", "stem_fwd_mfma_kernel|convgemm_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_mfma_kernel|stem_wgrad_kernel"},
-    {"dwconv3x3_fwd", "dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_data_strip_kernel"},
+    // (dwconv3x3_bwd_data also carries the one-sweep backward, dw_bwd_roll_s{1,2}_kernel: input gradient + weight gradient)
+    {"dwconv3x3_fwd", "dw_fwd_roll_kernel|dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_roll_s1_kernel|dw_bwd_roll_s2_kernel|dw_bwd_data_strip_kernel"},
     {"dwconv3x3_bwd_weight", "dw_bwd_weight_strip_kernel"},
     {"bn_finalize", "bn_finalize_kernel"}, {"bn_bwd_finalize", "bn_bwd_finalize_kernel"},
     {"join_fwd", "join_fwd_kernel"}, {"join_bwd", "join_bwd_kernel"},
