@@ -62,9 +62,20 @@ def main():
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'dwroll.s')
-        subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-S',
-                        '--cuda-device-only', os.path.join(CSRC, 'dwroll.hip'), '-o', out], check=True, capture_output=True)
+        res = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-S',
+                              '--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', os.path.join(CSRC, 'dwroll.hip'), '-o', out],
+                             check=True, capture_output=True, text=True)
         problems = check(open(out).read())
+        # a spilled register may be one with a request in flight (seen: a memory fault in an experimental build with 100 bytes
+        # of scratch): the row-pipelined kernels must not spill at all
+        name = None
+        for ln in res.stderr.split('\n'):
+            m = re.search(r'Function Name: (\S+)', ln)
+            if m:
+                name = m.group(1)
+            m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', ln)
+            if m and name and 'roll' in name and int(m.group(1)) != 0:
+                problems.append('%s: %s bytes of scratch per lane' % (name, m.group(1)))
     for pr in problems:
         print(pr)
     print('%d compiler-made reads of request destination registers' % len(problems))

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtss_hip.so')
+LIB_PATH = os.environ.get('TSS_HIP_LIB') or os.path.join(_HERE, 'libtss_hip.so')   # TSS_HIP_LIB: A/B builds (tools/ab_variants.sh)
 
 TSS_F32, TSS_BF16 = 0, 1
 ERRORS = {-1: 'TSS_ERR_DTYPE (unsupported dtype)', -2: 'TSS_ERR_SHAPE (unsupported shape or pitch)',

@@ -126,8 +126,20 @@ __device__ __forceinline__ void flush_slab(const float (&s1)[NC], const float (&
 }
 
 template <int S> struct RollCfg;
-template <> struct RollCfg<1> { static constexpr int PF = 6, NRAW = 2, ROWS = 1, ARRS = 1; };   // raw: main, halo
-template <> struct RollCfg<2> { static constexpr int PF = 3, NRAW = 6, ROWS = 2, ARRS = 2; };   // raw: per row main0, main1, halo
+#ifndef TSS_ROLL_PF1
+#define TSS_ROLL_PF1 6
+#endif
+#ifndef TSS_ROLL_PF2
+#define TSS_ROLL_PF2 2
+#endif
+#ifndef TSS_ROLL_BPF1
+#define TSS_ROLL_BPF1 4
+#endif
+#ifndef TSS_ROLL_BPF2
+#define TSS_ROLL_BPF2 2
+#endif
+template <> struct RollCfg<1> { static constexpr int PF = TSS_ROLL_PF1, NRAW = 2, ROWS = 1, ARRS = 1; };   // raw: main, halo
+template <> struct RollCfg<2> { static constexpr int PF = TSS_ROLL_PF2, NRAW = 6, ROWS = 2, ARRS = 2; };   // raw: per row main0, main1, halo
 
 template <int S>
 __global__ __launch_bounds__(NT, 2) void dw_fwd_roll_kernel(const RollArgs g) {
@@ -425,8 +437,16 @@ struct RollBwdArgs {
   int B, H, W, C;
   int CVS, PXL, nsl, nstrips, RS, nseg, rows_used, dseg, dstrip, db;
 };
+#ifdef TSS_ROLL_TIMING
+// debug build (tools/ab_variants.sh ... "-DTSS_ROLL_TIMING"): cycles of wave 0 of every block of dw_bwd_roll_s1_kernel, summed:
+// [wait for the row, transform + park, barrier, window + sums + emit, prologue, tail, -, blocks]
+__device__ unsigned long long g_roll_timing[8];
+#define TSS_RT(var) unsigned long long var; asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#else
+#define TSS_RT(var)
+#endif
 constexpr int BENT = NT + 32;      // LDS row: PXL * CVS <= 256 entries + two halo pixels (2 * CVS <= 32)
-constexpr int BPF = 4;             // steps in flight
+constexpr int BPF = TSS_ROLL_BPF1;   // steps in flight
 
 struct BCursor { int it, b, strip, seg, x0, o0; };
 __device__ __forceinline__ void advance(BCursor& c, const RollBwdArgs& g, int n_iter) {
@@ -445,6 +465,10 @@ __device__ __forceinline__ void advance(BCursor& c, const RollBwdArgs& g, int n_
 }
 
 __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs g) {
+  TSS_RT(rt_begin);
+#ifdef TSS_ROLL_TIMING
+  unsigned long long rt_ph[4] = {0, 0, 0, 0}, rt_ph4 = 0;
+#endif
   __shared__ __align__(16) float4 rows_s[4][BENT];   // [slot] g rows, [2 + slot] activated input rows; entry = window column * CVS + lane
   float4 (*Gs)[BENT] = rows_s;
   float4 (*As)[BENT] = rows_s + 2;
@@ -556,12 +580,15 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
     av = make_float4(ao[0], ao[1], ao[2], ao[3]);
   };
 
+  TSS_RT(rt_loop);
   int slot = 0;
   while (cc.b < g.B) {
 #pragma unroll
     for (int k = 0; k < BPF; ++k) {
       if (cc.b >= g.B) break;
+      TSS_RT(rt0);
       arrived2<6 * (BPF - 1)>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
+      TSS_RT(rt1);
       const int r = cc.o0 - 1 + cc.it;
       const bool vy = r >= 0 && r < g.H;
       float4 gown, aown;
@@ -576,9 +603,12 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
       const u32x2 xcur = keep2(raw[k][2]);
       settle(gown); settle(aown);
       asm volatile("" ::: "memory");      // the LDS stores above are issued (they hold the halo values) before the slot is re-requested
+      TSS_RT(rt1a);
       issue(ci, raw[k]);
       advance(ci, g, n_iter);
+      TSS_RT(rt2);
       __syncthreads();
+      TSS_RT(rt3);
       if (lane_on) {
         float G[3][4], A[3][4];     // window columns p-1, p, p+1
 #pragma unroll
@@ -637,10 +667,16 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
         }
         xprev = xcur;
       }
+#ifdef TSS_ROLL_TIMING
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * BPF));     // (the store of this step; the row requests stay in flight)
+      TSS_RT(rt4);
+      rt_ph[0] += rt1 - rt0; rt_ph[1] += rt2 - rt1a; rt_ph[2] += rt3 - rt2; rt_ph[3] += rt4 - rt3; rt_ph4 += rt1a - rt1;
+#endif
       advance(cc, g, n_iter);
       slot ^= 1;
     }
   }
+  TSS_RT(rt_tail);
   // the last BPF requests are never used but must land before their registers are reused (see the forward kernel)
 #pragma unroll
   for (int k = 0; k < BPF; ++k) arrived2<0>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
@@ -668,6 +704,17 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
       }
     }
   }
+#ifdef TSS_ROLL_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  TSS_RT(rt_end);
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) atomicAdd(&g_roll_timing[q], rt_ph[q]);
+    atomicAdd(&g_roll_timing[4], rt_loop - rt_begin);
+    atomicAdd(&g_roll_timing[5], rt_end - rt_tail);
+    atomicAdd(&g_roll_timing[6], rt_ph4);
+    atomicAdd(&g_roll_timing[7], 1ull);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -681,7 +728,7 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
 //                                                                                         + w02 g[o][po] + w00 g[o][po+1]
 //   dW[ky][kx] += g[o'][po] * a[2o'+ky-1][2po+kx-1]   with (o', ky) = (o, 0), (o, 1) on rows 2o-1, 2o and (o-1, 2) on row 2o-1
 // e, y: 1/4 pass each, x and e_in one pass each: 2.5 passes instead of the 4 of the two strip kernels.
-constexpr int B2PF = 2;
+constexpr int B2PF = TSS_ROLL_BPF2;
 
 struct B2Cursor { int it, b, strip, seg, x0, o0; };
 __device__ __forceinline__ void advance(B2Cursor& c, const RollBwdArgs& g, int n_iter) {
@@ -953,7 +1000,7 @@ void plan_bwd(RollBwdArgs& g, int S, int Ho, int Wo) {
   g.CVS = cv4 < 16 ? cv4 : 16;
   g.PXL = NT / g.CVS;
   g.nstrips = (Wo + g.PXL - 1) / g.PXL;              // strips and segments partition the OUTPUT pixels
-  const int cap = TSS_STAT_SLABS / g.nsl > 0 ? TSS_STAT_SLABS / g.nsl : 1;
+  const int cap = TSS_STAT_SLABS / g.nsl > 0 ? TSS_STAT_SLABS / g.nsl : 1;     // 2 blocks per CU over all slices
   const int halo = S == 1 ? 2 : 1;
   long best_cost = -1;
   for (int nseg = 1; nseg <= Ho; ++nseg) {
@@ -1027,3 +1074,11 @@ int dwroll_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const
 }
 
 }  // namespace tss
+
+#ifdef TSS_ROLL_TIMING
+extern "C" int tss_debug_roll_timing(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_roll_timing), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_roll_timing), z, sizeof(z)); }
+  return 0;
+}
+#endif
