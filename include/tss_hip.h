@@ -176,6 +176,16 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
  * sums, added to dw ([C][1][3][3]) by a second small launch.  tss_dwconv3x3_bwd_fused_supported: 1 when this entry
  * covers the shape. */
 int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype);
+/* The same sweep without the second launch: the per-block rows stay in ws, *rows_out (host) receives their number, and the caller
+ * adds them to the weight gradients of many layers at once with tss_dw_reduce_many (arrays of njobs device pointers / sizes in
+ * HOST memory: ws[j] = rows[j] x n[j] floats, dw[j][i] += sum over the rows; n = C * 9).  A training step has one such 5 us
+ * reduction per depthwise layer and nothing but the optimizer waits for them. */
+int tss_dwconv3x3_bwd_fused_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                                  const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                                  const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                  int x_pending, void* e_in, long ldei, double* bstats, float* ws,
+                                  int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream, int* rows_out);
+int tss_dw_reduce_many(int njobs, const float* const* ws, float* const* dw, const int* n, const int* rows, void* stream);
 /* 1 when the one-sweep backward is also the faster choice for this layer (row-pipelined kernels, csrc/dwroll.hip) */
 int tss_dwconv3x3_bwd_fused_preferred(int C, int stride, int dil, int dtype);
 int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr,

@@ -515,3 +515,41 @@ def test_ohem_loss_matches_reference_formula(case, dtype):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert abs(la.item() / lb.item() - 1) < tol
     assert rel(a.grad, b.grad) < tol
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
+    """Direct gradients (ops.direct_grads, the trainer's mode): the per-block rows of the one-sweep depthwise backward are summed
+    for all layers together at the end of the backward pass (tss_dw_reduce_many) -- same gradients as with one reduction launch
+    per layer, and nothing left pending afterwards."""
+    import importlib
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+
+    def run(batched):
+        torch.manual_seed(29)
+        m = nn.Sequential(F_.Conv2dBlock(24, 48, 1), F_.DWConv2dBlock(48, 48, kernel_size=3, padding=1, stride=stride),
+                          F_.Conv2dBlock(48, 72, 1), F_.DWConv2dBlock(72, 72, kernel_size=3, padding=1), F_.Conv2dBlock(72, 16, 1)).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p)
+        x = torch.randn(2, 24, 19, 27, device=DEV)
+        old = ops.batch_dw_reductions
+        ops.batch_dw_reductions = batched
+        try:
+            with ops.direct_grads(True):
+                out = m(x)
+                out.float().backward(torch.randn_like(out, dtype=torch.float32))
+        finally:
+            ops.batch_dw_reductions = old
+        assert not ops._pending_dw
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+    g1, g0 = run(True), run(False)
+    for k in g0:
+        if k in ('1.0.weight', '3.0.weight'):          # the depthwise weights: same rows, same summation order
+            assert torch.equal(g1[k], g0[k]), k
+        elif g0[k].norm() > 1e-3:                      # (small 1x1 weight gradients use float atomics: not bit-reproducible)
+            assert rel(g1[k], g0[k]) < 1e-4, k

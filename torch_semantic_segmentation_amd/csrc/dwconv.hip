@@ -417,6 +417,18 @@ __global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* 
   dw_reduce_block(ws, dw, n, rows, blockIdx.x, part);
 }
 
+// the row reductions of several layers in ONE launch (blockIdx.y = layer): the one-sweep backward of a depthwise layer leaves
+// its per-block rows in a workspace, and a training step has 13-17 such layers whose 5 us reductions nobody waits for
+// before the optimizer -- they are collected and summed together at the end of the backward pass
+constexpr int RED_MANY = 16;
+struct ReduceJobs { const float* ws[RED_MANY]; float* dw[RED_MANY]; int n[RED_MANY]; int rows[RED_MANY]; };
+__global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_many_kernel(const ReduceJobs j) {
+  __shared__ float part[RED_WAVES * 64];
+  const int job = blockIdx.y;
+  if ((int)blockIdx.x * 64 >= j.n[job]) return;
+  dw_reduce_block(j.ws[job], j.dw[job], j.n[job], j.rows[job], blockIdx.x, part);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Strip kernels: one lane owns 8 channels of FOUR pixels of a row (consecutive for stride 2, D apart for stride 1).  The
 // 3 x NCOL input window of a strip is loaded once (NCOL = 6 for stride 1 at any dilation, 9 for stride 2)
@@ -1033,11 +1045,52 @@ int tss_dwconv3x3_bwd_fused_supported(int C, int stride, int dil, int dtype) {
   return dtype == TSS_BF16 && strip_supported(stride, dil) && C > 0 && (C % 8) == 0 && C <= 768;
 }
 
+int tss_dw_reduce_many(int njobs, const float* const* ws, float* const* dw, const int* n, const int* rows, void* stream) {
+  TSS_REQUIRE(njobs >= 0 && (njobs == 0 || (ws && dw && n && rows)), TSS_ERR_SHAPE);
+  for (int j0 = 0; j0 < njobs; j0 += RED_MANY) {
+    ReduceJobs jobs = {};
+    const int cnt = njobs - j0 < RED_MANY ? njobs - j0 : RED_MANY;
+    int nmax = 0;
+    for (int q = 0; q < cnt; ++q) {
+      TSS_REQUIRE(ws[j0 + q] && dw[j0 + q] && n[j0 + q] > 0 && rows[j0 + q] > 0, TSS_ERR_SHAPE);
+      jobs.ws[q] = ws[j0 + q]; jobs.dw[q] = dw[j0 + q]; jobs.n[q] = n[j0 + q]; jobs.rows[q] = rows[j0 + q];
+      nmax = n[j0 + q] > nmax ? n[j0 + q] : nmax;
+    }
+    hipLaunchKernelGGL(dw_reduce_many_kernel, dim3((nmax + 63) / 64, cnt), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, jobs);
+  }
+  return tss::check_last("dw_reduce_many");
+}
+
+static int bwd_fused_impl(const void* e, long lde, const void* yraw, long ldyr,
+                          const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                          const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                          int x_pending, void* e_in, long ldei, double* bstats, float* ws, float* dw,
+                          int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream, int* rows_out);
+
 int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr,
                             const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
                             const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                             int x_pending, void* e_in, long ldei, double* bstats, float* ws, float* dw,
                             int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream) {
+  return bwd_fused_impl(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, x, ldx, in_mean, in_scale, in_bias, in_relu, x_pending, e_in, ldei,
+                        bstats, ws, dw, B, Hin, Win, C, stride, dil, dtype, stream, nullptr);
+}
+
+int tss_dwconv3x3_bwd_fused_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                                  const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                                  const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                  int x_pending, void* e_in, long ldei, double* bstats, float* ws,
+                                  int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream, int* rows_out) {
+  TSS_REQUIRE(rows_out != nullptr, TSS_ERR_SHAPE);
+  return bwd_fused_impl(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, x, ldx, in_mean, in_scale, in_bias, in_relu, x_pending, e_in, ldei,
+                        bstats, ws, reinterpret_cast<float*>(ws) /* unused */, B, Hin, Win, C, stride, dil, dtype, stream, rows_out);
+}
+
+static int bwd_fused_impl(const void* e, long lde, const void* yraw, long ldyr,
+                            const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                            const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                          int x_pending, void* e_in, long ldei, double* bstats, float* ws, float* dw,
+                          int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream, int* rows_out) {
   TSS_REQUIRE(tss_dwconv3x3_bwd_fused_supported(C, stride, dil, dtype), TSS_ERR_SHAPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= C && (ldei % 8) == 0 && ldei >= C && (ldx % 8) == 0 && ldx >= C, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= C && ga && gb && gce && gmu), TSS_ERR_SHAPE);
@@ -1063,7 +1116,8 @@ int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr
       rows = tss::dwroll_bwd_fused(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, x, ldx, in_mean, in_scale, in_bias, in_relu, x_pending,
                                    e_in, ldei, bstats, ws, B, Hin, Win, C, stride, (hipStream_t)stream);
     }
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
+    if (rows_out) *rows_out = rows;      // the caller sums the rows later (tss_dw_reduce_many)
+    else hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, rows);
     return tss::check_last("dwconv_bwd_fused");
   }
   const long U = (long)B * Hin * ((Win + WG_SW - 1) / WG_SW);
@@ -1073,7 +1127,8 @@ int tss_dwconv3x3_bwd_fused(const void* e, long lde, const void* yraw, long ldyr
                         ((double)Po * (yraw ? 2 : 1) + (double)P * 2) * C * esz(dtype), 36.0 * Po * C);
     launch_strip_fused(g, sgrid, threads, (hipStream_t)stream);
   }
-  hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, sgrid);
+  if (rows_out) *rows_out = sgrid;
+  else hipLaunchKernelGGL(dw_reduce_kernel, dim3((C * 9 + 63) / 64), dim3(RED_WAVES * 64), 0, (hipStream_t)stream, ws, dw, C * 9, sgrid);
   return tss::check_last("dwconv_bwd_fused");
 }
 

@@ -12,6 +12,7 @@ ordinary tensors with ordinary gradients.
 
 There is no torch/ATen fallback here: every operator calls the C ABI and raises if it is unavailable.
 """
+import ctypes
 import os
 
 import torch
@@ -53,6 +54,38 @@ overlap_wgrad = os.environ.get('TSS_OVERLAP_WGRAD', '0') == '1'   # measured: no
 fuse_dw_backward = os.environ.get('TSS_FUSE_DW_BWD', '0') == '1'
 overlap_max_elems = int(os.environ.get('TSS_OVERLAP_MAX', str(48 << 20)))   # only layers too small to fill the chip on their own (large ones just contend)
 overlap_min_elems = int(os.environ.get('TSS_OVERLAP_MIN', '0'))
+# the row reductions of the one-sweep depthwise backward, collected over a backward pass and summed in one launch at its end
+# (only for gradients written straight into their final buffer: a gradient RETURNED to autograd must be complete on return)
+batch_dw_reductions = os.environ.get('TSS_BATCH_DW_REDUCE', '1') == '1'
+_pending_dw = []
+
+
+def _flush_dw_reductions():
+    jobs = list(_pending_dw)
+    del _pending_dw[:]
+    if not jobs:
+        return
+    n = len(jobs)
+    ws = (ctypes.c_void_p * n)(*[j[0].data_ptr() for j in jobs])
+    dw = (ctypes.c_void_p * n)(*[j[1].data_ptr() for j in jobs])
+    cols = (ctypes.c_int * n)(*[j[2] for j in jobs])
+    rows = (ctypes.c_int * n)(*[j[3] for j in jobs])
+    with torch.cuda.device(jobs[0][0].device):
+        call('tss_dw_reduce_many', n, ws, dw, cols, rows, stream())
+
+
+def _defer_dw_reduction(ws, dw, ncols, nrows):
+    task = torch._C._current_graph_task_id()
+    if _pending_dw and _pending_dw[0][4] != task:
+        del _pending_dw[:]       # left over from a backward pass that raised before its callback ran: those gradients are void
+    if not _pending_dw:          # first job of this backward pass: flush when the engine has run every node
+        torch.autograd.variable.Variable._execution_engine.queue_callback(_flush_dw_reductions)
+    elif _pending_dw[0][0].device != ws.device:
+        _flush_dw_reductions()
+        torch.autograd.variable.Variable._execution_engine.queue_callback(_flush_dw_reductions)
+    _pending_dw.append((ws, dw, ncols, nrows, task))
+
+
 _side_streams = {}
 
 
@@ -653,6 +686,13 @@ class ConvUnitFn(Function):
                 if cfg.kind == 'pw':
                     call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
+                elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
+                    # the rows of per-block partial sums stay in ws; they are added to the (direct) gradient together with
+                    # those of every other depthwise layer, in one launch at the end of this backward pass
+                    rows = ctypes.c_int(0)
+                    call('tss_dwconv3x3_bwd_fused_sweep', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(e_in), ld(e_in),
+                         bst, ptr(ws), B, Hin, Win, Cout, s, d, dt, st, ctypes.byref(rows))
+                    _defer_dw_reduction(ws, dw, Cout * 9, rows.value)
                 elif cfg.kind == 'dw' and fused_dw:
                     call('tss_dwconv3x3_bwd_fused', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(e_in), ld(e_in),
                          bst, ptr(ws), ptr(dw), B, Hin, Win, Cout, s, d, dt, st)
