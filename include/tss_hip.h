@@ -169,6 +169,18 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+/* 1x1 layer, backward in ONE sweep (csrc/pwbwd.hip; bf16, Cin, Cout <= 128, both multiples of 8): e, yraw and x are read once,
+ * e_in written once -- replaces tss_pwconv_bwd_weight + tss_pwconv_bwd_data where their double read of (e, yraw) dominates
+ * (tss_pwconv_bwd_fused_preferred: few channels, many pixels).  x is the layer's input (always given); x_pending = 1 when it is a
+ * producer's raw output (in_* pending): e_in is then masked and bstats written as tss_pwconv_bwd_data does.  ws receives
+ * tss_pwconv_bwd_fused_rows(P, Cin, Cout) rows of Cout*Cin floats (per-block partial sums of dW in the parameter's own
+ * [Cout][Cin] order), to be added to dW by tss_dw_reduce_many.  wT_bf16: optional bf16 [Cin][Cout] shadow of w. */
+int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype);
+int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout);
+int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                         const float* gmu, const float* w, const void* wT_bf16, const void* x, long ldx, const float* in_mean,
+                         const float* in_scale, const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei,
+                         double* bstats, float* ws, long P, int Cin, int Cout, int dtype, void* stream);
 /* backward-data AND weight gradient of one layer in a single sweep (bf16; stride/dilation of the strip kernels): e, yraw
  * and x are read once.  x is the layer's input (always given: the weight gradient needs it); x_pending = 1 when it is a
  * producer's raw output whose BatchNorm(+ReLU) is still pending (in_* describe it): e_in is then masked and bstats

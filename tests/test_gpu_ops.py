@@ -553,3 +553,44 @@ def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
             assert torch.equal(g1[k], g0[k]), k
         elif g0[k].norm() > 1e-3:                      # (small 1x1 weight gradients use float atomics: not bit-reproducible)
             assert rel(g1[k], g0[k]) < 1e-4, k
+
+
+@pytest.mark.parametrize('chans', [(32, 48, 64), (24, 128, 128), (8, 8, 8), (64, 128, 40), (128, 64, 128)])
+@pytest.mark.parametrize('pending', [True, False])
+def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
+    """csrc/pwbwd.hip (input gradient + weight gradient of a 1x1 layer from one pass over e, y, x; used for the few-channel,
+    many-pixel layers) against tss_pwconv_bwd_weight + tss_pwconv_bwd_data on the same operands: ragged pixel count, both
+    register configurations (<= 64 and <= 128 channels), producer BatchNorm pending or not."""
+    import importlib
+    import os
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    c0, c1, c2 = chans
+
+    def run(fused):
+        torch.manual_seed(31)
+        layers = ([F_.Conv2dBlock(c0, c0, 1)] if pending else []) + [F_.Conv2dBlock(c0, c1, 1), F_.Conv2dBlock(c1, c2, 1), F_.Conv2dBlock(c2, 16, 1)]
+        m = nn.Sequential(*layers).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = torch.randn(3, c0, 37, 53, device=DEV).requires_grad_(True)
+        old = os.environ.get('TSS_PW_BWD_FUSED')
+        os.environ['TSS_PW_BWD_FUSED'] = '2' if fused else '0'       # 2: every layer inside the envelope, whatever its pixel count
+        try:
+            out = m(x)
+            out.float().backward(torch.randn_like(out, dtype=torch.float32))
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                del os.environ['TSS_PW_BWD_FUSED']
+            else:
+                os.environ['TSS_PW_BWD_FUSED'] = old
+        return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+    dx1, g1 = run(True)
+    dx0, g0 = run(False)
+    assert rel(dx1, dx0) < 1e-2
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert rel(g1[k], g0[k]) < 1e-2, k

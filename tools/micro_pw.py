@@ -1,13 +1,15 @@
 #!/usr/bin/env python
-"""Microbenchmark (GPU box): pointwise conv kernels over a size sweep."""
-import os, sys
+"""Microbenchmark (GPU box): backward of the benchmark's few-channel 1x1 layers, one sweep (csrc/pwbwd.hip) against the pair
+tss_pwconv_bwd_weight + tss_pwconv_bwd_data, on rotating buffers; prints times and the agreement of the two paths."""
+import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from torch_semantic_segmentation_amd import _native as N, ops
 
 dev = 'cuda:0'
-def timeit(fn, n=30):
-    for _ in range(5): fn()
+S = N.stat_slabs()
+def timeit(fn, n=10):
+    for _ in range(2): fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -15,25 +17,45 @@ def timeit(fn, n=30):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-S = N.stat_slabs()
-for (K, Nn) in ((128, 128), (64, 384), (384, 64), (32, 48), (128, 768), (768, 128)):
-    for P in (16384, 65536, 262144, 1048576):
-        if P * (K + Nn) > 6e8: continue
-        x = torch.randn(P, K, device=dev).bfloat16(); y = torch.empty(P, Nn, device=dev, dtype=torch.bfloat16)
-        e = torch.randn(P, Nn, device=dev).bfloat16(); ein = torch.empty(P, K, device=dev, dtype=torch.bfloat16)
-        w = torch.randn(Nn, K, device=dev) * 0.1
-        dw = torch.zeros(Nn, K, device=dev)
-        stats = torch.empty(S, 2 * Nn, dtype=torch.float64, device=dev); bst = torch.empty(S, 2 * K, dtype=torch.float64, device=dev)
-        mK = torch.zeros(K, device=dev); sK = torch.ones(K, device=dev)
-        mN = torch.zeros(Nn, device=dev); sN = torch.ones(Nn, device=dev)
-        st = N.stream()
-        fwd = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st)
-        fwd0 = lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, None, None, None, 0, N.ptr(w), None, None, N.ptr(y), Nn, None, P, K, Nn, 1, st)
-        bwd = lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), None,
-                             N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st)
-        wg = lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN),
-                            N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), None, 0, P, K, Nn, 1, st)
-        tf, tf0, tb, tw = timeit(fwd), timeit(fwd0), timeit(bwd), timeit(wg)
-        mbf = P * (K + Nn) * 2 / 1e6; mbb = P * (2 * Nn + 2 * K) * 2 / 1e6; mbw = P * (2 * Nn + K) * 2 / 1e6
-        print('pw K=%3d N=%3d P=%8d | fwd %7.1f us %5.0f GB/s (plain %7.1f us %5.0f) | bwd_data %7.1f us %5.0f GB/s | wgrad %7.1f us %5.0f GB/s'
-              % (K, Nn, P, tf, mbf / tf * 1e3, tf0, mbf / tf0 * 1e3, tb, mbb / tb * 1e3, tw, mbw / tw * 1e3))
+# (B, H, W, Cin, Cout): dsconv1 / dsconv2 pointwise, classifier dsconv pointwise, fusion, a bottleneck projection
+for (B, H, W, Cin, Cout) in ((8, 256, 512, 32, 48), (8, 128, 256, 48, 64), (8, 128, 256, 128, 128), (8, 128, 256, 64, 128), (8, 64, 128, 64, 64)):
+    P = B * H * W
+    nset = max(1, min(6, int(500e6 // (P * (Cin + 2 * Cout) * 2))))
+    mk = lambda c: ops.new_nhwc(B, c, H, W, torch.bfloat16, dev).normal_()
+    es, ys, xs, eins = [mk(Cout) for _ in range(nset)], [mk(Cout) for _ in range(nset)], [mk(Cin) for _ in range(nset)], [mk(Cin) for _ in range(nset)]
+    v = lambda c, s=0.1: torch.randn(c, device=dev) * s
+    ga, gb, gce, gmu = torch.rand(Cout, device=dev) + 0.5, v(Cout, 0.05), v(Cout, 0.01), v(Cout)
+    mean, sc, bias = v(Cin), torch.rand(Cin, device=dev) + 0.5, v(Cin)
+    w = torch.randn(Cout, Cin, device=dev) * 0.2
+    wT = w.t().contiguous().to(torch.bfloat16)
+    dw = torch.zeros(Cout, Cin, device=dev)
+    bst = torch.empty(S, 2 * Cin, dtype=torch.float64, device=dev)
+    rows = N.lib().tss_pwconv_bwd_fused_rows(P, Cin, Cout)
+    wsf = torch.empty(rows, Cout * Cin, device=dev)
+    nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, N.TSS_BF16)
+    wsp = torch.empty(max(nws, 1), device=dev)
+    st = N.stream()
+    def fused():
+        for e, y, x, ei in zip(es, ys, xs, eins):
+            N.call('tss_pwconv_bwd_fused', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), N.ptr(wT),
+                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, 1, N.ptr(ei), Cin, N.ptr(bst), N.ptr(wsf), P, Cin, Cout, N.TSS_BF16, st)
+            ops._reduce_rows_now(wsf, dw, Cout * Cin, rows)
+    def pair():
+        for e, y, x, ei in zip(es, ys, xs, eins):
+            N.call('tss_pwconv_bwd_weight', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
+                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(dw), N.ptr(wsp) if nws else None, 1 if nws else 0, P, Cin, Cout, N.TSS_BF16, st)
+            N.call('tss_pwconv_bwd_data', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), N.ptr(wT),
+                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(ei), Cin, N.ptr(bst),
+                   N.ptr(wsp) if nws else None, N.ptr(dw) if nws else None, P, Cin, Cout, N.TSS_BF16, st)
+    rl = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+    dw.zero_(); pair(); torch.cuda.synchronize()
+    ei0, dw0, st0 = eins[0].float().clone(), dw.clone(), bst.sum(0)
+    t0 = timeit(pair) / nset
+    dw.zero_(); fused(); torch.cuda.synchronize()
+    ei1, dw1, st1 = eins[0].float().clone(), dw.clone(), bst.sum(0)
+    t1 = timeit(fused) / nset
+    alg = P * (2 * Cout + 2 * Cin) * 2
+    print('pw bwd  %dx%dx%d  %d->%d  one sweep %7.1f us (%5.0f GB/s on e, y, x, e_in once)  pair %7.1f us   e_in rel %.2e  dW rel %.2e  stats rel %.2e' % (
+        B, H, W, Cin, Cout, t1, alg / t1 / 1e3, t0, rl(ei1, ei0), rl(dw1, dw0), rl(st1, st0)))
+    del es, ys, xs, eins
+    torch.cuda.empty_cache()

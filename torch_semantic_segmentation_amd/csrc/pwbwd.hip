@@ -1,0 +1,442 @@
+// Backward of a 1x1 (pointwise) layer in ONE sweep: input gradient AND weight gradient from a single pass over (e, y, x).
+//
+// pwfast_kernel<true> (input gradient) and wgfast_kernel (weight gradient) each read e and y of the layer -- the largest
+// operands of its backward -- and each evaluate g = BN'(e, y).  For the layers where that double read is most of the traffic
+// (few channels, many pixels: the depthwise-separable blocks at 1/4 and 1/8 resolution, 300-600 MB per layer) this kernel
+// reads e, y, x once and writes e_in once.  Per tile of TM pixels a thread loads one 4-pixel x 8-channel unit of e, y and
+// of x (16-byte loads, one tile ahead), evaluates g and a = relu?(BN(x)) in registers and stores them THREE ways:
+//   Xs  [pixel][channel of g]           -> e_in^T[ci][p]  = sum_kc  W^T[ci][kc] * g[p][kc]      (matrix cores, as pwfast)
+//   Gt  [channel of g][pixel], At [channel of a][pixel]  (transposing 8-byte stores, as wgfast)
+//                                       -> dW[kc][ci]    += sum_p   g^T[kc][p]  * a^T[ci][p]     (matrix cores, as wgfast)
+// The block keeps its whole [NC][KC] weight-gradient tile in accumulators over all its pixel tiles and writes it once, to
+// its own workspace row; the rows are summed by tss_dw_reduce_many (plain column sums: the row is already in the
+// [Cout][Cin] order of the parameter).  Envelope: bf16, Cout <= 128, Cin <= 128 (one weight tile per block).
+#include <cstdlib>
+
+#include "common.h"
+
+namespace {
+
+typedef bf16_t T;
+constexpr int NT = 256;
+
+struct PbArgs {
+  long P; int NC, KC;                       // NC = Cout (channels of e / y), KC = Cin (channels of x / e_in)
+  const T* e; long lde; const T* y; long ldy; const float* ga; const float* gb; const float* gce; const float* gmu;
+  const float* w;                           // [NC][KC] f32
+  const T* wT; long ldwT;                   // optional bf16 shadow of the transpose, [KC][NC]
+  const T* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_pending;
+  T* ein; long ldei; double* stats; float* ws; int gslots;
+};
+
+__device__ __forceinline__ float blo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// TM pixels per tile; FKM = 16-channel fragments of Cin a wave handles (all of them); NFW = 16-channel fragments of Cout
+// whose weight-gradient rows a wave owns (fragments w, w + 4, ...)
+template <int TM, int FKM, int NFW>
+__global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
+  constexpr int NCM = 64 * NFW, KCM = 16 * FKM;          // channel capacities
+  constexpr int RSX = NCM + 8;                           // Xs / Ws row pitch (elements): +16 bytes against bank conflicts
+  constexpr int ROWT = TM * 2 + 16;                      // Gt / At row pitch (bytes)
+  constexpr int NPG = TM / 4, MFX = TM / 64, NKP = TM / 32;
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Xs = reinterpret_cast<T*>(smem);                    // [TM][RSX]
+  T* Ws = Xs + TM * RSX;                                 // [KCM][RSX]   W^T: row = input channel, columns = output channels
+  unsigned char* Gt = reinterpret_cast<unsigned char*>(Ws + KCM * RSX);   // [NCM][ROWT]
+  unsigned char* At = Gt + NCM * ROWT;                   // [KCM][ROWT]
+  float* Ec = reinterpret_cast<float*>(At + KCM * ROWT); // [3][KCM]: producer's mean / scale / bias (ReLU mask, statistics)
+  float* Cg = Ec + 3 * KCM;                              // [3][NCM]: g = ca*e + cb*y + cc
+  float* Ca = Cg + 3 * NCM;                              // [2][KCM]: a = relu?(x*as + ab)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int NC = g.NC, KC = g.KC;
+  const int FN = (NC + 15) >> 4, FK = (KC + 15) >> 4;
+  const int nks = (NC + 31) >> 5;                        // k-steps of the input-gradient product
+
+  const int xcd = (int)blockIdx.x & 7, gslot = (int)blockIdx.x >> 3;
+  const long ntiles = (g.P + TM - 1) / TM;
+  const long per = (ntiles + 7) >> 3;
+  const long t_begin = xcd * per + gslot;
+  long t_end = xcd * per + per;
+  if (t_end > ntiles) t_end = ntiles;
+
+  // ---- staging units of this thread: 4 pixels x 8 channels of (e, y) and of x
+  const int nvG = NC >> 3, nvA = KC >> 3;
+  const int pgG = tid / nvG, cvG = tid - pgG * nvG;
+  const int pgA = tid / nvA, cvA = tid - pgA * nvA;
+  const bool onG = pgG < NPG, onA = pgA < NPG;
+  const T* eg = g.e + (onG ? cvG * 8 : 0);
+  const T* yg = (g.y ? g.y : g.e) + (onG ? cvG * 8 : 0);
+  const long ldyy = g.y ? g.ldy : g.lde;
+  const T* xg = g.x + (onA ? cvA * 8 : 0);
+  uint4 re[4], ry[4], rx[4];
+  uint2 rxn[FKM][MFX];       // raw producer output under this lane's e_in values (ReLU mask + statistics)
+  auto issue = [&](long tile) {
+    const long p0 = tile * TM;
+    if (onG) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + pgG * 4 + i;
+        const long pc = p < g.P ? p : p0;          // clamp to the tile's first pixel (always valid) and zero afterwards
+        re[i] = *reinterpret_cast<const uint4*>(eg + pc * g.lde);
+        ry[i] = *reinterpret_cast<const uint4*>(yg + pc * ldyy);
+      }
+    }
+    if (onA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + pgA * 4 + i;
+        const long pc = p < g.P ? p : p0;
+        rx[i] = *reinterpret_cast<const uint4*>(xg + pc * g.ldx);
+      }
+    }
+  };
+  // the raw producer output under this lane's e_in values travels separately: requested behind the epilogue that used the
+  // previous set, so that no second copy of it is alive during the matrix products
+  auto issue_x = [&](long tile) {
+    const long p0 = tile * TM;
+#pragma unroll
+    for (int i = 0; i < FKM; ++i) {
+      if (i < FK) {
+        const int n = i * 16 + fq * 4;
+        const T* px = g.x + (n < KC ? n : 0);
+#pragma unroll
+        for (int m = 0; m < MFX; ++m) {
+          const long p = p0 + wave * (TM / 4) + m * 16 + fr;
+          rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
+        }
+      }
+    }
+  };
+  if (t_begin < t_end) { issue(t_begin); if (g.x_pending) issue_x(t_begin); }
+
+  // ---- block set-up under the first tile's loads: zero the images once (padding rows / columns stay zero), W^T, constants
+  {
+    constexpr int total = (TM * RSX + KCM * RSX) * 2 + (NCM + KCM) * ROWT;
+    for (int i = tid; i < total / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (tid < KCM) {
+    const bool in = tid < KC, has = g.x_pending != 0;
+    Ec[tid] = (in && has && g.xm) ? g.xm[tid] : 0.f;
+    Ec[KCM + tid] = (in && has && g.xs) ? g.xs[tid] : 1.f;
+    Ec[2 * KCM + tid] = (in && has && g.xb) ? g.xb[tid] : 0.f;
+  }
+  __syncthreads();
+  if (g.wT) {
+    const int nvr = NC >> 3;                         // 16-byte vectors per row of the transpose
+    for (int i = tid; i < KC * nvr; i += NT) {
+      const int ci = i / nvr, v = i - ci * nvr;
+      *reinterpret_cast<uint4*>(Ws + ci * RSX + v * 8) = *reinterpret_cast<const uint4*>(g.wT + (long)ci * g.ldwT + v * 8);
+    }
+  } else {
+    for (int i = tid; i < NC * KC; i += NT) {        // coalesced reads of w[kc][ci], transposing 2-byte stores
+      const int kc = i / KC, ci = i - kc * KC;
+      Ws[ci * RSX + kc] = (T)g.w[i];
+    }
+  }
+  // per-channel constants of the two transforms -> LDS (read back as 16-byte vectors by the staging threads: 40 registers less)
+  {
+    const bool hy = g.y != nullptr, hs = g.xs != nullptr;
+    if (tid < NCM) {
+      const bool in = tid < NC;
+      const float a = (in && g.ga) ? g.ga[tid] : 1.f, b = (in && hy) ? g.gb[tid] : 0.f;
+      const float ce = (in && hy) ? g.gce[tid] : 0.f, mu = (in && hy) ? g.gmu[tid] : 0.f;
+      Cg[tid] = a; Cg[NCM + tid] = b; Cg[2 * NCM + tid] = hy ? -(a * ce) - b * mu : 0.f;
+    }
+    if (tid < KCM) {
+      const bool in = tid < KC;
+      const float sc = (in && hs) ? g.xs[tid] : 1.f;
+      const float bb = (in && hs && g.xb) ? g.xb[tid] : 0.f, mm = (in && hs && g.xm) ? g.xm[tid] : 0.f;
+      Ca[tid] = sc; Ca[KCM + tid] = __builtin_fmaf(-mm, sc, bb);
+    }
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+
+  f32x4 dw[NFW][FKM];        // this wave's rows of the weight gradient: output-channel fragments wave, wave + 4, ...
+#pragma unroll
+  for (int u = 0; u < NFW; ++u)
+#pragma unroll
+    for (int j = 0; j < FKM; ++j) dw[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float st1[FKM][4], st2[FKM][4];
+#pragma unroll
+  for (int i = 0; i < FKM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
+
+  auto unit_ptr = [&](unsigned char* tile, int row, int pg) -> unsigned char* {
+    const int boff = pg * 8;
+    return tile + row * ROWT + ((((boff >> 4)) ^ ((row >> 3) & 7)) << 4) + (boff & 15);
+  };
+
+  for (long tile = t_begin; tile < t_end; tile += g.gslots) {
+    const long p0 = tile * TM;
+    __syncthreads();          // the previous tile's matrix products have read the images (first pass: set-up complete)
+    if (onG) {
+      float v[4][8], ca[8], cb[8], cc[8];
+      V8<float>::load(Cg + cvG * 8, ca); V8<float>::load(Cg + NCM + cvG * 8, cb); V8<float>::load(Cg + 2 * NCM + cvG * 8, cc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = p0 + pgG * 4 + i < g.P;
+        const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[i]);
+        const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[i]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          v[i][2 * h] = ca[2 * h] * blo(ue[h]) + (cb[2 * h] * blo(uy[h]) + cc[2 * h]);
+          v[i][2 * h + 1] = ca[2 * h + 1] * bhi(ue[h]) + (cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]);
+        }
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+        V8<T>::store(Xs + (pgG * 4 + i) * RSX + cvG * 8, v[i]);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x4 o; o[0] = (T)v[0][j]; o[1] = (T)v[1][j]; o[2] = (T)v[2][j]; o[3] = (T)v[3][j];
+        *reinterpret_cast<bf16x4*>(unit_ptr(Gt, cvG * 8 + j, pgG)) = o;
+      }
+    }
+    if (onA) {
+      float v[4][8], as[8], ab[8];
+      V8<float>::load(Ca + cvA * 8, as); V8<float>::load(Ca + KCM + cvA * 8, ab);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = p0 + pgA * 4 + i < g.P;
+        const uint32_t* ux = reinterpret_cast<const uint32_t*>(&rx[i]);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          v[i][2 * h] = fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
+          v[i][2 * h + 1] = fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
+        }
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        bf16x4 o; o[0] = (T)v[0][j]; o[1] = (T)v[1][j]; o[2] = (T)v[2][j]; o[3] = (T)v[3][j];
+        *reinterpret_cast<bf16x4*>(unit_ptr(At, cvA * 8 + j, pgA)) = o;
+      }
+    }
+    if (tile + g.gslots < t_end) issue(tile + g.gslots);
+    __syncthreads();
+
+    // ---- input gradient: D[ci][p] = sum_kc W^T[ci][kc] * g[p][kc]; this wave's pixels: wave * TM/4 ...
+    f32x4 acc[MFX][FKM];
+#pragma unroll
+    for (int m = 0; m < MFX; ++m)
+#pragma unroll
+      for (int i = 0; i < FKM; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const T* xrow = Xs + (wave * (TM / 4) + fr) * RSX + fq * 8;
+      const T* wrow = Ws + fr * RSX + fq * 8;
+      for (int ks = 0; ks < nks; ++ks) {
+        bf16x8 xf[MFX];
+#pragma unroll
+        for (int m = 0; m < MFX; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RSX + ks * 32);
+#pragma unroll
+        for (int i = 0; i < FKM; ++i) {
+          if (i < FK) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RSX + ks * 32);
+#pragma unroll
+            for (int m = 0; m < MFX; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- weight gradient: D[kc][ci] += sum_p g^T[kc][p] * a^T[ci][p]
+#pragma unroll
+    for (int u = 0; u < NFW; ++u) {
+      const int f = wave + 4 * u;
+      if (f < FN) {
+        const int rg = f * 16 + fr;
+        const unsigned char* grow = Gt + rg * ROWT;
+        for (int ks = 0; ks < NKP; ++ks) {
+          const bf16x8 gf = *reinterpret_cast<const bf16x8*>(grow + (((ks * 4 + fq) ^ ((rg >> 3) & 7)) << 4));
+#pragma unroll
+          for (int j = 0; j < FKM; ++j) {
+            if (j < FK) {
+              const int rk = j * 16 + fr;
+              const bf16x8 af = *reinterpret_cast<const bf16x8*>(At + rk * ROWT + (((ks * 4 + fq) ^ ((rk >> 3) & 7)) << 4));
+              dw[u][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, af, dw[u][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    // ---- epilogue of the input gradient: ReLU mask of the producer, statistics, store (lane: pixel fr, 4 channels)
+#pragma unroll
+    for (int i = 0; i < FKM; ++i) {
+      if (i < FK) {
+        const int n = i * 16 + fq * 4;
+        if (n < KC) {
+          const float4 e0 = *reinterpret_cast<const float4*>(Ec + n);
+          const float4 e1 = *reinterpret_cast<const float4*>(Ec + KCM + n);
+          const float4 e2 = *reinterpret_cast<const float4*>(Ec + 2 * KCM + n);
+          const float cmm[4] = {e0.x, e0.y, e0.z, e0.w}, cms[4] = {e1.x, e1.y, e1.z, e1.w}, cmb[4] = {e2.x, e2.y, e2.z, e2.w};
+#pragma unroll
+          for (int m = 0; m < MFX; ++m) {
+            const long p = p0 + wave * (TM / 4) + m * 16 + fr;
+            if (p < g.P) {
+              float v[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q];
+              bf16x4 o;
+              if (g.x_pending) {
+                const uint2 xr = rxn[i][m];
+                const float xc[4] = {blo(xr.x) - cmm[0], bhi(xr.x) - cmm[1], blo(xr.y) - cmm[2], bhi(xr.y) - cmm[3]};
+                if (g.x_relu) {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) if (!(xc[q] * cms[q] + cmb[q] > 0.f)) v[q] = 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+              }
+              *reinterpret_cast<bf16x4*>(g.ein + p * g.ldei + n) = o;
+            }
+          }
+        }
+      }
+    }
+    if (g.x_pending && tile + g.gslots < t_end) issue_x(tile + g.gslots);
+  }
+
+  // ---- the block's weight-gradient tile -> its workspace row, [NC][KC] like the parameter (blocks without tiles write zeros)
+  const int row = xcd + 8 * gslot;
+  {
+    float* wr = g.ws + (long)row * NC * KC;
+#pragma unroll
+    for (int u = 0; u < NFW; ++u) {
+      const int f = wave + 4 * u;
+      if (f < FN) {
+#pragma unroll
+        for (int j = 0; j < FKM; ++j) {
+          if (j < FK) {
+            const int ci = j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int kc = f * 16 + fq * 4 + r;
+              if (kc < NC && ci < KC) wr[(long)kc * KC + ci] = dw[u][j][r];
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- statistics slab row of this block: sum over the 16 pixel lanes of a fragment row, then over the four waves
+  if (g.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][KCM]
+#pragma unroll
+    for (int i = 0; i < FKM; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float u1 = row16_sum(st1[i][q]), u2 = row16_sum(st2[i][q]);
+        if (fr == 0) {
+          red[(wave * 2 + 0) * KCM + i * 16 + fq * 4 + q] = u1;
+          red[(wave * 2 + 1) * KCM + i * 16 + fq * 4 + q] = u2;
+        }
+      }
+    __syncthreads();
+    if (tid < KC) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 2 + 0) * KCM + tid]; b += (double)red[(w * 2 + 1) * KCM + tid]; }
+      const int rows_used = 8 * g.gslots;
+      g.stats[(long)row * 2 * KC + tid] = a;
+      g.stats[(long)row * 2 * KC + KC + tid] = b;
+      for (int rr = row + rows_used; rr < TSS_STAT_SLABS; rr += rows_used) {
+        g.stats[(long)rr * 2 * KC + tid] = 0.0;
+        g.stats[(long)rr * 2 * KC + KC + tid] = 0.0;
+      }
+    }
+  }
+}
+
+template <int TM, int FKM, int NFW>
+constexpr size_t smem_bytes() {
+  return (size_t)(TM + 16 * FKM) * (64 * NFW + 8) * 2 + (size_t)(64 * NFW + 16 * FKM) * (TM * 2 + 16) + (5 * 16 * FKM + 3 * 64 * NFW) * sizeof(float);
+}
+
+template <int TM, int FKM, int NFW>
+int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
+  const long ntiles = (g.P + TM - 1) / TM;
+  long gs = (ntiles + 7) / 8;
+  const long cap = 32 * blocks_per_cu;            // 8 * gs blocks: at most 256 CUs x blocks per CU, and <= 512 slab rows
+  if (gs > cap) gs = cap;
+  if (gs < 1) gs = 1;
+  g.gslots = (int)gs;
+  constexpr size_t smem = smem_bytes<TM, FKM, NFW>();
+  static tss::DevOnce attr;
+  if (attr.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<TM, FKM, NFW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((pwbwd_kernel<TM, FKM, NFW>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
+  return 8 * (int)gs;
+}
+
+inline bool small_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
+
+}  // namespace
+
+extern "C" {
+
+// 1 when tss_pwconv_bwd_fused covers the layer AND is the faster choice (few channels, many pixels: the double read of e, y
+// by the two separate kernels dominates); the number of workspace rows it writes comes from tss_pwconv_bwd_fused_rows
+int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
+  // TSS_PW_BWD_FUSED: 0 = never; n > 1 = every layer inside the envelope with at least n pixels (tests, A/B runs).
+  // Default: the two-blocks-per-CU instance (both channel counts <= 64) from 50 k pixels -- measured 99 vs 157 us (32 -> 48
+  // channels at 1 M pixels), 43 vs 62 (48 -> 64, 262 k), 23.5 vs 27.9 (64 -> 64, 65 k); the 128-channel instance runs at one
+  // wave per SIMD and loses (157 vs 123 us for 128 -> 128 at 262 k pixels), so those layers keep the two kernels.
+  const char* sw = getenv("TSS_PW_BWD_FUSED");
+  if (sw && atoi(sw) == 0) return 0;
+  const bool inside = dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128;
+  if (sw && atol(sw) > 1) return inside && P >= atol(sw);
+  return inside && small_shape(Cin, Cout) && P >= 50000;
+}
+
+int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
+  const bool small = small_shape(Cin, Cout);
+  const long TM = small ? 128 : 64;
+  long gs = ((P + TM - 1) / TM + 7) / 8;
+  const long cap = small ? 64 : 32;
+  if (gs > cap) gs = cap;
+  if (gs < 1) gs = 1;
+  return (int)(8 * gs);
+}
+
+// e_in = relu'(BN(x)) * (g W) with g = ga*(e-gce) + gb*(y-gmu), and ws[row][Cout][Cin] = per-block partial sums of
+// dW = g^T a, a = relu?(BN(x)) (rows: tss_pwconv_bwd_fused_rows; the caller adds them to dW with tss_dw_reduce_many).
+// x_pending = 1: x is the producer's raw output (in_* pending): e_in is masked and bstats written, as tss_pwconv_bwd_data does.
+int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                         const float* gmu, const float* w, const void* wT_bf16, const void* x, long ldx, const float* in_mean,
+                         const float* in_scale, const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei,
+                         double* bstats, float* ws, long P, int Cin, int Cout, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128, TSS_ERR_SHAPE);
+  TSS_REQUIRE(P > 0 && e && x && e_in && ws && w, TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= Cout && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= Cout && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || x_pending, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(x) && (!yraw || tss::aligned16(yraw)) && ((uintptr_t)e_in & 7u) == 0, TSS_ERR_ALIGN);
+  PbArgs g = {};
+  g.P = P; g.NC = Cout; g.KC = Cin;
+  g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldy = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.w = w;
+  if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wT = (const T*)wT_bf16; g.ldwT = Cout; }
+  g.x = (const T*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_pending = x_pending;
+  g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
+  tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
+                      ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0, 4.0 * (double)P * Cin * Cout);
+  if (small_shape(Cin, Cout)) launch<128, 4, 1>(g, (hipStream_t)stream, 2);
+  else launch<64, 8, 2>(g, (hipStream_t)stream, 1);
+  return tss::check_last("pwconv_bwd_fused");
+}
+
+}  // extern "C"

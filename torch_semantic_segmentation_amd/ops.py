@@ -57,6 +57,7 @@ overlap_min_elems = int(os.environ.get('TSS_OVERLAP_MIN', '0'))
 # the row reductions of the one-sweep depthwise backward, collected over a backward pass and summed in one launch at its end
 # (only for gradients written straight into their final buffer: a gradient RETURNED to autograd must be complete on return)
 batch_dw_reductions = os.environ.get('TSS_BATCH_DW_REDUCE', '1') == '1'
+fuse_pw_backward = os.environ.get('TSS_PW_BWD_FUSED', '1') != '0'     # csrc/pwbwd.hip, for the layers it prefers
 _pending_dw = []
 
 
@@ -72,6 +73,11 @@ def _flush_dw_reductions():
     rows = (ctypes.c_int * n)(*[j[3] for j in jobs])
     with torch.cuda.device(jobs[0][0].device):
         call('tss_dw_reduce_many', n, ws, dw, cols, rows, stream())
+
+
+def _reduce_rows_now(ws, dw, ncols, nrows):
+    a, b = (ctypes.c_void_p * 1)(ws.data_ptr()), (ctypes.c_void_p * 1)(dw.data_ptr())
+    call('tss_dw_reduce_many', 1, a, b, (ctypes.c_int * 1)(ncols), (ctypes.c_int * 1)(nrows), stream())
 
 
 def _defer_dw_reduction(ws, dw, ncols, nrows):
@@ -651,7 +657,14 @@ class ConvUnitFn(Function):
         else:
             xargs = (ptr(x), ld(x), *_aff(il), int(cfg.in_relu))
             deferred_in = il is not None or cfg.in_relu
+            fused_pw = False
             if cfg.kind == 'pw':
+                # few channels, many pixels: input gradient and weight gradient in ONE sweep (csrc/pwbwd.hip): e, y, x read once
+                fused_pw = bool(fuse_pw_backward and need_dx and side is None and e.dtype == torch.bfloat16
+                                and not N.fast_paths_disabled() and N.lib().tss_pwconv_bwd_fused_preferred(P, Cin, Cout, dt))
+            if fused_pw:
+                pass
+            elif cfg.kind == 'pw':
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
                 defer = 1 if (ws is not None and need_dx and side is None) else 0   # backward-data carries the reduce
@@ -683,7 +696,16 @@ class ConvUnitFn(Function):
                 e_in = new_nhwc(B, Cin, Hin, Win, e.dtype, dev)
                 margs = xargs if deferred_in else (None, 0, None, None, None, 0)
                 bst = ptr(il.bstats) if il is not None else None
-                if cfg.kind == 'pw':
+                if fused_pw:
+                    rows = N.lib().tss_pwconv_bwd_fused_rows(P, Cin, Cout)
+                    ws = torch.empty((rows, Cout * Cin), dtype=torch.float32, device=dev)
+                    call('tss_pwconv_bwd_fused', *gargs, ptr(weight), _shadow(weight, 1), *xargs, int(bool(deferred_in)),
+                         ptr(e_in), ld(e_in), bst, ptr(ws), P, Cin, Cout, dt, st)
+                    if dw_ret is None and batch_dw_reductions:
+                        _defer_dw_reduction(ws, dw, Cout * Cin, rows)       # summed with the depthwise rows, at the end of the pass
+                    else:
+                        _reduce_rows_now(ws, dw, Cout * Cin, rows)
+                elif cfg.kind == 'pw':
                     call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
                 elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
