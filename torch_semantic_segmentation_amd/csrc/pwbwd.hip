@@ -18,7 +18,6 @@
 namespace {
 
 typedef bf16_t T;
-constexpr int NT = 256;
 
 struct PbArgs {
   long P; int NC, KC;                       // NC = Cout (channels of e / y), KC = Cin (channels of x / e_in)
@@ -32,14 +31,18 @@ struct PbArgs {
 __device__ __forceinline__ float blo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-// TM pixels per tile; FKM = 16-channel fragments of Cin a wave handles (all of them); NFW = 16-channel fragments of Cout
-// whose weight-gradient rows a wave owns (fragments w, w + 4, ...)
-template <int TM, int FKM, int NFW>
-__global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
-  constexpr int NCM = 64 * NFW, KCM = 16 * FKM;          // channel capacities
+// NT threads (NW waves); TM pixels per tile, TM / NW per wave; FKM = 16-channel fragments of Cin a wave handles (all of them);
+// NFW = 16-channel fragments of Cout whose weight-gradient rows a wave owns (fragments w, w + NW, ...).  Two instances:
+// NSPLIT = 2: the waves pair up over the input-channel fragments of the input gradient (half of FKM each, twice the pixels).
+//   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU
+template <int NT, int TM, int FKM, int NFW, int NSPLIT>
+__global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
+  constexpr int NW = NT / 64;
+  constexpr int NCM = 16 * NW * NFW, KCM = 16 * FKM;     // channel capacities
   constexpr int RSX = NCM + 8;                           // Xs / Ws row pitch (elements): +16 bytes against bank conflicts
   constexpr int ROWT = TM * 2 + 16;                      // Gt / At row pitch (bytes)
-  constexpr int NPG = TM / 4, MFX = TM / 64, NKP = TM / 32;
+  constexpr int NPG = TM / 4, PXW = TM / (NW / NSPLIT), MFX = PXW / 16, NKP = TM / 32, FKW = FKM / NSPLIT;
+  static_assert(PXW % 16 == 0 && NPG * 16 <= NT * 2, "tile shape");
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);                    // [TM][RSX]
   T* Ws = Xs + TM * RSX;                                 // [KCM][RSX]   W^T: row = input channel, columns = output channels
@@ -51,6 +54,7 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
+  const int wp = wave / NSPLIT, i0 = (wave % NSPLIT) * FKW;     // pixel group and first input-channel fragment of this wave (dX)
   const int NC = g.NC, KC = g.KC;
   const int FN = (NC + 15) >> 4, FK = (KC + 15) >> 4;
   const int nks = (NC + 31) >> 5;                        // k-steps of the input-gradient product
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
   const long ldyy = g.y ? g.ldy : g.lde;
   const T* xg = g.x + (onA ? cvA * 8 : 0);
   uint4 re[4], ry[4], rx[4];
-  uint2 rxn[FKM][MFX];       // raw producer output under this lane's e_in values (ReLU mask + statistics)
+  uint2 rxn[FKW][MFX];       // raw producer output under this lane's e_in values (ReLU mask + statistics)
   auto issue = [&](long tile) {
     const long p0 = tile * TM;
     if (onG) {
@@ -98,13 +102,13 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
   auto issue_x = [&](long tile) {
     const long p0 = tile * TM;
 #pragma unroll
-    for (int i = 0; i < FKM; ++i) {
-      if (i < FK) {
-        const int n = i * 16 + fq * 4;
+    for (int i = 0; i < FKW; ++i) {
+      if (i0 + i < FK) {
+        const int n = (i0 + i) * 16 + fq * 4;
         const T* px = g.x + (n < KC ? n : 0);
 #pragma unroll
         for (int m = 0; m < MFX; ++m) {
-          const long p = p0 + wave * (TM / 4) + m * 16 + fr;
+          const long p = p0 + wp * PXW + m * 16 + fr;
           rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
         }
       }
@@ -159,9 +163,9 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
   for (int u = 0; u < NFW; ++u)
 #pragma unroll
     for (int j = 0; j < FKM; ++j) dw[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float st1[FKM][4], st2[FKM][4];
+  float st1[FKW][4], st2[FKW][4];
 #pragma unroll
-  for (int i = 0; i < FKM; ++i)
+  for (int i = 0; i < FKW; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) { st1[i][q] = 0.f; st2[i][q] = 0.f; }
 
@@ -225,22 +229,22 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
     __syncthreads();
 
     // ---- input gradient: D[ci][p] = sum_kc W^T[ci][kc] * g[p][kc]; this wave's pixels: wave * TM/4 ...
-    f32x4 acc[MFX][FKM];
+    f32x4 acc[MFX][FKW];
 #pragma unroll
     for (int m = 0; m < MFX; ++m)
 #pragma unroll
-      for (int i = 0; i < FKM; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < FKW; ++i) acc[m][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-      const T* xrow = Xs + (wave * (TM / 4) + fr) * RSX + fq * 8;
+      const T* xrow = Xs + (wp * PXW + fr) * RSX + fq * 8;
       const T* wrow = Ws + fr * RSX + fq * 8;
       for (int ks = 0; ks < nks; ++ks) {
         bf16x8 xf[MFX];
 #pragma unroll
         for (int m = 0; m < MFX; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RSX + ks * 32);
 #pragma unroll
-        for (int i = 0; i < FKM; ++i) {
-          if (i < FK) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + i * 16 * RSX + ks * 32);
+        for (int i = 0; i < FKW; ++i) {
+          if (i0 + i < FK) {
+            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wrow + (i0 + i) * 16 * RSX + ks * 32);
 #pragma unroll
             for (int m = 0; m < MFX; ++m) acc[m][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[m], acc[m][i], 0, 0, 0);
           }
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
     // ---- weight gradient: D[kc][ci] += sum_p g^T[kc][p] * a^T[ci][p]
 #pragma unroll
     for (int u = 0; u < NFW; ++u) {
-      const int f = wave + 4 * u;
+      const int f = wave + NW * u;
       if (f < FN) {
         const int rg = f * 16 + fr;
         const unsigned char* grow = Gt + rg * ROWT;
@@ -269,9 +273,9 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
     }
     // ---- epilogue of the input gradient: ReLU mask of the producer, statistics, store (lane: pixel fr, 4 channels)
 #pragma unroll
-    for (int i = 0; i < FKM; ++i) {
-      if (i < FK) {
-        const int n = i * 16 + fq * 4;
+    for (int i = 0; i < FKW; ++i) {
+      if (i0 + i < FK) {
+        const int n = (i0 + i) * 16 + fq * 4;
         if (n < KC) {
           const float4 e0 = *reinterpret_cast<const float4*>(Ec + n);
           const float4 e1 = *reinterpret_cast<const float4*>(Ec + KCM + n);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
           const float cmm[4] = {e0.x, e0.y, e0.z, e0.w}, cms[4] = {e1.x, e1.y, e1.z, e1.w}, cmb[4] = {e2.x, e2.y, e2.z, e2.w};
 #pragma unroll
           for (int m = 0; m < MFX; ++m) {
-            const long p = p0 + wave * (TM / 4) + m * 16 + fr;
+            const long p = p0 + wp * PXW + m * 16 + fr;
             if (p < g.P) {
               float v[4];
 #pragma unroll
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
     float* wr = g.ws + (long)row * NC * KC;
 #pragma unroll
     for (int u = 0; u < NFW; ++u) {
-      const int f = wave + 4 * u;
+      const int f = wave + NW * u;
       if (f < FN) {
 #pragma unroll
         for (int j = 0; j < FKM; ++j) {
@@ -334,22 +338,24 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
   // ---- statistics slab row of this block: sum over the 16 pixel lanes of a fragment row, then over the four waves
   if (g.stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);      // [4 waves][2][KCM]
+    float* red = reinterpret_cast<float*>(smem);      // [NW waves][2][KCM]
+    for (int i = tid; i < NW * 2 * KCM; i += NT) red[i] = 0.f;     // (a wave only covers its own channel fragments)
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < FKM; ++i)
+    for (int i = 0; i < FKW; ++i)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float u1 = row16_sum(st1[i][q]), u2 = row16_sum(st2[i][q]);
         if (fr == 0) {
-          red[(wave * 2 + 0) * KCM + i * 16 + fq * 4 + q] = u1;
-          red[(wave * 2 + 1) * KCM + i * 16 + fq * 4 + q] = u2;
+          red[(wave * 2 + 0) * KCM + (i0 + i) * 16 + fq * 4 + q] = u1;
+          red[(wave * 2 + 1) * KCM + (i0 + i) * 16 + fq * 4 + q] = u2;
         }
       }
     __syncthreads();
     if (tid < KC) {
       double a = 0.0, b = 0.0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += (double)red[(w * 2 + 0) * KCM + tid]; b += (double)red[(w * 2 + 1) * KCM + tid]; }
+      for (int w = 0; w < NW; ++w) { a += (double)red[(w * 2 + 0) * KCM + tid]; b += (double)red[(w * 2 + 1) * KCM + tid]; }
       const int rows_used = 8 * g.gslots;
       g.stats[(long)row * 2 * KC + tid] = a;
       g.stats[(long)row * 2 * KC + KC + tid] = b;
@@ -361,12 +367,13 @@ __global__ __launch_bounds__(NT, (FKM <= 4 ? 2 : 1)) void pwbwd_kernel(const PbA
   }
 }
 
-template <int TM, int FKM, int NFW>
+template <int NT, int TM, int FKM, int NFW>
 constexpr size_t smem_bytes() {
-  return (size_t)(TM + 16 * FKM) * (64 * NFW + 8) * 2 + (size_t)(64 * NFW + 16 * FKM) * (TM * 2 + 16) + (5 * 16 * FKM + 3 * 64 * NFW) * sizeof(float);
+  constexpr int NCM = 16 * (NT / 64) * NFW, KCM = 16 * FKM;
+  return (size_t)(TM + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float);
 }
 
-template <int TM, int FKM, int NFW>
+template <int NT, int TM, int FKM, int NFW, int NSPLIT>
 int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
@@ -374,11 +381,11 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   g.gslots = (int)gs;
-  constexpr size_t smem = smem_bytes<TM, FKM, NFW>();
+  constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW>();
   static tss::DevOnce attr;
   if (attr.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<TM, FKM, NFW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((pwbwd_kernel<TM, FKM, NFW>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
   return 8 * (int)gs;
 }
 
@@ -393,8 +400,8 @@ extern "C" {
 int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
   // TSS_PW_BWD_FUSED: 0 = never; n > 1 = every layer inside the envelope with at least n pixels (tests, A/B runs).
   // Default: the two-blocks-per-CU instance (both channel counts <= 64) from 50 k pixels -- measured 99 vs 157 us (32 -> 48
-  // channels at 1 M pixels), 43 vs 62 (48 -> 64, 262 k), 23.5 vs 27.9 (64 -> 64, 65 k); the 128-channel instance runs at one
-  // wave per SIMD and loses (157 vs 123 us for 128 -> 128 at 262 k pixels), so those layers keep the two kernels.
+  // channels at 1 M pixels), 43 vs 62 (48 -> 64, 262 k), 23.5 vs 27.9 (64 -> 64, 65 k); the 128-channel instance (one 8-wave block per
+  // CU, 40 spilled registers) loses (139 vs 119 us for 128 -> 128 at 262 k pixels), so those layers keep the two kernels.
   const char* sw = getenv("TSS_PW_BWD_FUSED");
   if (sw && atoi(sw) == 0) return 0;
   const bool inside = dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128;
@@ -404,7 +411,7 @@ int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
 
 int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
   const bool small = small_shape(Cin, Cout);
-  const long TM = small ? 128 : 64;
+  const long TM = 128;
   long gs = ((P + TM - 1) / TM + 7) / 8;
   const long cap = small ? 64 : 32;
   if (gs > cap) gs = cap;
@@ -434,8 +441,8 @@ int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, c
   g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0, 4.0 * (double)P * Cin * Cout);
-  if (small_shape(Cin, Cout)) launch<128, 4, 1>(g, (hipStream_t)stream, 2);
-  else launch<64, 8, 2>(g, (hipStream_t)stream, 1);
+  if (small_shape(Cin, Cout)) launch<256, 128, 4, 1, 1>(g, (hipStream_t)stream, 2);
+  else launch<512, 128, 8, 1, 2>(g, (hipStream_t)stream, 1);
   return tss::check_last("pwconv_bwd_fused");
 }
 
