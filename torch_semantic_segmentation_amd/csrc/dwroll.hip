@@ -464,14 +464,18 @@ __device__ __forceinline__ void advance(BCursor& c, const RollBwdArgs& g, int n_
   }
 }
 
+// RPJ = input rows per step: 2 halves the barriers, the cursor arithmetic and the waits per byte (the steps are instruction-
+// issue bound, not latency bound: DESIGN.md section 4)
+template <int RPJ>
 __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs g) {
+  constexpr int PFB = RPJ == 1 ? BPF : 2;        // steps in flight
   TSS_RT(rt_begin);
 #ifdef TSS_ROLL_TIMING
   unsigned long long rt_ph[4] = {0, 0, 0, 0}, rt_ph4 = 0;
 #endif
-  __shared__ __align__(16) float4 rows_s[4][BENT];   // [slot] g rows, [2 + slot] activated input rows; entry = window column * CVS + lane
-  float4 (*Gs)[BENT] = rows_s;
-  float4 (*As)[BENT] = rows_s + 2;
+  __shared__ __align__(16) float4 rows_s[4 * RPJ][BENT];   // [slot][row] g rows, then [slot][row] activated input rows; entry = window column * CVS + lane
+  auto Gs = [&](int slot_, int jr) -> float4* { return rows_s[slot_ * RPJ + jr]; };
+  auto As = [&](int slot_, int jr) -> float4* { return rows_s[2 * RPJ + slot_ * RPJ + jr]; };
   static_assert(sizeof(float4) * 4 * BENT >= sizeof(float) * (NT * 16 + NT), "flush_slab scratch");
   const int tid = threadIdx.x;
   const int p = tid / g.CVS, cg = tid - p * g.CVS;
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
   const int lde = (int)g.lde, ldy = (int)g.ldyr, ldx = (int)g.ldx;
   const bf16_t* ysrc = g.yr ? g.yr : g.e;           // no BatchNorm behind this layer: the y requests re-read e (cb = 0)
 
-  const int n_iter = g.RS + 2;
+  const int n_iter = (g.RS + 2 + RPJ - 1) / RPJ;
   BCursor ci, cc;
   ci.it = 0;
   ci.seg = brow % g.nseg;
@@ -494,25 +498,28 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
   ci.o0 = ci.seg * g.RS;
   cc = ci;
 
-  u32x2 raw[BPF][6];      // e, y, x under the lane's pixel; e, y, x of its halo column (edge lanes; the others re-request)
-  auto issue = [&](const BCursor& c, u32x2 (&r)[6]) {
+  u32x2 raw[PFB][6 * RPJ];      // per row: e, y, x under the lane's pixel; e, y, x of its halo column (edge lanes; the others re-request)
+  auto issue = [&](const BCursor& c, u32x2 (&r)[6 * RPJ]) {
     const int b = c.b < g.B ? c.b : g.B - 1;
-    const int iy = clampi(c.o0 - 1 + c.it, 0, g.H - 1);
+#pragma unroll
+   for (int jr = 0; jr < RPJ; ++jr) {
+    const int iy = clampi(c.o0 - 1 + c.it * RPJ + jr, 0, g.H - 1);
     const long rowpix = ((long)b * g.H + iy) * g.W;
     const int xm_ = clampi(c.x0 + p, 0, g.W - 1), xh_ = clampi(c.x0 + halo_dx, 0, g.W - 1);
     const bf16_t* re = g.e + rowpix * g.lde;
     const bf16_t* ry = ysrc + rowpix * (g.yr ? g.ldyr : g.lde);
     const bf16_t* rx = g.x + rowpix * g.ldx;
     const int ldyy = g.yr ? ldy : lde;
-    request2(r[0], re, xm_ * lde + c0);
-    request2(r[1], ry, xm_ * ldyy + c0);
-    request2(r[2], rx, xm_ * ldx + c0);
-    request2(r[3], re, xh_ * lde + c0);
-    request2(r[4], ry, xh_ * ldyy + c0);
-    request2(r[5], rx, xh_ * ldx + c0);
+    request2(r[6 * jr + 0], re, xm_ * lde + c0);
+    request2(r[6 * jr + 1], ry, xm_ * ldyy + c0);
+    request2(r[6 * jr + 2], rx, xm_ * ldx + c0);
+    request2(r[6 * jr + 3], re, xh_ * lde + c0);
+    request2(r[6 * jr + 4], ry, xh_ * ldyy + c0);
+    request2(r[6 * jr + 5], rx, xh_ * ldx + c0);
+   }
   };
 #pragma unroll
-  for (int k = 0; k < BPF; ++k) {
+  for (int k = 0; k < PFB; ++k) {
     issue(ci, raw[k]);
     advance(ci, g, n_iter);
   }
@@ -584,24 +591,30 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
   int slot = 0;
   while (cc.b < g.B) {
 #pragma unroll
-    for (int k = 0; k < BPF; ++k) {
+    for (int k = 0; k < PFB; ++k) {
       if (cc.b >= g.B) break;
       TSS_RT(rt0);
-      arrived2<6 * (BPF - 1)>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
+#pragma unroll
+      for (int jr = 0; jr < RPJ; ++jr)
+        arrived2<6 * RPJ * (PFB - 1)>(raw[k][6 * jr], raw[k][6 * jr + 1], raw[k][6 * jr + 2], raw[k][6 * jr + 3], raw[k][6 * jr + 4], raw[k][6 * jr + 5]);
       TSS_RT(rt1);
-      const int r = cc.o0 - 1 + cc.it;
-      const bool vy = r >= 0 && r < g.H;
-      float4 gown, aown;
-      ga_of(raw[k][0], raw[k][1], raw[k][2], vy && cc.x0 + p < g.W, gown, aown);
-      if (p < g.PXL) { Gs[slot][tid + g.CVS] = gown; As[slot][tid + g.CVS] = aown; }
-      if (halo_l || halo_r) {
-        float4 gh, ah;
-        ga_of(raw[k][3], raw[k][4], raw[k][5], vy && (halo_l ? cc.x0 - 1 >= 0 : cc.x0 + g.PXL < g.W), gh, ah);
-        const int eh = halo_l ? tid : tid + 2 * g.CVS;
-        Gs[slot][eh] = gh; As[slot][eh] = ah;
+      float4 gown[RPJ], aown[RPJ];
+      u32x2 xcur[RPJ];
+#pragma unroll
+      for (int jr = 0; jr < RPJ; ++jr) {
+        const int r = cc.o0 - 1 + cc.it * RPJ + jr;
+        const bool vy = r >= 0 && r < g.H;
+        ga_of(raw[k][6 * jr], raw[k][6 * jr + 1], raw[k][6 * jr + 2], vy && cc.x0 + p < g.W, gown[jr], aown[jr]);
+        if (p < g.PXL) { Gs(slot, jr)[tid + g.CVS] = gown[jr]; As(slot, jr)[tid + g.CVS] = aown[jr]; }
+        if (halo_l || halo_r) {
+          float4 gh, ah;
+          ga_of(raw[k][6 * jr + 3], raw[k][6 * jr + 4], raw[k][6 * jr + 5], vy && (halo_l ? cc.x0 - 1 >= 0 : cc.x0 + g.PXL < g.W), gh, ah);
+          const int eh = halo_l ? tid : tid + 2 * g.CVS;
+          Gs(slot, jr)[eh] = gh; As(slot, jr)[eh] = ah;
+        }
+        xcur[jr] = keep2(raw[k][6 * jr + 2]);
+        settle(gown[jr]); settle(aown[jr]);
       }
-      const u32x2 xcur = keep2(raw[k][2]);
-      settle(gown); settle(aown);
       asm volatile("" ::: "memory");      // the LDS stores above are issued (they hold the halo values) before the slot is re-requested
       TSS_RT(rt1a);
       issue(ci, raw[k]);
@@ -610,14 +623,17 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
       __syncthreads();
       TSS_RT(rt3);
       if (lane_on) {
+#pragma unroll
+       for (int jr = 0; jr < RPJ; ++jr) {
+        const int idx = cc.it * RPJ + jr;          // row o0 - 1 + idx of the unit
         float G[3][4], A[3][4];     // window columns p-1, p, p+1
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const float4 gq = Gs[slot][tid + q * g.CVS], aq = As[slot][tid + q * g.CVS];
+          const float4 gq = Gs(slot, jr)[tid + q * g.CVS], aq = As(slot, jr)[tid + q * g.CVS];
           G[q][0] = gq.x; G[q][1] = gq.y; G[q][2] = gq.z; G[q][3] = gq.w;
           A[q][0] = aq.x; A[q][1] = aq.y; A[q][2] = aq.z; A[q][3] = aq.w;
         }
-        if (cc.it == 0) {
+        if (idx == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { accA[j] = 0.f; accB[j] = 0.f; }
         }
@@ -630,12 +646,13 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
           accB[j] += wr[3][j] * G[2][j]; accB[j] += wr[4][j] * G[1][j]; accB[j] += wr[5][j] * G[0][j];
           accC[j] = wr[6][j] * G[2][j]; accC[j] += wr[7][j] * G[1][j]; accC[j] += wr[8][j] * G[0][j];
         }
-        const int q = r - 1;     // finished e_in row
-        if (cc.it >= 2 && q < g.H && cc.x0 + p < g.W) {
+        const int q = cc.o0 + idx - 2;     // finished e_in row
+        const bool prev_owned = idx >= 2 && idx <= g.RS + 1;
+        if (prev_owned && q < g.H && cc.x0 + p < g.W) {
           float out[4];
           if (g.x_mask) {
             float xv[4];
-            unpack4(xprev, xv);
+            unpack4(jr == 0 ? xprev : xcur[jr > 0 ? jr - 1 : 0], xv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const bool dead = g.x_relu && !(xv[j] * sc[j] + sh[j] > 0.f);
@@ -649,11 +666,11 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
           }
           V4<bf16_t>::store(g.ein + (((long)cc.b * g.H + q) * g.W + cc.x0 + p) * g.ldei + c0, out);
         }
-        // weight gradient over the rows this unit owns (it = 1 .. RS for row r, it = 2 .. RS + 1 for row r - 1)
-        const bool own_cur = cc.it >= 1 && cc.it <= g.RS, own_prev = cc.it >= 2;
+        // weight gradient over the rows this unit owns (idx = 1 .. RS for row r, 2 .. RS + 1 for row r - 1)
+        const bool own_cur = idx >= 1 && idx <= g.RS;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gc = own_cur ? G[1][j] : 0.f, gp = own_prev ? gprev[j] : 0.f;
+          const float gc = own_cur ? G[1][j] : 0.f, gp = prev_owned ? gprev[j] : 0.f;
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             dwa[6 + kx][j] += gp * A[kx][j];          // o = r - 1, tap row 2: a[o + 1]
@@ -665,10 +682,11 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
           for (int kx = 0; kx < 3; ++kx) aprev[kx][j] = A[kx][j];
           accA[j] = accB[j]; accB[j] = accC[j];
         }
-        xprev = xcur;
+       }
+        xprev = xcur[RPJ - 1];
       }
 #ifdef TSS_ROLL_TIMING
-      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * BPF));     // (the store of this step; the row requests stay in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(6 * RPJ * PFB));     // (the store of this step; the row requests stay in flight)
       TSS_RT(rt4);
       rt_ph[0] += rt1 - rt0; rt_ph[1] += rt2 - rt1a; rt_ph[2] += rt3 - rt2; rt_ph[3] += rt4 - rt3; rt_ph4 += rt1a - rt1;
 #endif
@@ -679,7 +697,10 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
   TSS_RT(rt_tail);
   // the last BPF requests are never used but must land before their registers are reused (see the forward kernel)
 #pragma unroll
-  for (int k = 0; k < BPF; ++k) arrived2<0>(raw[k][0], raw[k][1], raw[k][2], raw[k][3], raw[k][4], raw[k][5]);
+  for (int k = 0; k < PFB; ++k)
+#pragma unroll
+    for (int jr = 0; jr < RPJ; ++jr)
+      arrived2<0>(raw[k][6 * jr], raw[k][6 * jr + 1], raw[k][6 * jr + 2], raw[k][6 * jr + 3], raw[k][6 * jr + 4], raw[k][6 * jr + 5]);
 
   float* red = reinterpret_cast<float*>(&rows_s[0][0]);
   if (g.stats) flush_slab<4>(s1, s2, g.stats, g.C, g.CVS, g.PXL, sl, brow, g.rows_used, p, cg, lane_on, red);
@@ -994,7 +1015,7 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s2_kernel(const RollBwdArgs
   }
 }
 
-void plan_bwd(RollBwdArgs& g, int S, int Ho, int Wo) {
+void plan_bwd(RollBwdArgs& g, int S, int Ho, int Wo, int rpj = 1) {
   const int cv4 = g.C / 4;
   g.nsl = (g.C + 63) / 64;
   g.CVS = cv4 < 16 ? cv4 : 16;
@@ -1009,7 +1030,7 @@ void plan_bwd(RollBwdArgs& g, int S, int Ho, int Wo) {
     const int segs = (Ho + RS - 1) / RS;
     const long units = (long)g.B * g.nstrips * segs;
     const long k = (units + cap - 1) / cap;
-    const long cost = k * (RS + halo) + 6;
+    const long cost = k * ((RS + halo + rpj - 1) / rpj) * rpj + 6;
     if (best_cost < 0 || cost < best_cost) {
       best_cost = cost;
       g.RS = RS; g.nseg = segs;
@@ -1067,8 +1088,11 @@ int dwroll_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const
   g.x_mask = x_pending; g.ein = (bf16_t*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
   g.B = B; g.H = H; g.W = W; g.C = C;
   const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
-  plan_bwd(g, stride, Ho, Wo);
-  if (stride == 1) hipLaunchKernelGGL(dw_bwd_roll_s1_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
+  const char* sw = getenv("TSS_ROLL_RPJ");               // A/B: input rows per step of the stride-1 sweep (default 2)
+  const int rpj = (stride == 1 && !(sw && atoi(sw) == 1)) ? 2 : 1;
+  plan_bwd(g, stride, Ho, Wo, rpj);
+  if (stride == 1 && rpj == 2) hipLaunchKernelGGL(dw_bwd_roll_s1_kernel<2>, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
+  else if (stride == 1) hipLaunchKernelGGL(dw_bwd_roll_s1_kernel<1>, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g);
   else hipLaunchKernelGGL(dw_bwd_roll_s2_kernel, dim3(g.nsl * g.rows_used), dim3(NT), 0, stream, g, Ho, Wo);
   return g.rows_used;
 }
