@@ -251,7 +251,9 @@ DW = [
 
 
 @pytest.mark.parametrize('case', DW, ids=[c[0] for c in DW])
-def test_depthwise_strip_kernels_vs_f64_oracle(case):
+def test_depthwise_kernels_vs_f64_oracle(case):
+    """Depthwise layers between two 1x1 layers: the row-pipelined kernels of csrc/dwroll.hip (dilation 1: forward, and input gradient +
+    weight gradient in one sweep) and the strip kernels (dilation 4) against the f64 bf16-storage oracle."""
     name, spec, shape = case
     bad = check(name, *run_case(spec, shape))
     assert not bad, bad
