@@ -66,6 +66,12 @@ def test_adaptive_pool_fwd_bwd(bins, h, w):
     assert rel(ya, yb) < 1e-5 and rel(a.grad, b.grad) < 1e-5
 
 
+def maxrel(a, b):
+    """largest elementwise difference relative to the largest element: catches a few channels that are plainly wrong, which a
+    relative L2 norm over a large tensor hides"""
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30)).item()
+
+
 @pytest.mark.parametrize('stride,dil,c,h,w', [(1, 1, 48, 9, 21), (2, 1, 32, 10, 22), (1, 4, 128, 12, 19)])
 @pytest.mark.parametrize('pending', [True, False])
 def test_depthwise_fused_backward_matches_two_launches(stride, dil, c, h, w, pending):
@@ -136,10 +142,10 @@ def test_depthwise_row_pipelined_backward_matches_two_launches(c, h, w, stride, 
         return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
     dx1, g1 = run(True)
     dx0, g0 = run(False)
-    assert rel(dx1, dx0) < 1e-2
+    assert rel(dx1, dx0) < 1e-2 and maxrel(dx1, dx0) < 5e-2
     for k in g0:
         if g0[k].norm() > 1e-3:
-            assert rel(g1[k], g0[k]) < 1e-2, k
+            assert rel(g1[k], g0[k]) < 1e-2 and maxrel(g1[k], g0[k]) < 5e-2, k
 
 
 def test_resize_image_matches_interpolate():
@@ -590,7 +596,7 @@ def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
         return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
     dx1, g1 = run(True)
     dx0, g0 = run(False)
-    assert rel(dx1, dx0) < 1e-2
+    assert rel(dx1, dx0) < 1e-2 and maxrel(dx1, dx0) < 5e-2
     for k in g0:
         if g0[k].norm() > 1e-3:
-            assert rel(g1[k], g0[k]) < 1e-2, k
+            assert rel(g1[k], g0[k]) < 1e-2 and maxrel(g1[k], g0[k]) < 5e-2, k

@@ -34,7 +34,8 @@ __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0x
 // NT threads (NW waves); TM pixels per tile, TM / NW per wave; FKM = 16-channel fragments of Cin a wave handles (all of them);
 // NFW = 16-channel fragments of Cout whose weight-gradient rows a wave owns (fragments w, w + NW, ...).  Two instances:
 // NSPLIT = 2: the waves pair up over the input-channel fragments of the input gradient (half of FKM each, twice the pixels).
-//   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU
+//   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <256, 64, 4, 2, 1>: Cin <= 64, Cout <= 128, two blocks per CU;
+//   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU (opt-in: it loses to the two separate kernels)
 template <int NT, int TM, int FKM, int NFW, int NSPLIT>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
   constexpr int NW = NT / 64;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   constexpr int RSX = NCM + 8;                           // Xs / Ws row pitch (elements): +16 bytes against bank conflicts
   constexpr int ROWT = TM * 2 + 16;                      // Gt / At row pitch (bytes)
   constexpr int NPG = TM / 4, PXW = TM / (NW / NSPLIT), MFX = PXW / 16, NKP = TM / 32, FKW = FKM / NSPLIT;
-  static_assert(PXW % 16 == 0 && NPG * 16 <= NT * 2, "tile shape");
+  static_assert(PXW % 16 == 0 && TM >= 64, "tile shape (the XOR swizzle of the transposed images needs >= 8 chunks of 16 bytes per row)");
   extern __shared__ __align__(16) unsigned char smem[];
   T* Xs = reinterpret_cast<T*>(smem);                    // [TM][RSX]
   T* Ws = Xs + TM * RSX;                                 // [KCM][RSX]   W^T: row = input channel, columns = output channels
@@ -390,6 +391,7 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
 }
 
 inline bool small_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
+inline bool mid_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 128; }     // 64-pixel tiles, two blocks per CU
 
 }  // namespace
 
@@ -399,21 +401,22 @@ extern "C" {
 // by the two separate kernels dominates); the number of workspace rows it writes comes from tss_pwconv_bwd_fused_rows
 int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
   // TSS_PW_BWD_FUSED: 0 = never; n > 1 = every layer inside the envelope with at least n pixels (tests, A/B runs).
-  // Default: the two-blocks-per-CU instance (both channel counts <= 64) from 50 k pixels -- measured 99 vs 157 us (32 -> 48
-  // channels at 1 M pixels), 43 vs 62 (48 -> 64, 262 k), 23.5 vs 27.9 (64 -> 64, 65 k); the 128-channel instance (one 8-wave block per
+  // Default: the two-blocks-per-CU instances -- both channel counts <= 64 from 50 k pixels: 99 vs 157 us (32 -> 48 channels at
+  // 1 M pixels), 43 vs 62 (48 -> 64, 262 k), 23.5 vs 27.9 (64 -> 64, 65 k); Cin <= 64, Cout <= 128 from 200 k pixels: 73 vs 96 us
+  // (64 -> 128, 262 k); the 128-channel instance (one 8-wave block per
   // CU, 40 spilled registers) loses (139 vs 119 us for 128 -> 128 at 262 k pixels), so those layers keep the two kernels.
   const char* sw = getenv("TSS_PW_BWD_FUSED");
   if (sw && atoi(sw) == 0) return 0;
   const bool inside = dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128;
   if (sw && atol(sw) > 1) return inside && P >= atol(sw);
-  return inside && small_shape(Cin, Cout) && P >= 50000;
+  return inside && ((small_shape(Cin, Cout) && P >= 50000) || (mid_shape(Cin, Cout) && P >= 200000));
 }
 
 int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
-  const bool small = small_shape(Cin, Cout);
-  const long TM = 128;
+  const bool small = small_shape(Cin, Cout), mid = !small && mid_shape(Cin, Cout);
+  const long TM = mid ? 64 : 128;
   long gs = ((P + TM - 1) / TM + 7) / 8;
-  const long cap = small ? 64 : 32;
+  const long cap = (small || mid) ? 64 : 32;
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   return (int)(8 * gs);
@@ -442,6 +445,7 @@ int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, c
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0, 4.0 * (double)P * Cin * Cout);
   if (small_shape(Cin, Cout)) launch<256, 128, 4, 1, 1>(g, (hipStream_t)stream, 2);
+  else if (mid_shape(Cin, Cout)) launch<256, 64, 4, 2, 1>(g, (hipStream_t)stream, 2);
   else launch<512, 128, 8, 1, 2>(g, (hipStream_t)stream, 1);
   return tss::check_last("pwconv_bwd_fused");
 }
