@@ -36,7 +36,10 @@ __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0x
 // NSPLIT = 2: the waves pair up over the input-channel fragments of the input gradient (half of FKM each, twice the pixels).
 //   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <256, 64, 4, 2, 1>: Cin <= 64, Cout <= 128, two blocks per CU;
 //   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU (opt-in: it loses to the two separate kernels)
-template <int NT, int TM, int FKM, int NFW, int NSPLIT>
+// TR: no pixel-major image of g at all -- the input-gradient product reads its g operand out of the channel-major image Gt with
+// the transposing LDS read of gfx950 (ds_read_b64_tr_b16: a group of 16 lanes reads a 4-row x 16-column block and lane i receives
+// column i), which frees the 17 KB that keep the 128-channel shape from fitting twice into a CU's LDS
+template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
   constexpr int NW = NT / 64;
   constexpr int NCM = 16 * NW * NFW, KCM = 16 * FKM;     // channel capacities
@@ -45,8 +48,8 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   constexpr int NPG = TM / 4, PXW = TM / (NW / NSPLIT), MFX = PXW / 16, NKP = TM / 32, FKW = FKM / NSPLIT;
   static_assert(PXW % 16 == 0 && TM >= 64, "tile shape (the XOR swizzle of the transposed images needs >= 8 chunks of 16 bytes per row)");
   extern __shared__ __align__(16) unsigned char smem[];
-  T* Xs = reinterpret_cast<T*>(smem);                    // [TM][RSX]
-  T* Ws = Xs + TM * RSX;                                 // [KCM][RSX]   W^T: row = input channel, columns = output channels
+  T* Xs = reinterpret_cast<T*>(smem);                    // [TM][RSX]  (TR: absent)
+  T* Ws = Xs + (TR ? 0 : TM * RSX);                                 // [KCM][RSX]   W^T: row = input channel, columns = output channels
   unsigned char* Gt = reinterpret_cast<unsigned char*>(Ws + KCM * RSX);   // [NCM][ROWT]
   unsigned char* At = Gt + NCM * ROWT;                   // [KCM][ROWT]
   float* Ec = reinterpret_cast<float*>(At + KCM * ROWT); // [3][KCM]: producer's mean / scale / bias (ReLU mask, statistics)
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 
   // ---- block set-up under the first tile's loads: zero the images once (padding rows / columns stay zero), W^T, constants
   {
-    constexpr int total = (TM * RSX + KCM * RSX) * 2 + (NCM + KCM) * ROWT;
+    constexpr int total = ((TR ? 0 : TM * RSX) + KCM * RSX) * 2 + (NCM + KCM) * ROWT;
     for (int i = tid; i < total / 16; i += NT) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (tid < KCM) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
-        V8<T>::store(Xs + (pgG * 4 + i) * RSX + cvG * 8, v[i]);
+        if (!TR) V8<T>::store(Xs + (pgG * 4 + i) * RSX + cvG * 8, v[i]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -241,7 +244,25 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
       for (int ks = 0; ks < nks; ++ks) {
         bf16x8 xf[MFX];
 #pragma unroll
-        for (int m = 0; m < MFX; ++m) xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RSX + ks * 32);
+        for (int m = 0; m < MFX; ++m) {
+          if (!TR) {
+            xf[m] = *reinterpret_cast<const bf16x8*>(xrow + m * 16 * RSX + ks * 32);
+          } else {
+            // lane (fr, fq) needs g[pixel px0 + fr][channels kc0 .. kc0 + 7], kc0 = ks*32 + fq*8: two transposed reads of the blocks
+            // (rows kc0 + 0..3 | kc0 + 4..7) x (16 pixels from px0) of Gt; lane 4q + p of the group addresses row q, pixels 4p .. 4p+3
+            const int px0 = wp * PXW + m * 16, q = fr >> 2, pq = fr & 3;
+            typedef __attribute__((ext_vector_type(4))) short v4s;
+            v4s lo, hi;
+            {
+              const int row = ks * 32 + fq * 8 + q, pg = (px0 >> 2) + pq;
+              lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)unit_ptr(Gt, row, pg));
+              hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)unit_ptr(Gt, row + 4, pg));
+            }
+            union { v4s h[2]; bf16x8 v; } u;
+            u.h[0] = lo; u.h[1] = hi;
+            xf[m] = u.v;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < FKW; ++i) {
           if (i0 + i < FK) {
@@ -368,13 +389,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   }
 }
 
-template <int NT, int TM, int FKM, int NFW>
+template <int NT, int TM, int FKM, int NFW, bool TR>
 constexpr size_t smem_bytes() {
   constexpr int NCM = 16 * (NT / 64) * NFW, KCM = 16 * FKM;
-  return (size_t)(TM + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float);
+  return (size_t)((TR ? 0 : TM) + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float);
 }
 
-template <int NT, int TM, int FKM, int NFW, int NSPLIT>
+template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR>
 int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
@@ -382,16 +403,19 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   g.gslots = (int)gs;
-  constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW>();
+  constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW, TR>();
   static tss::DevOnce attr;
   if (attr.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
   return 8 * (int)gs;
 }
 
 inline bool small_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
 inline bool mid_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 128; }     // 64-pixel tiles, two blocks per CU
+// the two 128-channel instances (neither is used by default: both lose to the two separate kernels -- 139 us for the 8-wave one,
+// 209 us for the transposed-read one, which spills 69 registers, against 121 us): TSS_PW_BWD_BIG=2 selects the transposed-read one
+inline bool big_tr() { const char* s = getenv("TSS_PW_BWD_BIG"); return s && atoi(s) == 2; }
 
 }  // namespace
 
@@ -414,9 +438,10 @@ int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
 
 int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
   const bool small = small_shape(Cin, Cout), mid = !small && mid_shape(Cin, Cout);
-  const long TM = mid ? 64 : 128;
+  const bool big2 = !small && !mid && big_tr();
+  const long TM = (mid || big2) ? 64 : 128;
   long gs = ((P + TM - 1) / TM + 7) / 8;
-  const long cap = (small || mid) ? 64 : 32;
+  const long cap = (small || mid || big2) ? 64 : 32;
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   return (int)(8 * gs);
@@ -444,9 +469,10 @@ int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, c
   g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0, 4.0 * (double)P * Cin * Cout);
-  if (small_shape(Cin, Cout)) launch<256, 128, 4, 1, 1>(g, (hipStream_t)stream, 2);
-  else if (mid_shape(Cin, Cout)) launch<256, 64, 4, 2, 1>(g, (hipStream_t)stream, 2);
-  else launch<512, 128, 8, 1, 2>(g, (hipStream_t)stream, 1);
+  if (small_shape(Cin, Cout)) launch<256, 128, 4, 1, 1, false>(g, (hipStream_t)stream, 2);
+  else if (mid_shape(Cin, Cout)) launch<256, 64, 4, 2, 1, false>(g, (hipStream_t)stream, 2);
+  else if (big_tr()) launch<256, 64, 8, 2, 2, true>(g, (hipStream_t)stream, 2);
+  else launch<512, 128, 8, 1, 2, false>(g, (hipStream_t)stream, 1);
   return tss::check_last("pwconv_bwd_fused");
 }
 
