@@ -169,6 +169,14 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
                            int B, int Hin, int Win, int C, int stride, int dil, int dtype, void* stream);
+/* tss_pwconv_bwd_data for a layer whose (materialised) input has a second consumer -- the skip of a residual block: the other
+ * gradient of that tensor, radd (bf16 [P][K], pitch ldr), is added in the epilogue instead of by an elementwise launch:
+ * e_in = g W + radd.  Lean bf16 path only (tss_pwconv_bwd_data_radd_supported); no producer mask / statistics (input materialised). */
+int tss_pwconv_bwd_data_radd_supported(long P, int K, int N, int dtype);
+int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldyr,
+                             const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
+                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, const void* radd, long ldr,
+                             long P, int K, int N, int dtype, void* stream);
 /* 1x1 layer, backward in ONE sweep (csrc/pwbwd.hip; bf16, Cin, Cout <= 128, both multiples of 8): e, yraw and x are read once,
  * e_in written once -- replaces tss_pwconv_bwd_weight + tss_pwconv_bwd_data where their double read of (e, yraw) dominates
  * (tss_pwconv_bwd_fused_preferred: few channels, many pixels).  x is the layer's input (always given); x_pending = 1 when it is a

@@ -468,3 +468,37 @@ def test_fused_bottleneck_backward_matches_the_layer_by_layer_backward(shape, ci
     assert errs['dx'] < 2e-2
     for k, v in errs.items():
         assert v < 3e-2, (k, v)
+
+
+def test_residual_fan_in_folded_into_the_first_layers_backward_matches_autograds_add():
+    """The block input of a residual bottleneck has two consumers; ops.residual_fork hands the skip's gradient to the epilogue of
+    conv1's backward-data kernel (tss_pwconv_bwd_data_radd) instead of letting autograd add the two tensors with a launch of its
+    own.  Same gradients as the unfolded graph (TSS_FOLD_RESIDUAL=0), up to one bf16 rounding of the sum."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+
+    def run(fold):
+        torch.manual_seed(37)
+        m = F_.BottleneckModule(32, 32, expansion=6, repeats=3, stride=1).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = torch.randn(2, 32, 24, 40, device=DEV).requires_grad_(True)
+        old = ops.fold_residual_adds
+        ops.fold_residual_adds = fold
+        try:
+            out = ops.materialize(m(x))
+            out.float().backward(torch.randn_like(out, dtype=torch.float32))
+        finally:
+            ops.fold_residual_adds = old
+        assert not ops._pending_forks
+        return out.float(), x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+    o1, dx1, g1 = run(True)
+    o0, dx0, g0 = run(False)
+    assert torch.equal(o1, o0)
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(dx1, dx0) < 1e-2
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert l2(g1[k], g0[k]) < 2e-2, k

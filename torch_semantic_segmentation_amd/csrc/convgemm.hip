@@ -508,7 +508,7 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
-                         long P, int K, int N, hipStream_t stream);  // pwfast.hip
+                         long P, int K, int N, hipStream_t stream, const void* radd = nullptr, long ldr = 0);  // pwfast.hip
 void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream);  // wgrad.hip
 bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
                          int B, int Cin, int Hin, int Win, int N, int stride, int dtype, hipStream_t stream);  // stem.hip
@@ -565,6 +565,28 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   }
   if (wg_ws && wg_dw) tss_wg_reduce_standalone(wg_ws, wg_dw, P, K, N, (hipStream_t)stream);   // nobody else will
   return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
+}
+
+// tss_pwconv_bwd_data with the fan-in of a residual block folded in: e_in = g W + radd (bf16 [P][K], pitch ldr).  Only on the lean
+// bf16 path and only for a materialised input (no xraw): tss_pwconv_bwd_data_radd_supported says whether the call will be taken;
+// otherwise the caller adds the two gradients itself.
+int tss_pwconv_bwd_data_radd_supported(long P, int K, int N, int dtype) {
+  return dtype == TSS_BF16 && !g_tss_disable_fast && N <= 768 && (N % 8) == 0 && (K % 8) == 0 && P > 0;
+}
+
+int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldyr,
+                             const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
+                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, const void* radd, long ldr,
+                             long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(tss_pwconv_bwd_data_radd_supported(P, K, N, dtype) && yraw && radd, TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= N && (ldyr % 8) == 0 && ldyr >= N && (ldei % 4) == 0 && ldei >= K && (ldr % 4) == 0 && ldr >= K, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(w) && ((uintptr_t)radd & 7u) == 0, TSS_ERR_ALIGN);
+  const double bytes = (double)P * (N * 2 + K * 2) * 2.0;
+  tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
+  if (!tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, wT_bf16, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                           e_in, ldei, nullptr, wg_ws, wg_dw, P, K, N, (hipStream_t)stream, radd, ldr))
+    return TSS_ERR_SHAPE;
+  return tss::check_last("pwfast_bwd_data_radd");
 }
 
 int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

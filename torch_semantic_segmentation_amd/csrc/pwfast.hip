@@ -38,6 +38,7 @@ struct FastArgs {
   const float* bias;
   T* y; long ldy; double* stats;
   const T* xm; long ldxm; const float* mm; const float* ms; const float* mb; int m_relu;
+  const T* radd; long ldr;              // bwd, input already materialised (no xm): e_in = acc + radd (the skip gradient of a residual block)
   int gslots;
   tss_wg::ReduceArgs red;               // bwd: pending weight-gradient slot reduction of the same layer (nred == 0: none)
   int nred8;                            // its block count rounded up to 8 (keeps blockIdx % 8 == XCD for the main blocks)
@@ -385,6 +386,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
               for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             } else {
+              if (BWD && g.radd) {     // fan-in of a residual block: the other gradient of this tensor is added here, not by a launch of its own
+                const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
+                const uint2 rr = *reinterpret_cast<const uint2*>(g.radd + pr * g.ldr + nlane + i * 16);
+                v[0] += bits_lo(rr.x); v[1] += bits_hi(rr.x); v[2] += bits_lo(rr.y); v[3] += bits_hi(rr.y);
+              }
               bf16x4 o;
 #pragma unroll
               for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
@@ -647,6 +653,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
               for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             } else {
+              if (BWD && g.radd) {     // fan-in of a residual block: the other gradient of this tensor is added here, not by a launch of its own
+                const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
+                const uint2 rr = *reinterpret_cast<const uint2*>(g.radd + pr * g.ldr + nlane + i * 16);
+                v[0] += bits_lo(rr.x); v[1] += bits_hi(rr.x); v[2] += bits_lo(rr.y); v[3] += bits_hi(rr.y);
+              }
               bf16x4 o;
 #pragma unroll
               for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
@@ -776,8 +787,9 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
-                         long P, int K, int N, hipStream_t stream) {
+                         long P, int K, int N, hipStream_t stream, const void* radd, long ldr) {
   if (g_tss_disable_fast || !yraw || N > KTOT || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
+  if (radd && (xraw || (ldr % 4) != 0 || ldr < K)) return false;     // the add is only folded into the unmasked epilogue
   FastArgs g = {};
   if (red_ws && red_dw) {   // the layer's weight-gradient slots are summed by the first blocks of this launch
     g.red = tss_wg::reduce_args(red_ws, red_dw, P, K, N);
@@ -788,6 +800,7 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   g.w = w; g.w_trans = 1; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wb = (const T*)wT_bf16; g.ldwb = N; }   // transpose [conv K][conv N]: rows of N contraction channels
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
+  g.radd = (const T*)radd; g.ldr = ldr;
   if (N <= KMAX) {
     static const long thr = getenv("TSS_PW_BWD_SMALL") ? atol(getenv("TSS_PW_BWD_SMALL")) : 4200;   // 32-pixel tiles, as above
     const long t64 = (P + 63) / 64 * ((K + NCH - 1) / NCH);

@@ -54,14 +54,21 @@ class BottleneckBlock(nn.Module):
 
     def forward(self, input):
         x = ops.to_nhwc(ops.materialize(input))
+        # shape-equal skip: the block input has two consumers; their gradients meet in the epilogue of conv1's backward-data kernel
+        # (ops.residual_fork) instead of in an elementwise launch of autograd's
+        c1, c2, c3 = self.conv1[0], self.conv2[0], self.conv3[0]
+        residual = tuple(c2.stride) == (1, 1) and c1.in_channels == c3.out_channels and not has_hooks(self.conv1)
+        xa, xb, fork = ops.residual_fork(x) if residual else (x, x, None)
         d = None
         if not (has_hooks(self.conv1) or has_hooks(self.conv2)):
-            d = ops.expand_dw_unit(x, self.conv1, self.conv2)       # one autograd node: the backward never touches the 6x tensors
+            d = ops.expand_dw_unit(xa, self.conv1, self.conv2)       # one autograd node: the backward never touches the 6x tensors
         if d is None:
-            d = run(self.conv2, run(self.conv1, x))
+            d = run(self.conv2, run(self.conv1, xa))
+        if fork is not None:
+            ops._pending_forks.pop(id(xa), None)
         d = run(self.conv3, d)
         same = tuple(d.shape) == tuple(x.shape)
-        return ops.join(d, x if same else None, relu=True)
+        return ops.join(d, xb if same else None, relu=True, fork=fork if same else None)
 
 
 def LinearBottleneck(in_channels, out_channels, num_blocks, expansion=6, stride=1):

@@ -92,6 +92,52 @@ def _defer_dw_reduction(ws, dw, ncols, nrows):
     _pending_dw.append((ws, dw, ncols, nrows, task))
 
 
+# Residual blocks: the block input has two consumers (the first 1x1 layer and the skip), so its gradient is a sum of two tensors.
+# Autograd would add them with an elementwise launch of its own; instead the skip's gradient (produced first, by the join's
+# backward) is handed to the first layer's backward-data kernel, which adds it in its epilogue (tss_pwconv_bwd_data_radd).
+fold_residual_adds = os.environ.get('TSS_FOLD_RESIDUAL', '1') != '0'
+_pending_forks = {}
+
+
+class _Fork:
+    __slots__ = ('g2', 'consumed')
+
+    def __init__(self):
+        self.g2, self.consumed = None, False
+
+
+class ForkFn(Function):
+    """x -> (x, x): two handles of one tensor whose gradients meet here.  If the consumer of the first handle has already added the
+    second handle's gradient into its own (fork.consumed), that sum is passed on as it is."""
+
+    @staticmethod
+    def forward(ctx, x, fork):
+        ctx.fork = fork
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        fork = ctx.fork
+        consumed = fork.consumed
+        fork.g2, fork.consumed = None, False
+        if ga is None:
+            return gb, None
+        if gb is None or consumed:
+            return ga, None
+        return ga + gb, None
+
+
+def residual_fork(x):
+    """(handle for the convolution path, handle for the skip, fork) of a residual block's input; (x, x, None) when nothing is folded."""
+    if not (fold_residual_adds and torch.is_grad_enabled() and torch.is_tensor(x) and x.requires_grad and x.is_cuda
+            and x.dtype == torch.bfloat16 and not N.fast_paths_disabled()):
+        return x, x, None
+    fork = _Fork()
+    xa, xb = ForkFn.apply(x, fork)
+    _pending_forks[id(xa)] = fork          # picked up by the first conv unit that consumes xa (conv_unit)
+    return xa, xb, fork
+
+
 _side_streams = {}
 
 
@@ -398,7 +444,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork')
 
 
 def _classify(conv, x_is_image):
@@ -450,12 +496,14 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         cfg.in_link, cfg.in_relu = None, False
         cfg.image_f32 = x_raw.dtype == torch.float32
         cfg.out_dtype = out_dtype or x_raw.dtype
+        cfg.res_fork = None
     else:
         d = as_deferred(x).take()
         x_raw = d.raw
         cfg.in_link, cfg.in_relu = d.link, d.relu
         cfg.image_f32 = False
         cfg.out_dtype = x_raw.dtype
+        cfg.res_fork = _pending_forks.pop(id(x_raw), None) if _pending_forks else None
     if x_raw.shape[1] != conv.in_channels:
         raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
     cfg.bn = bn
@@ -706,8 +754,16 @@ class ConvUnitFn(Function):
                     else:
                         _reduce_rows_now(ws, dw, Cout * Cin, rows)
                 elif cfg.kind == 'pw':
-                    call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
-                         ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
+                    fork = getattr(cfg, 'res_fork', None)
+                    radd = fork.g2 if fork is not None else None
+                    if (radd is not None and not deferred_in and y is not None and e.dtype == torch.bfloat16 and radd.dtype == e.dtype
+                            and tuple(radd.shape) == tuple(e_in.shape) and N.lib().tss_pwconv_bwd_data_radd_supported(P, Cin, Cout, dt)):
+                        call('tss_pwconv_bwd_data_radd', *gargs, ptr(weight), _shadow(weight, 1), ptr(e_in), ld(e_in),
+                             ptr(ws) if defer else None, ptr(dw) if defer else None, ptr(radd), ld(radd), P, Cin, Cout, dt, st)
+                        fork.consumed = True
+                    else:
+                        call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
+                             ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
                 elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
                     # the rows of per-block partial sums stay in ws; they are added to the (direct) gradient together with
                     # those of every other depthwise layer, in one launch at the end of this backward pass
@@ -886,10 +942,10 @@ class ExpandDwFn(Function):
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
 
 class JoinCfg:
-    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus', 'drop_p')
+    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus', 'drop_p', 'res_fork')
 
 
-def join(a, b=None, relu=False, dropout_p=0.0):
+def join(a, b=None, relu=False, dropout_p=0.0, fork=None):
     """relu?(bn_a(a) + bn_b(b)) -> ordinary NHWC tensor.  a, b: Deferred (without pending ReLU) or tensors.
     dropout_p > 0 (ReLU joins only): nn.Dropout applied in the same pass, forward and backward."""
     a = as_deferred(a).take()
@@ -910,6 +966,7 @@ def join(a, b=None, relu=False, dropout_p=0.0):
         if b.raw.shape != a.raw.shape or b.raw.dtype != a.raw.dtype:
             raise RuntimeError('join: operands differ in shape/dtype: %s vs %s' % (a.raw.shape, b.raw.shape))
         braw, cfg.b_link = b.raw, b.link
+    cfg.res_fork = fork if b is not None else None
     return JoinFn.apply(a.raw, braw, cfg)
 
 
@@ -944,6 +1001,9 @@ class JoinFn(Function):
                  ptr(e), ld(e) if e is not None else 0, 1.0 / (1.0 - cfg.drop_p) if cfg.drop_p else 1.0,
                  npix(dout), dout.shape[1], N.dtype_code(dout.dtype), stream())
         g = e if e is not None else dout
+        fork = getattr(cfg, 'res_fork', None)
+        if fork is not None and ctx.has_b:
+            fork.g2 = g                    # the skip's gradient, for the epilogue of the block's first layer
         return g, (g if ctx.has_b else None), None
 
 
