@@ -1,6 +1,7 @@
 """ContextNet (12/14/18) on the MI355X HIP path: public surface, module tree and state_dict keys (314) of
 TSS/models/contextnet.py; arithmetic in the HIP kernels behind include/tss_hip.h.
 """
+import torch
 from torch import nn
 
 from .. import ops
@@ -134,12 +135,35 @@ class ContextNet(HipModel):
 
     logit_scale = 8   # the head's F.interpolate(scale_factor=8) (TSS/models/contextnet.py:74-76)
 
+    def _branches_can_overlap(self):
+        # not with hooks on the branches (user code would run under the side stream), and not with cross-replica BatchNorm: its
+        # all-reduces would be issued from two streams onto one communicator, in an order that can differ between the ranks
+        if has_hooks(self.context) or has_hooks(self.spatial):
+            return False
+        return not any(isinstance(m, ops.SyncBatchNorm) for m in self.modules())
+
     def forward_lowres(self, input):
         """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits."""
         input = self.image_in(input)
-        spatial = self.spatial(input)
-        context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
-        context = self.context(context)
+        if ops.overlap_branches and input.is_cuda and self._branches_can_overlap():
+            # the two branches are independent up to the fusion module (TSS/models/contextnet.py:66-72): the context branch (a chain of
+            # small kernels on the 1/4-resolution image) runs on a side stream under the spatial branch's full-resolution kernels;
+            # in a captured step the two become parallel branches of the graph, forward and backward
+            dev = input.device
+            main, side = torch.cuda.current_stream(dev), ops._side_stream(dev)
+            side.wait_stream(main)
+            input.record_stream(side)
+            with torch.cuda.stream(side):
+                context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
+                context = self.context(context)
+            spatial = self.spatial(input)
+            main.wait_stream(side)
+            for t in ops.tensors_of(context):
+                t.record_stream(main)      # allocated on the side stream, consumed (and later freed) under the main one
+        else:
+            spatial = self.spatial(input)
+            context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
+            context = self.context(context)
         fusion = self.feature_fusion(context, spatial)
         return self.classifier(fusion)
 
