@@ -410,6 +410,7 @@ def main():
             dt = (time.perf_counter() - t1) / n_hb
             pipe.step()
             torch.cuda.synchronize()
+            pipe.close()                    # its captured steps and input slots leave the trainer with it
             mb = (bx.numel() * bx.element_size() + by.numel() * by.element_size()) / 1e6
             host_batch['pipelined_%s' % wire] = {'ms_per_step': round(1e3 * dt, 3), 'images_per_sec': round(args.batch / dt, 1),
                                                  'wire_MB_per_step': round(mb, 1),

@@ -38,6 +38,13 @@ extern "C" {
 #define TSS_F32 0
 #define TSS_BF16 1
 
+/* The arguments of tss_bn_bwd_finalize as a plain struct: a finalize that rides in front of another launch
+ * (tss_pwconv_bwd_weight's `fin`) is described by one of these, filled in by the caller on the host. */
+typedef struct tss_bn_bwd_job {
+  const double* bstats; double count; const float* invstd; const float* gamma; int training; int accumulate;
+  float* dgamma; float* dbeta; float* ga; float* gb; float* gce; int C;
+} tss_bn_bwd_job;
+
 /* kernel ids for the profiler (tss_prof_*) */
 enum {
   TSS_K_PWCONV_FWD = 0, TSS_K_PWCONV_BWD_DATA, TSS_K_PWCONV_BWD_WEIGHT,
@@ -82,21 +89,28 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
  * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
  * wT_bf16 (optional, bf16 path): a current bf16 TRANSPOSE [K][N] of w written by tss_cast_weights.
- * wg_ws / wg_dw (optional): the workspace and dW of a tss_pwconv_bwd_weight(..., defer_reduce = 1) call of the SAME layer
- * (same P, K, N): its slot reduction is carried by the first blocks of this launch instead of a kernel of its own. */
+ * wg_ws / wg_dw (optional): the workspace and dW of an earlier tss_pwconv_bwd_weight(..., defer_reduce = 1) call -- of this
+ * layer (wg_P = 0) or of ANY 1x1 layer whose weight gradient has been launched (wg_P, wg_K, wg_N = that call's P, K, N): its
+ * slot reduction is carried by the first blocks of this launch instead of a kernel of its own. */
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
+                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
                         long P, int K, int N, int dtype, void* stream);
 /* dw[n][k] += sum_p g[p][n] * act(x[p][k]).  ws: f32 workspace of tss_pwconv_bwd_weight_ws(P, K, N, dtype) floats for the
  * blocks' partial tiles (summed deterministically by a second kernel, or -- defer_reduce = 1 -- by the backward-data
- * launch of the same layer, see tss_pwconv_bwd_data); ws NULL, or a size of 0: f32 atomics onto dw. */
+ * launch of a later tss_pwconv_bwd_data / _radd call, or by tss_pwconv_wg_reduce); ws NULL, or a size of 0: f32 atomics onto dw.
+ * fin (optional): a BatchNorm-backward finalize of ANOTHER layer (tss_bn_bwd_finalize's arguments) that rides in front of this
+ * launch's grid: the weight gradient of a layer depends on nothing the backward pass computes after that layer's input
+ * gradient, so the caller may postpone it until the next finalize is due and save that launch (>= 4.7 us in a replayed graph). */
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, void* stream);
+                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, const tss_bn_bwd_job* fin,
+                          void* stream);
 long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype);
+/* the slot reduction of a tss_pwconv_bwd_weight(..., defer_reduce = 1) call that no later launch carried */
+int tss_pwconv_wg_reduce(const float* ws, float* dw, long P, int K, int N, void* stream);
 
 /* ---- dense 3x3 convolution, padding = dilation ------------------------------------------------------
  * replaces: nn.Conv2d(128,128,3,padding=1) of ConvBlock TSS/models/contextnet.py:55 (and any Conv2dBlock k=3, Cin%8==0).
@@ -175,20 +189,24 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
 int tss_pwconv_bwd_data_radd_supported(long P, int K, int N, int dtype);
 int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
-                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, const void* radd, long ldr,
-                             long P, int K, int N, int dtype, void* stream);
+                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
+                             const void* radd, long ldr, long P, int K, int N, int dtype, void* stream);
 /* 1x1 layer, backward in ONE sweep (csrc/pwbwd.hip; bf16, Cin, Cout <= 128, both multiples of 8): e, yraw and x are read once,
  * e_in written once -- replaces tss_pwconv_bwd_weight + tss_pwconv_bwd_data where their double read of (e, yraw) dominates
  * (tss_pwconv_bwd_fused_preferred: few channels, many pixels).  x is the layer's input (always given); x_pending = 1 when it is a
  * producer's raw output (in_* pending): e_in is then masked and bstats written as tss_pwconv_bwd_data does.  ws receives
  * tss_pwconv_bwd_fused_rows(P, Cin, Cout) rows of Cout*Cin floats (per-block partial sums of dW in the parameter's own
- * [Cout][Cin] order), to be added to dW by tss_dw_reduce_many.  wT_bf16: optional bf16 [Cin][Cout] shadow of w. */
+ * [Cout][Cin] order), to be added to dW by tss_dw_reduce_many.  wT_bf16: optional bf16 [Cin][Cout] shadow of w.
+ * bias_ws (optional): rows of Cout floats, per-block partial sums of g over the pixels -- the bias gradient of a biased conv
+ * (nn.Conv2d(128, classes, 1) of the classifiers, TSS/models/fastscnn.py:97), summed by tss_dw_reduce_many like the others.
+ * Cin <= 128, Cout <= 64 (and not both <= 64): Cout may be ragged (19 classes); e / yraw are then read through their pitch
+ * (>= Cout rounded up to 8) and whatever sits in the padding is ignored. */
 int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype);
 int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout);
 int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
                          const float* gmu, const float* w, const void* wT_bf16, const void* x, long ldx, const float* in_mean,
                          const float* in_scale, const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei,
-                         double* bstats, float* ws, long P, int Cin, int Cout, int dtype, void* stream);
+                         double* bstats, float* ws, float* bias_ws, long P, int Cin, int Cout, int dtype, void* stream);
 /* backward-data AND weight gradient of one layer in a single sweep (bf16; stride/dilation of the strip kernels): e, yraw
  * and x are read once.  x is the layer's input (always given: the weight gradient needs it); x_pending = 1 when it is a
  * producer's raw output whose BatchNorm(+ReLU) is still pending (in_* describe it): e_in is then masked and bstats
@@ -351,13 +369,15 @@ int tss_ohem_bwd(const void* logits, const long long* target, const float* lse, 
 /* Fused decoder head + loss: cross-entropy (mean over the non-ignored pixels) of the bilinearly upsampled logits,
  * straight from the low-res NHWC logits (replaces F.interpolate TSS/models/fastscnn.py:63-64 + the loss call
  * TSS/engine.py:30 as one operator; the full-resolution logits and their gradient are never materialised).
- * One pass computes the loss AND the unscaled low-res gradient (dlow_acc, f32, caller-zeroed, same [B][h][w][ldl]
- * layout as low); backward = tss_upsample_ce_bwd: dlow = dlow_acc * grad_out / count.  C <= 24, H >= h, W >= w. */
-int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* dlow_acc,
-                        double* acc, float* loss, float* inv_count,
+ * One pass computes the loss AND the unscaled low-res gradient, as per-block tiles and per-block loss rows in `ws`
+ * (tss_upsample_ce_ws(...) floats, 16-byte aligned, NOT initialised by the caller: every element that is read was written by
+ * the pass); backward = tss_upsample_ce_bwd gathers the tiles of every low-res cell in a fixed order: dlow = sum * grad_out /
+ * count ([B][h][w][ldl], pitch padding zeroed).  No atomics anywhere: bit-identical from run to run.  C <= 24, H >= h, W >= w. */
+long tss_upsample_ce_ws(int B, int C, int h, int w, int H, int W);
+int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* ws, float* loss, float* inv_count,
                         int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream);
-int tss_upsample_ce_bwd(const float* dlow_acc, const float* inv_count, const float* grad_out, void* dlow,
-                        long n, int dtype, void* stream);
+int tss_upsample_ce_bwd(const float* ws, const float* inv_count, const float* grad_out, void* dlow, long ldl,
+                        int B, int C, int h, int w, int H, int W, int dtype, void* stream);
 int tss_upsample_head_bwd_cols(const float* tmp, void* dlow, long ldl, int B, int N, int h, int w, int W,
                                int dtype, void* stream);
 /* Fused evaluation head: argmax of the bilinearly upsampled logits (+ confusion matrix, rows = truth) from the low-res

@@ -220,6 +220,60 @@ def test_flat_adamw_and_graph_replay_match_eager():
         assert other[3] == base[3] == 3
 
 
+@pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
+def test_captured_step_is_bit_reproducible_and_scheduling_is_exact(name):
+    """the benchmarked step (bf16, fused head + loss, HIP-graph replay) has no atomics and no
+    order-dependent sums left -- two replays on the same batch from the same weights give BIT-IDENTICAL flat gradients,
+    losses and BatchNorm statistics; and the backward-pass scheduling (weight gradients postponed so that the next
+    BatchNorm-backward finalize rides in front of them, slot reductions carried by a later layer's launch) changes no bit
+    of the gradient against the plain launch order."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    from torch_semantic_segmentation_amd import ops
+    x, y = synthetic_batch(2, 128, 256)
+    x, y = x.to(DEV), y.to(DEV)
+
+    def run(use_graph, postpone):
+        prev = ops.postpone_wgrad
+        ops.postpone_wgrad = postpone
+        try:
+            torch.manual_seed(3)
+            m = cases.product_model(name).to(DEV)
+            cases.zero_dropout(m)
+            tssa.set_compute_dtype(m, torch.bfloat16)
+            opt = E.FlatAdamW(m.parameters(), lr=0.0, weight_decay=0.0)       # lr 0: every step starts from the same weights
+            tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=use_graph)
+            out = []
+            for _ in range(3):
+                loss = tr.step_async(x, y)
+                torch.cuda.synchronize()
+                out.append((loss.clone(), opt.flat_grad.clone()))
+            bn = [b.clone() for n_, b in m.named_buffers() if n_.endswith('running_var')]
+            return out, bn
+        finally:
+            ops.postpone_wgrad = prev
+    names = []
+    for n_, p_ in cases.product_model(name).named_parameters():
+        names += [n_] * p_.numel()
+
+    def same(a, b):
+        if torch.equal(a, b):
+            return True
+        bad = sorted({names[i] for i in (a != b).nonzero().flatten().tolist()})
+        raise AssertionError('gradients differ in %d parameter tensors: %s' % (len(bad), bad[:12]))
+    graph, bn_g = run(True, True)
+    assert torch.isfinite(graph[0][1]).all() and graph[0][1].abs().max() > 0
+    for loss, grad in graph[1:]:
+        assert torch.equal(loss, graph[0][0]) and same(grad, graph[0][1])
+    eager, bn_e = run(False, True)
+    plain, bn_p = run(False, False)
+    for (la, ga), (lb, gb), (lc, gc) in zip(graph, eager, plain):
+        assert torch.equal(la, lb) and same(ga, gb)          # replayed == launched one by one
+        assert torch.equal(lb, lc) and same(gb, gc)          # postponed / carried == plain order
+    for a, b, c in zip(bn_g, bn_e, bn_p):
+        assert torch.equal(a, b) and torch.equal(b, c)
+
+
 def test_bf16_training_tracks_f32():
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import engine as E
@@ -451,6 +505,19 @@ def test_host_batch_pipeline_overlaps_h2d_and_decodes_uint8(use_graph):
         assert abs(got[0] / want[0] - 1) < 2e-5 and np.allclose(got, want, rtol=3e-3), (wire, got, want)
         with pytest.raises(RuntimeError):
             pipe.step()
+        if wire == 'u8_hwc':
+            # a pipeline re-created on the SAME trainer (a loader per epoch) must get slots of its own -- with
+            # recycled slot numbers the captured step of the old pipeline would decode the old staging buffers
+            slots_a = list(pipe.slots)
+            pipe.close()
+            assert all(s not in tr._graphs and s not in tr._statics for s in slots_a)
+            pipe2 = E.HostBatchPipeline(tr, ex, ey, wire='u8', mean=mean, std=std, image_hwc=True, device=DEV)
+            assert not set(pipe2.slots) & set(slots_a)
+            pipe2.put(*feed[1])
+            l2 = pipe2.step().item()
+            assert np.isfinite(l2)
+            with pytest.raises(RuntimeError):       # a slot's buffers are fixed: adopting other tensors must not pass silently
+                tr.static_batch(torch.empty_like(pipe2.decoded[0]), torch.empty_like(pipe2.decoded[1]), pipe2.slots[0], adopt=True)
     # the decode kernel itself, bit for bit against the same f32 formula (x * 1/(255 std) - mean/std)
     img, tgt = batches[0]
     out = torch.empty((B, 3, H, W), dtype=torch.float32, device=DEV)

@@ -240,7 +240,8 @@ def test_unsupported_shapes_fail_loudly():
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 5, 6, 4), 4)])
+@pytest.mark.parametrize('shape,scale', [((2, 19, 8, 16), 8), ((1, 19, 5, 7), 8), ((2, 5, 6, 4), 4), ((2, 19, 24, 72), 8),
+                                         ((1, 21, 40, 33), 8), ((3, 19, 70, 36), 2), ((1, 19, 9, 300), 1)])
 def test_fused_upsample_cross_entropy_matches_unfused(shape, scale, dtype):
     """Fused head+loss == cross_entropy(interpolate(low)) in value and gradient."""
     import torch_semantic_segmentation_amd as tssa
@@ -259,6 +260,25 @@ def test_fused_upsample_cross_entropy_matches_unfused(shape, scale, dtype):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert abs(la.item() / lb.item() - 1) < tol
     assert rel(a.grad, b.grad) < tol
+    # no atomics anywhere: a second evaluation is bit-identical, and no element of the (uninitialised) workspace that the
+    # backward gathers was left unwritten by the pass (NaN-filled workspace through the C ABI)
+    from torch_semantic_segmentation_amd import _native as N
+    a2 = a.detach().clone().requires_grad_(True)
+    la2 = tssa.upsample_cross_entropy(a2, target, scale_factor=scale, ignore_index=255)
+    (0.7 * la2).backward()
+    assert torch.equal(la, la2) and torch.equal(a.grad, a2.grad)
+    H, W = h * scale, w * scale
+    ws = torch.full((N.lib().tss_upsample_ce_ws(B, C, h, w, H, W),), float('nan'), device=DEV)
+    scal = torch.empty(2, device=DEV)
+    ad = ops.to_nhwc(a.detach())
+    N.call('tss_upsample_ce_fwd', N.ptr(ad), ad.stride(3), N.ptr(target), N.ptr(ws), N.ptr(scal[0:1]), N.ptr(scal[1:2]),
+           B, C, h, w, H, W, 255, N.dtype_code(ad.dtype), N.stream())
+    out = torch.full((B, h, w, ad.stride(3)), float('nan'), dtype=ad.dtype, device=DEV)
+    gout = torch.tensor([0.7], device=DEV)
+    N.call('tss_upsample_ce_bwd', N.ptr(ws), N.ptr(scal[1:2]), N.ptr(gout), N.ptr(out), ad.stride(3), B, C, h, w, H, W,
+           N.dtype_code(ad.dtype), N.stream())
+    assert torch.isfinite(out.float()).all() and torch.equal(out.permute(0, 3, 1, 2)[:, :C], a.grad)
+    assert (out[..., C:] == 0).all()
 
 
 @pytest.mark.parametrize('K,Nn,P', [(128, 128, 1000), (64, 384, 4096), (384, 64, 2500), (32, 48, 8192 + 37), (96, 576, 777),
@@ -279,7 +299,7 @@ def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
     def run(ws):
         dw = torch.zeros(Nn, K, device=DEV)
         N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
-               N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1, N.ptr(dw), N.ptr(ws), 0, P, K, Nn, 1, st)
+               N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1, N.ptr(dw), N.ptr(ws), 0, P, K, Nn, 1, None, st)
         return dw
 
     nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1)
@@ -292,6 +312,67 @@ def test_pw_weight_gradient_workspace_path_matches_atomics_and_f32(K, Nn, P):
     ref = g.t() @ a
     assert rel(d_ws, d_at) < 2e-5
     assert rel(d_ws, ref) < 5e-3
+
+
+@pytest.mark.parametrize('K,Nn,P,C2', [(128, 768, 16384, 768), (384, 64, 65536, 96), (64, 64, 300001, 8), (128, 128, 4000, 132)])
+def test_pw_weight_gradient_carries_a_finalize_and_its_reduce_rides_on_another_layer(K, Nn, P, C2):
+    """The backward-pass scheduling primitives through the C ABI: (1) tss_pwconv_bwd_weight(fin=job) == the stand-alone
+    tss_bn_bwd_finalize of that (other) layer + the plain weight gradient, bit for bit; (2) the slot reduction of that weight
+    gradient carried by the backward-data launch of a DIFFERENT 1x1 layer (wg_P, wg_K, wg_N) == tss_pwconv_wg_reduce."""
+    import ctypes
+    from torch_semantic_segmentation_amd import _native as N
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(11)
+    e = torch.randn(P, Nn, device=DEV).bfloat16(); y = torch.randn(P, Nn, device=DEV).bfloat16()
+    x = torch.randn(P, K, device=DEV).bfloat16()
+    ga, gb = torch.rand(Nn, device=DEV) + 0.5, torch.randn(Nn, device=DEV) * 0.3
+    gce, gmu = torch.randn(Nn, device=DEV) * 0.1, torch.randn(Nn, device=DEV) * 0.2
+    xm, xs, xb = torch.randn(K, device=DEV) * 0.2, torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    st, S = N.stream(), N.stat_slabs()
+    nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1)
+    assert nws > 0
+    gargs = (N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu))
+    xargs = (N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1)
+    # the other layer's BatchNorm-backward sums
+    bst = torch.randn(S, 2 * C2, dtype=torch.float64, device=DEV)
+    invstd, gamma = torch.rand(C2, device=DEV) + 0.5, torch.randn(C2, device=DEV)
+    count = 12345.0
+    # a third layer (K3 -> N3) whose backward-data launch carries the reduce
+    K3, N3, P3 = 64, 128, 5000
+    e3 = torch.randn(P3, N3, device=DEV).bfloat16(); y3 = torch.randn(P3, N3, device=DEV).bfloat16()
+    w3 = torch.randn(N3, K3, device=DEV) * 0.1
+    c3 = [torch.rand(N3, device=DEV) + 0.5, torch.randn(N3, device=DEV) * 0.3, torch.randn(N3, device=DEV) * 0.1, torch.randn(N3, device=DEV) * 0.2]
+
+    def run(ride):
+        dw = torch.zeros(Nn, K, device=DEV)
+        ws = torch.full((nws,), float('nan'), device=DEV)
+        outs = torch.full((5, C2), float('nan'), device=DEV)      # dgamma, dbeta, ga, gb, gce of the other layer
+        outs[0:2] = 1.0                                           # accumulate = 1: += onto existing gradients
+        job = ops.BnBwdJob(N.ptr(bst), count, N.ptr(invstd), N.ptr(gamma), 1, 1, N.ptr(outs[0]), N.ptr(outs[1]), N.ptr(outs[2]),
+                           N.ptr(outs[3]), N.ptr(outs[4]), C2)
+        ein = torch.empty(P3, K3, device=DEV, dtype=torch.bfloat16)
+        if ride:
+            N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), 1, P, K, Nn, 1, ctypes.byref(job), st)
+            N.call('tss_pwconv_bwd_data', N.ptr(e3), N3, N.ptr(y3), N3, *[N.ptr(c) for c in c3], N.ptr(w3), None,
+                   None, 0, None, None, None, 0, N.ptr(ein), K3, None, N.ptr(ws), N.ptr(dw), P, K, Nn, P3, K3, N3, 1, st)
+        else:
+            N.call('tss_bn_bwd_finalize', N.ptr(bst), count, N.ptr(invstd), N.ptr(gamma), 1, 1, N.ptr(outs[0]), N.ptr(outs[1]),
+                   N.ptr(outs[2]), N.ptr(outs[3]), N.ptr(outs[4]), C2, st)
+            N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), 1, P, K, Nn, 1, None, st)
+            N.call('tss_pwconv_wg_reduce', N.ptr(ws), N.ptr(dw), P, K, Nn, st)
+            N.call('tss_pwconv_bwd_data', N.ptr(e3), N3, N.ptr(y3), N3, *[N.ptr(c) for c in c3], N.ptr(w3), None,
+                   None, 0, None, None, None, 0, N.ptr(ein), K3, None, None, None, 0, 0, 0, P3, K3, N3, 1, st)
+        torch.cuda.synchronize()
+        return dw, outs, ein
+    a, b = run(True), run(False)
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    g = (ga * (e.float() - gce) + gb * (y.float() - gmu)).bfloat16().float()
+    act = torch.relu((x.float() - xm) * xs + xb).bfloat16().float()
+    assert rel(a[0], g.t() @ act) < 5e-3
+    se, sey = bst[:, :C2].sum(0), bst[:, C2:].sum(0)
+    assert rel(a[1][0] - 1.0, (invstd.double() * sey).float()) < 1e-5 and rel(a[1][1] - 1.0, se.float()) < 1e-5
 
 
 @pytest.mark.parametrize('K,Nn,P', [(384, 64, 40000), (576, 96, 16384), (768, 128, 30000), (64, 384, 40000), (96, 576, 16384),
@@ -321,7 +402,7 @@ def test_pointwise_lean_kernels_every_tile_size_vs_general_kernels(K, Nn, P):
             ein = torch.empty(P, K, device=DEV, dtype=torch.bfloat16)
             bst = torch.empty(S, 2 * K, dtype=torch.float64, device=DEV)
             N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), None,
-                   N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(bK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st)
+                   N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(bK), 1, N.ptr(ein), K, N.ptr(bst), None, None, 0, 0, 0, P, K, Nn, 1, st)
             torch.cuda.synchronize()
         finally:
             N.call('tss_set_option', 1, 0)
@@ -377,9 +458,9 @@ def test_pw_weight_gradient_reduce_carried_by_backward_data(K, Nn, P):
         ws = torch.full((nws,), float('nan'), device=DEV)
         gargs = (N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu))
         xargs = (N.ptr(x), K, N.ptr(xm), N.ptr(xs), N.ptr(xb), 1)
-        N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), defer, P, K, Nn, 1, st)
+        N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws), defer, P, K, Nn, 1, None, st)
         N.call('tss_pwconv_bwd_data', *gargs, N.ptr(w), None, *xargs, N.ptr(ein), K, N.ptr(bst),
-               N.ptr(ws) if defer else None, N.ptr(dw) if defer else None, P, K, Nn, 1, st)
+               N.ptr(ws) if defer else None, N.ptr(dw) if defer else None, 0, 0, 0, P, K, Nn, 1, st)
         return dw, ein.float(), bst.sum(0)
 
     a, b = run(0), run(1)
@@ -561,6 +642,63 @@ def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
             assert rel(g1[k], g0[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('classes,P_hw', [(19, (96, 160)), (21, (33, 47)), (8, (64, 64))])
+def test_classifier_conv_backward_in_one_sweep_with_bias_rows(classes, P_hw):
+    """VERDICT r02 #2d: the biased 128 -> classes conv of the classifiers (TSS/models/fastscnn.py:97) through the one-sweep
+    backward (csrc/pwbwd.hip, ragged Cout, bias gradient as per-block rows): against the general kernels of round 2
+    (convgemm + wgrad + colsum, f32 atomics) and against an f32 torch evaluation; deterministic; garbage in the pitch padding
+    of the incoming gradient is ignored."""
+    import importlib
+    import os
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    H, W = P_hw
+
+    def run(fused, poison=False):
+        torch.manual_seed(17)
+        m = nn.Sequential(F_.Conv2dBlock(16, 128, 1), F_.FusedSequential(nn.Conv2d(128, classes, 1))).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = torch.randn(2, 16, H, W, device=DEV).bfloat16()      # bf16 activations from the first layer on (no stem here)
+        old = os.environ.get('TSS_PW_BWD_FUSED')
+        os.environ['TSS_PW_BWD_FUSED'] = '2' if fused else '0'
+        try:
+            out = m(x)
+            cot = torch.randn(out.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+            if poison:      # a cotangent whose pitch padding holds NaN: must not reach the products
+                from torch_semantic_segmentation_amd import ops
+                g = ops.new_nhwc(*out.shape, torch.bfloat16, out.device)
+                base = torch.full((out.shape[0], H, W, (classes + 7) // 8 * 8), float('nan'), dtype=torch.bfloat16, device=DEV)
+                g = base.permute(0, 3, 1, 2)[:, :classes]
+                g.copy_(cot)
+                out.backward(g)
+            else:
+                out.backward(cot.to(out.dtype))
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                del os.environ['TSS_PW_BWD_FUSED']
+            else:
+                os.environ['TSS_PW_BWD_FUSED'] = old
+        hid = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv2d(x.float(), m[0][0].weight), None, None, m[0][1].weight, m[0][1].bias, True))
+        ref_dw = torch.einsum('bnhw,bkhw->nk', cot.bfloat16().float(), hid.bfloat16().float())
+        return {k: p.grad.float().clone() for k, p in m.named_parameters()}, ref_dw, cot.bfloat16().float().sum((0, 2, 3))
+    g1, ref_dw, ref_db = run(True)
+    g1b, _, _ = run(True)
+    g0, _, _ = run(False)
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        assert torch.equal(g1[k], g1b[k]), k                     # no atomics on this path
+        assert rel(g1[k], g0[k]) < 1e-2, k
+    assert rel(g1['1.0.weight'].reshape(classes, 128), ref_dw) < 1e-2
+    assert rel(g1['1.0.bias'], ref_db) < 1e-5
+    if classes % 8:
+        gp, _, _ = run(True, poison=True)
+        for k in g1:
+            assert torch.equal(gp[k], g1[k]), k
+
+
 @pytest.mark.parametrize('chans', [(32, 48, 64), (24, 128, 128), (8, 8, 8), (64, 128, 40), (128, 64, 128)])
 @pytest.mark.parametrize('pending', [True, False])
 def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
@@ -581,7 +719,7 @@ def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
         m = nn.Sequential(*layers).to(DEV)
         tssa.set_compute_dtype(m, torch.bfloat16)
         m.train()
-        x = torch.randn(3, c0, 37, 53, device=DEV).requires_grad_(True)
+        x = torch.randn(3, c0, 37, 53, device=DEV).bfloat16().requires_grad_(True)    # bf16 activations: the lean kernels
         old = os.environ.get('TSS_PW_BWD_FUSED')
         os.environ['TSS_PW_BWD_FUSED'] = '2' if fused else '0'       # 2: every layer inside the envelope, whatever its pixel count
         try:

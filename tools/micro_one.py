@@ -19,8 +19,8 @@ nws = N.lib().tss_pwconv_bwd_weight_ws(P, K, Nn, 1) if which == 'wgrad' else 0
 wsw = torch.empty(nws, device=dev) if nws and os.environ.get('TSS_WG_ATOMIC') != '1' else None
 fns = {
  'pwfwd': lambda: N.call('tss_pwconv_fwd', N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(w), None, None, N.ptr(y), Nn, N.ptr(stats), P, K, Nn, 1, st),
- 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), None, N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, P, K, Nn, 1, st),
- 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), 0, P, K, Nn, 1, st),
+ 'pwbwd': lambda: N.call('tss_pwconv_bwd_data', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(w), None, N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(ein), K, N.ptr(bst), None, None, 0, 0, 0, P, K, Nn, 1, st),
+ 'wgrad': lambda: N.call('tss_pwconv_bwd_weight', N.ptr(e), Nn, N.ptr(y), Nn, N.ptr(sN), N.ptr(sN), N.ptr(mN), N.ptr(mN), N.ptr(x), K, N.ptr(mK), N.ptr(sK), N.ptr(mK), 1, N.ptr(dw), N.ptr(wsw), 0, P, K, Nn, 1, None, st),
 }
 if which in ('dwfwd', 'dwbwd', 'dwwg'):
     C, B, H, W = K, 8, Nn, P
@@ -36,9 +36,9 @@ if which == 'ceup':
     B, C, h, w, sc = 8, K, Nn, P, 8
     low = ops.new_nhwc(B, C, h, w, torch.bfloat16, dev); low.normal_()
     tgt = torch.randint(0, C, (B, h * sc, w * sc), device=dev)
-    dacc = torch.zeros((B, h, w, low.stride(3)), dtype=torch.float32, device=dev)
-    acc = torch.zeros(2, dtype=torch.float64, device=dev); scal = torch.empty(2, dtype=torch.float32, device=dev)
-    fns['ceup'] = lambda: N.call('tss_upsample_ce_fwd', N.ptr(low), low.stride(3), N.ptr(tgt), N.ptr(dacc), N.ptr(acc), N.ptr(scal[0:1]), N.ptr(scal[1:2]), B, C, h, w, h * sc, w * sc, 255, 1, st)
+    ws = torch.empty(N.lib().tss_upsample_ce_ws(B, C, h, w, h * sc, w * sc), dtype=torch.float32, device=dev)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    fns['ceup'] = lambda: N.call('tss_upsample_ce_fwd', N.ptr(low), low.stride(3), N.ptr(tgt), N.ptr(ws), N.ptr(scal[0:1]), N.ptr(scal[1:2]), B, C, h, w, h * sc, w * sc, 255, 1, st)
 for _ in range(10):
     fns[which]()
 torch.cuda.synchronize()

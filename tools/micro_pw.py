@@ -38,15 +38,15 @@ for (B, H, W, Cin, Cout) in ((8, 256, 512, 32, 48), (8, 128, 256, 48, 64), (8, 1
     def fused():
         for e, y, x, ei in zip(es, ys, xs, eins):
             N.call('tss_pwconv_bwd_fused', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), N.ptr(wT),
-                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, 1, N.ptr(ei), Cin, N.ptr(bst), N.ptr(wsf), P, Cin, Cout, N.TSS_BF16, st)
+                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, 1, N.ptr(ei), Cin, N.ptr(bst), N.ptr(wsf), None, P, Cin, Cout, N.TSS_BF16, st)
             ops._reduce_rows_now(wsf, dw, Cout * Cin, rows)
     def pair():
         for e, y, x, ei in zip(es, ys, xs, eins):
             N.call('tss_pwconv_bwd_weight', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu),
-                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(dw), N.ptr(wsp) if nws else None, 1 if nws else 0, P, Cin, Cout, N.TSS_BF16, st)
+                   N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(dw), N.ptr(wsp) if nws else None, 1 if nws else 0, P, Cin, Cout, N.TSS_BF16, None, st)
             N.call('tss_pwconv_bwd_data', N.ptr(e), Cout, N.ptr(y), Cout, N.ptr(ga), N.ptr(gb), N.ptr(gce), N.ptr(gmu), N.ptr(w), N.ptr(wT),
                    N.ptr(x), Cin, N.ptr(mean), N.ptr(sc), N.ptr(bias), 1, N.ptr(ei), Cin, N.ptr(bst),
-                   N.ptr(wsp) if nws else None, N.ptr(dw) if nws else None, P, Cin, Cout, N.TSS_BF16, st)
+                   N.ptr(wsp) if nws else None, N.ptr(dw) if nws else None, 0, 0, 0, P, Cin, Cout, N.TSS_BF16, st)
     rl = lambda a, b: ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
     dw.zero_(); pair(); torch.cuda.synchronize()
     ei0, dw0, st0 = eins[0].float().clone(), dw.clone(), bst.sum(0)

@@ -507,7 +507,7 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
+                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw, long red_P, int red_K, int red_N,
                          long P, int K, int N, hipStream_t stream, const void* radd = nullptr, long ldr = 0);  // pwfast.hip
 void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream);  // wgrad.hip
 bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
@@ -539,11 +539,13 @@ int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
 int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw,
+                        void* e_in, long ldei, double* bstats, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
                         long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldei % 4) == 0 && ldei >= K,
               TSS_ERR_SHAPE);
+  if (wg_P <= 0) { wg_P = P; wg_K = K; wg_N = N; }      // the slots of this layer's own weight gradient
+  TSS_REQUIRE(!(wg_ws && wg_dw) || (wg_K > 0 && wg_N > 0 && (wg_K % 8) == 0 && (wg_N % 8) == 0), TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8), TSS_ERR_SHAPE);
   TSS_REQUIRE(!xraw || ((ldx % 4) == 0 && ldx >= K), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
@@ -560,10 +562,10 @@ int tss_pwconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && N <= 768 && (N % 8) == 0 && (K % 4) == 0) {
     tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
     if (tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, wT_bf16, xraw, ldx, in_mean, in_scale, in_bias, in_relu,
-                            e_in, ldei, bstats, wg_ws, wg_dw, P, K, N, (hipStream_t)stream))
+                            e_in, ldei, bstats, wg_ws, wg_dw, wg_P, wg_K, wg_N, P, K, N, (hipStream_t)stream))
       return tss::check_last("pwfast_bwd_data");
   }
-  if (wg_ws && wg_dw) tss_wg_reduce_standalone(wg_ws, wg_dw, P, K, N, (hipStream_t)stream);   // nobody else will
+  if (wg_ws && wg_dw) tss_wg_reduce_standalone(wg_ws, wg_dw, wg_P, wg_K, wg_N, (hipStream_t)stream);   // nobody else will
   return launch(g, dtype, TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes);
 }
 
@@ -576,15 +578,17 @@ int tss_pwconv_bwd_data_radd_supported(long P, int K, int N, int dtype) {
 
 int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
-                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, const void* radd, long ldr,
-                             long P, int K, int N, int dtype, void* stream) {
+                             void* e_in, long ldei, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
+                             const void* radd, long ldr, long P, int K, int N, int dtype, void* stream) {
   TSS_REQUIRE(tss_pwconv_bwd_data_radd_supported(P, K, N, dtype) && yraw && radd, TSS_ERR_SHAPE);
+  if (wg_P <= 0) { wg_P = P; wg_K = K; wg_N = N; }
+  TSS_REQUIRE(!(wg_ws && wg_dw) || (wg_K > 0 && wg_N > 0 && (wg_K % 8) == 0 && (wg_N % 8) == 0), TSS_ERR_SHAPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= N && (ldyr % 8) == 0 && ldyr >= N && (ldei % 4) == 0 && ldei >= K && (ldr % 4) == 0 && ldr >= K, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(w) && ((uintptr_t)radd & 7u) == 0, TSS_ERR_ALIGN);
   const double bytes = (double)P * (N * 2 + K * 2) * 2.0;
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
   if (!tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, wT_bf16, nullptr, 0, nullptr, nullptr, nullptr, 0,
-                           e_in, ldei, nullptr, wg_ws, wg_dw, P, K, N, (hipStream_t)stream, radd, ldr))
+                           e_in, ldei, nullptr, wg_ws, wg_dw, wg_P, wg_K, wg_N, P, K, N, (hipStream_t)stream, radd, ldr))
     return TSS_ERR_SHAPE;
   return tss::check_last("pwfast_bwd_data_radd");
 }

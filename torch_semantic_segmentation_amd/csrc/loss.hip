@@ -105,10 +105,19 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
 //   gA[c] += l0y*dz_c, gB[c] += l1y*dz_c and only when the row tap advances is a finished low-res row gathered
 //   horizontally through LDS (one thread per low-res cell and class) and added to the f32 gradient (global atomics:
 //   ~650 per 8 output rows of a block, each address touched by <= 4 blocks).
+// Run-to-run determinism: a low-res cell receives contributions from up to four blocks (two bands x two strips).  Each
+// block therefore stores ITS contribution to every (row, cell, class) of its footprint into a tile of its own (plain
+// stores, every element of the footprint written exactly once, nothing zero-filled), its loss / count partial into a row
+// of its own, and the backward kernel gathers the <= 4 tiles of a cell in a fixed order.  (Round 2 added them with f32
+// global atomics into a zero-filled buffer: last-bit differences from run to run that a train step amplifies.)
+//   ws = [nblocks][2] f64 loss rows, then [nblocks][tile_rows][tile_cells][CP] f32 tiles; block = (b * nband + band) * nstrip + strip
+struct CeGeom { int nstrip, nband, band_rows, tile_rows, tile_cells; };
+
 template <typename T, int CP>
 __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
-                                                                 float* dlow, double* acc, int B, int C, int h, int w,
-                                                                 int H, int W, int ignore_index, int band_rows) {
+                                                                 float* tiles, double* lossrows, int B, int C, int h, int w,
+                                                                 int H, int W, int ignore_index, const CeGeom geo) {
+  const int band_rows = geo.band_rows;
   constexpr int MAXCELL = NT + 2, WTAB = 1024;
   constexpr float LOG2E = 1.44269504088896340736f;
   // Hh[k][lane][c]: the one-hot half of the gradient, sum over the rows seen so far of (row weight) * [target == c], kept
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
   __shared__ float Wt[WTAB];                          // gather weights [cell][lane - Wlo[cell]] (fixed for the block)
   __shared__ double red[2][NT / 64];
   const int tid = threadIdx.x;
-  const int nstrip = (W + NT - 1) / NT, nband = (H + band_rows - 1) / band_rows;
+  const int nstrip = geo.nstrip, nband = geo.nband;
+  float* const tile = tiles + (long)blockIdx.x * geo.tile_rows * geo.tile_cells * CP;
   int bid = blockIdx.x;
   const int strip = bid % nstrip; bid /= nstrip;
   const int band = bid % nband;
@@ -168,6 +178,9 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
     }
   }
 
+  int rA = ac_tap(sy, ya, h).i0;
+  int rB = rA + (rA < h - 1 ? 1 : 0);
+  const int r_first = rA;
   float aA[CP], aB[CP], gA[CP], gB[CP];
   auto load_row = [&](int r, float* a) {   // a[c] = l0x * L[r][i0x][c] + l1x * L[r][i1x][c]
     const T* p0 = low + ((b * h + r) * (long)w + tx.i0) * ldl;
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
     }
     lsum -= zt;
     __syncthreads();
-    float* drow = dlow + ((b * h + r) * (long)w + cx0) * ldl;
+    float* drow = tile + (long)(r - r_first) * geo.tile_cells * CP;
     for (int i = tid; i < ncell * CP; i += NT) {
       const int cell = i / CP, c = i - cell * CP;
       const int llo = Wlo[cell], lhi = Whi[cell];
@@ -214,16 +227,14 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
           sum += wgt * G[l * CP + c];
         }
       }
-      if (c < C && sum != 0.f) atomicAdd(drow + (long)cell * ldl + c, sum);
+      drow[i] = sum;                       // [cell][c]: every element of the block's footprint, exactly once
     }
     __syncthreads();
 #pragma unroll
     for (int c4 = 0; c4 < CP; c4 += 4) *reinterpret_cast<float4*>(G + tid * CP + c4) = make_float4(0.f, 0.f, 0.f, 0.f);
   };
 
-  int rA = ac_tap(sy, ya, h).i0;
-  int rB = rA + (rA < h - 1 ? 1 : 0);
-  int kA = 0;                                  // Hh[kA] belongs to row rA, Hh[kA ^ 1] to row rB
+ int kA = 0;                                  // Hh[kA] belongs to row rA, Hh[kA ^ 1] to row rB
   load_row(rA, aA);
   load_row(rB, aB);
 #pragma unroll
@@ -287,22 +298,81 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
   if (tid == 0) {
     double a = 0.0, c = 0.0;
     for (int wv = 0; wv < NT / 64; ++wv) { a += red[0][wv]; c += red[1][wv]; }
-    atomicAdd(acc, a);
-    atomicAdd(acc + 1, c);
+    lossrows[2 * (long)blockIdx.x] = a;
+    lossrows[2 * (long)blockIdx.x + 1] = c;
   }
 }
 
-// dlow = (T)(dlow_acc * grad_out / count), 8 elements per lane
-template <typename T>
-__global__ __launch_bounds__(NT) void upsample_ce_scale_kernel(const float* dacc, const float* inv_count,
-                                                               const float* grad_out, T* dlow, long n8) {
+// loss = sum(rows[.][0]) / sum(rows[.][1]) in a fixed order (one block; thread t takes rows t, t + NT, ...)
+__global__ __launch_bounds__(NT) void ce_finalize_rows_kernel(const double* rows, int nrows, float* loss, float* inv_count) {
+  __shared__ double red[2][NT];
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nrows; i += NT) { a += rows[2 * (long)i]; c += rows[2 * (long)i + 1]; }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = c;
+  __syncthreads();
+  for (int s = NT / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) { red[0][threadIdx.x] += red[0][threadIdx.x + s]; red[1][threadIdx.x] += red[1][threadIdx.x + s]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double n = red[1][0];
+    *loss = (float)(red[0][0] / n);          // n == 0 -> nan, like torch
+    *inv_count = n > 0.0 ? (float)(1.0 / n) : 0.f;
+  }
+}
+
+// first / last low-res row a band's block wrote, first cell / cell count of a strip: the same expressions as in the pass
+__device__ __forceinline__ void ce_band_rows(float sy, int band, int band_rows, int H, int h, int* r0, int* r1) {
+  const int ya = band * band_rows;
+  const int yb = ya + band_rows < H ? ya + band_rows : H;
+  *r0 = ac_tap(sy, ya, h).i0;
+  *r1 = ac_tap(sy, yb - 1, h).i1;
+}
+__device__ __forceinline__ void ce_strip_cells(float sx, int strip, int W, int w, int* c0, int* n) {
+  const int xl = (strip * NT + NT - 1 < W) ? strip * NT + NT - 1 : W - 1;
+  *c0 = ac_tap(sx, strip * NT, w).i0;
+  *n = ac_tap(sx, xl, w).i1 - *c0 + 1;
+}
+
+// dlow[b][r][cx][:] = (T)(grad_out / count * sum over the tiles that hold cell (r, cx), in (band, strip) order); thread = one
+// cell x 8 channels.  Channels >= CP (pitch padding) are written as zeros.
+template <typename T, int CP>
+__global__ __launch_bounds__(NT) void upsample_ce_gather_kernel(const float* tiles, const float* inv_count, const float* grad_out,
+                                                                T* dlow, long ldl, int B, int h, int w, int H, int W,
+                                                                const CeGeom geo) {
   const float gs = (*inv_count) * (grad_out ? *grad_out : 1.f);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+  const float sy = ac_scale(h, H), sx = ac_scale(w, W);
+  const int cv = (int)(ldl / 8);
+  const long total = (long)B * h * w * cv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = (int)(i % cv) * 8;
+    long q = i / cv;
+    const int cx = (int)(q % w); q /= w;
+    const int r = (int)(q % h);
+    const long b = q / h;
     float v[8];
-    V8<float>::load(dacc + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    int ylo, yhi, xlo, xhi;
+    ac_window(sy, r, H, &ylo, &yhi);
+    ac_window(sx, cx, W, &xlo, &xhi);
+    for (int band = ylo / geo.band_rows; band <= yhi / geo.band_rows; ++band) {
+      int r0, r1;
+      ce_band_rows(sy, band, geo.band_rows, H, h, &r0, &r1);
+      if (r < r0 || r > r1) continue;
+      for (int strip = xlo / NT; strip <= xhi / NT; ++strip) {
+        int c0, n;
+        ce_strip_cells(sx, strip, W, w, &c0, &n);
+        if (cx < c0 || cx >= c0 + n) continue;
+        const float* t = tiles + ((((b * geo.nband + band) * geo.nstrip + strip) * geo.tile_rows + (r - r0)) * (long)geo.tile_cells
+                                  + (cx - c0)) * CP + c8;
+        if (c8 + 4 <= CP) { float u[4]; V4<float>::load(t, u); v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3]; }
+        if (c8 + 8 <= CP) { float u[4]; V4<float>::load(t + 4, u); v[4] += u[0]; v[5] += u[1]; v[6] += u[2]; v[7] += u[3]; }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= gs;
-    V8<T>::store(dlow + i * 8, v);
+    V8<T>::store(dlow + ((b * h + r) * (long)w + cx) * ldl + c8, v);
   }
 }
 
@@ -510,45 +580,73 @@ int tss_upsample_argmax_confusion(const void* low, long ldl, const long long* ta
   return tss::check_last("upsample_argmax_confusion");
 }
 
-int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* dlow_acc /*[B][h][w][ldl] f32, zeroed*/,
-                        double* acc /*[2], zeroed*/, float* loss, float* inv_count,
+// Geometry of the pass (the same on the host, in the pass and in the gather): bands / strips and the tile every block owns.
+static CeGeom ce_geom(int B, int h, int w, int H, int W) {
+  CeGeom g;
+  g.nstrip = (W + NT - 1) / NT;
+  // bands: enough blocks to fill the chip, but every band pays two extra row flushes
+  g.band_rows = 64;
+  while (g.band_rows > 16 && (long)B * g.nstrip * ((H + g.band_rows - 1) / g.band_rows) < 2048) g.band_rows /= 2;
+  g.nband = (H + g.band_rows - 1) / g.band_rows;
+  // conservative tile extent: a band of R output rows touches at most floor((R - 1) * (h - 1) / (H - 1)) + 3 low-res rows
+  // (the pass and the gather index the tile by the rows / cells actually touched, which they both compute exactly)
+  const double sy = H > 1 ? (double)(h - 1) / (double)(H - 1) : 0.0, sx = W > 1 ? (double)(w - 1) / (double)(W - 1) : 0.0;
+  g.tile_rows = (int)((g.band_rows - 1) * sy) + 3;
+  g.tile_cells = (int)((NT - 1) * sx) + 3;
+  if (g.tile_rows > h) g.tile_rows = h;
+  if (g.tile_cells > w) g.tile_cells = w;
+  return g;
+}
+
+long tss_upsample_ce_ws(int B, int C, int h, int w, int H, int W) {
+  if (B <= 0 || C <= 0 || C > 24 || h <= 0 || w <= 0 || H < h || W < w) return 0;
+  const CeGeom g = ce_geom(B, h, w, H, W);
+  const long nblocks = (long)B * g.nband * g.nstrip;
+  const int CP = C <= 20 ? 20 : 24;
+  return nblocks * 4 /* 2 doubles */ + nblocks * g.tile_rows * g.tile_cells * CP;
+}
+
+int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, float* ws /* tss_upsample_ce_ws floats, not initialised */,
+                        float* loss, float* inv_count,
                         int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(low) && tss::aligned16(dlow_acc), TSS_ERR_ALIGN);
+  TSS_REQUIRE(tss::aligned16(low) && tss::aligned16(ws), TSS_ERR_ALIGN);
   if ((long)B * H * W == 0) return TSS_OK;
+  const CeGeom geo = ce_geom(B, h, w, H, W);
+  const long grid = (long)B * geo.nstrip * geo.nband;
+  double* lossrows = reinterpret_cast<double*>(ws);
+  float* tiles = ws + grid * 4;
   {
-    // bands: enough blocks to fill the chip, but every band pays two extra row flushes
-    const int nstrip = (W + NT - 1) / NT;
-    int band_rows = 64;
-    while (band_rows > 16 && (long)B * nstrip * ((H + band_rows - 1) / band_rows) < 2048) band_rows /= 2;
-    const long grid = (long)B * nstrip * ((H + band_rows - 1) / band_rows);
     tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream,
                         (double)B * h * w * C * (esz(dtype) + 8.0) + (double)B * H * W * 8.0, 0);
 #define TSS_CE_LAUNCH(TT, CPV)                                                                                   \
     hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, \
-                       (const TT*)low, ldl, target, dlow_acc, acc, B, C, h, w, H, W, ignore_index, band_rows)
+                       (const TT*)low, ldl, target, tiles, lossrows, B, C, h, w, H, W, ignore_index, geo)
     if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_LAUNCH(bf16_t, 20); else TSS_CE_LAUNCH(bf16_t, 24); }
     else { if (C <= 20) TSS_CE_LAUNCH(float, 20); else TSS_CE_LAUNCH(float, 24); }
 #undef TSS_CE_LAUNCH
   }
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc, loss, inv_count);
+  hipLaunchKernelGGL(ce_finalize_rows_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, lossrows, (int)grid, loss, inv_count);
   return tss::check_last("upsample_ce_fwd");
 }
 
-int tss_upsample_ce_bwd(const float* dlow_acc, const float* inv_count, const float* grad_out, void* dlow,
-                        long n /* = B*h*w*ldl */, int dtype, void* stream) {
+int tss_upsample_ce_bwd(const float* ws, const float* inv_count, const float* grad_out, void* dlow, long ldl,
+                        int B, int C, int h, int w, int H, int W, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
-  TSS_REQUIRE(n >= 0 && (n % 8) == 0, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(dlow_acc) && tss::aligned16(dlow), TSS_ERR_ALIGN);
+  TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(ws) && tss::aligned16(dlow), TSS_ERR_ALIGN);
+  const long n = (long)B * h * w * ldl;
   if (n == 0) return TSS_OK;
+  const CeGeom geo = ce_geom(B, h, w, H, W);
+  const float* tiles = ws + (long)B * geo.nstrip * geo.nband * 4;
   tss::ProfScope prof(TSS_K_UPSAMPLE_CE_BWD, (hipStream_t)stream, (double)n * (4.0 + esz(dtype)), 0);
-  if (dtype == TSS_BF16)
-    hipLaunchKernelGGL(upsample_ce_scale_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(NT), 0, (hipStream_t)stream,
-                       dlow_acc, inv_count, grad_out, (bf16_t*)dlow, n / 8);
-  else
-    hipLaunchKernelGGL(upsample_ce_scale_kernel<float>, dim3(grid_for(n / 8)), dim3(NT), 0, (hipStream_t)stream,
-                       dlow_acc, inv_count, grad_out, (float*)dlow, n / 8);
+#define TSS_CE_GATHER(TT, CPV)                                                                                      \
+  hipLaunchKernelGGL((upsample_ce_gather_kernel<TT, CPV>), dim3(grid_for(n / 8)), dim3(NT), 0, (hipStream_t)stream, \
+                     tiles, inv_count, grad_out, (TT*)dlow, ldl, B, h, w, H, W, geo)
+  if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_GATHER(bf16_t, 20); else TSS_CE_GATHER(bf16_t, 24); }
+  else { if (C <= 20) TSS_CE_GATHER(float, 20); else TSS_CE_GATHER(float, 24); }
+#undef TSS_CE_GATHER
   return tss::check_last("upsample_ce_bwd");
 }
 

@@ -6,51 +6,13 @@
 //     re-layout, fused flat AdamW
 #include <cstdlib>
 #include "common.h"
+#include "bnfin.h"
 
 namespace {
 
 constexpr int NT = 256;
 
-// ------------------------------------------------------------------------------------------ BN
-// Column sums over the TSS_STAT_SLABS partial rows for a group of FIN_CH channels per block.  A wave's 64 lanes are
-// FIN_RG row groups x 2 columns (sum, second moment) x FIN_CH channels: every load instruction reads 2 x FIN_RG contiguous
-// 64-byte segments; the 16 waves take interleaved rows (8 loads per lane, all in flight at once) and meet in LDS.
-// History: one wave per channel with lanes along the ROWS (64 different cache lines per instruction): 8-10 us per finalize
-// x 88 launches per step; 32 channels per block: 6.4 us -- each block still streamed 262 KB through ONE CU, and a layer
-// has only C/32 = 2..24 such blocks; 8 channels per block: 65 KB per block, four times as many CUs pulling: 5.35 us
-// (4 channels per block, 32-byte segments: 6.5 us).
-constexpr int FIN_CH = 8, FIN_RG = 4, FIN_WAVES = 4, FIN_NT = FIN_WAVES * 64;
-static_assert(2 * FIN_CH * FIN_RG == 64, "one wave = row groups x 2 columns x channels");
-__device__ __forceinline__ void slab_sum(const double* slabs, int C, double* s0, double* s1, int* c_out) {
-  __shared__ double red[FIN_WAVES][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cl = lane & (FIN_CH - 1), hs = (lane / FIN_CH) & 1, rg = lane / (2 * FIN_CH);
-  const int c = blockIdx.x * FIN_CH + cl;
-  const bool in = c < C;
-  const double* col = slabs + (long)hs * C + (in ? c : 0);
-  constexpr int RSTEP = FIN_WAVES * FIN_RG;        // rows covered by one load instruction of the block
-  constexpr int R = TSS_STAT_SLABS / RSTEP;        // loads per lane
-  static_assert(TSS_STAT_SLABS % RSTEP == 0, "slab rows must divide evenly");
-  double acc = 0.0;
-  double v[R];   // all loads of the lane in flight: one memory round trip per finalize
-#pragma unroll
-  for (int u = 0; u < R; ++u) v[u] = col[(long)(wave * FIN_RG + rg + RSTEP * u) * 2 * C];
-#pragma unroll
-  for (int u = 0; u < R; ++u) acc += v[u];
-  red[wave][lane] = in ? acc : 0.0;
-  __syncthreads();
-  double a = 0.0, b = 0.0;
-  if (threadIdx.x < FIN_CH) {
-#pragma unroll
-    for (int w = 0; w < FIN_WAVES; ++w)
-#pragma unroll
-      for (int q = 0; q < FIN_RG; ++q) {
-        a += red[w][q * 2 * FIN_CH + threadIdx.x];
-        b += red[w][q * 2 * FIN_CH + FIN_CH + threadIdx.x];
-      }
-  }
-  *s0 = a; *s1 = b; *c_out = blockIdx.x * FIN_CH + threadIdx.x;   // valid for threadIdx.x < FIN_CH
-}
+using namespace tss_fin;
 
 __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums, double count, const float* gamma,
                                    float eps, float momentum, float* running_mean, float* running_var,
@@ -65,7 +27,7 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums,
   const float rv_in = (running_var ? running_var : mean_out)[cp];
   double ssum, ssq;
   int c;
-  slab_sum(sums, C, &ssum, &ssq, &c);
+  slab_sum(sums, C, blockIdx.x, &ssum, &ssq, &c);
   if (threadIdx.x >= FIN_CH || c >= C) return;
   const double mean = ssum / count;
   double var = ssq / count - mean * mean;
@@ -91,7 +53,7 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_kernel(const double* sums,
 __global__ __launch_bounds__(FIN_NT) void slab_reduce_kernel(const double* slabs, double count, double* out, int C) {
   double s0, s1;
   int c;
-  slab_sum(slabs, C, &s0, &s1, &c);
+  slab_sum(slabs, C, blockIdx.x, &s0, &s1, &c);
   if (blockIdx.x == 0 && threadIdx.x == 0) out[2 * C] = count;
   if (threadIdx.x >= FIN_CH || c >= C) return;
   out[c] = s0;
@@ -126,7 +88,7 @@ __global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_sync_kernel(const doub
                                                                       float* gce, int C) {
   double se, sey;
   int c;
-  slab_sum(bstats, C, &se, &sey, &c);           // this replica's sums: parameter gradients
+  slab_sum(bstats, C, blockIdx.x, &se, &sey, &c);           // this replica's sums: parameter gradients
   if (threadIdx.x >= FIN_CH || c >= C) return;
   const double r = invstd[c];
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)(r * sey);
@@ -169,37 +131,7 @@ __global__ __launch_bounds__(128) void bn_eval_affine_batched_kernel(const long 
   out[2 * C + c] = (gamma ? g : 1.f) * invstd;
 }
 
-// bstats = [sum(e), sum(e*(y-mean))] over the N = count elements of each channel (centred: no cancellation).
-// training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
-//           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
-// frozen  : g = k*e
-__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const double* bstats, double count, const float* invstd,
-                                       const float* gamma, int training, int accumulate,
-                                       float* dgamma, float* dbeta, float* ga, float* gb, float* gce, int C) {
-  const int cp = min(blockIdx.x * FIN_CH + (int)(threadIdx.x & (FIN_CH - 1)), C - 1);
-  const float r_in = invstd[cp];                       // requested ahead of the slab rows, as in bn_finalize_kernel
-  const float g_in = (gamma ? gamma : invstd)[cp];
-  const float dg_in = (dgamma ? dgamma : invstd)[cp];
-  const float db_in = (dbeta ? dbeta : invstd)[cp];
-  double se, sey;
-  int c;
-  slab_sum(bstats, C, &se, &sey, &c);
-  if (threadIdx.x >= FIN_CH || c >= C) return;
-  const double r = r_in;
-  const double dg = r * sey;
-  const double db = se;
-  if (dgamma) dgamma[c] = (accumulate ? dg_in : 0.f) + (float)dg;
-  if (dbeta) dbeta[c] = (accumulate ? db_in : 0.f) + (float)db;
-  const double k = (gamma ? (double)g_in : 1.0) * r;
-  if (training) {
-    const double c1 = db / count, c2 = dg / count;
-    ga[c] = (float)k;
-    gb[c] = (float)(-k * c2 * r);
-    gce[c] = (float)c1;
-  } else {
-    ga[c] = (float)k; gb[c] = 0.f; gce[c] = 0.f;
-  }
-}
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_kernel(const tss_bn_bwd_job j) { bn_bwd_finalize_block(j, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------ join
 struct JoinArgs {
@@ -635,8 +567,8 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         float* ga, float* gb, float* gce, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_NT), 0, (hipStream_t)stream, bstats, count,
-                     invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C);
+  const tss_bn_bwd_job j = {bstats, count, invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C};
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_NT), 0, (hipStream_t)stream, j);
   return tss::check_last("bn_bwd_finalize");
 }
 

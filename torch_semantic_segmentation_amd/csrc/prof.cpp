@@ -31,7 +31,7 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     {"adaptive_pool_fwd", "adaptive_pool_fwd_kernel|ppm_pool_fwd_kernel"}, {"adaptive_pool_bwd", "adaptive_pool_bwd_kernel|ppm_pool_bwd_kernel"},
     {"copy_nhwc", "copy_nhwc_kernel"},
     {"cross_entropy_fwd", "ce_fwd_kernel"}, {"cross_entropy_bwd", "ce_bwd_kernel"}, {"argmax_confusion", "argmax_confusion_kernel"},
-    {"upsample_ce_fwd", "upsample_ce_onepass_kernel"}, {"upsample_ce_bwd", "upsample_ce_scale_kernel"},
+    {"upsample_ce_fwd", "upsample_ce_onepass_kernel"}, {"upsample_ce_bwd", "upsample_ce_gather_kernel"},
 };
 
 struct Rec { int kid; hipEvent_t a, b; double bytes, flops; };

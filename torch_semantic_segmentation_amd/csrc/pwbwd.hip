@@ -26,6 +26,7 @@ struct PbArgs {
   const T* wT; long ldwT;                   // optional bf16 shadow of the transpose, [KC][NC]
   const T* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_pending;
   T* ein; long ldei; double* stats; float* ws; int gslots;
+  float* bias_ws;                           // optional [rows][NC]: per-block partial sums of g over the pixels (bias gradient)
 };
 
 __device__ __forceinline__ float blo(uint32_t u) { return __uint_as_float(u << 16); }
@@ -35,6 +36,8 @@ __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0x
 // NFW = 16-channel fragments of Cout whose weight-gradient rows a wave owns (fragments w, w + NW, ...).  Two instances:
 // NSPLIT = 2: the waves pair up over the input-channel fragments of the input gradient (half of FKM each, twice the pixels).
 //   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <256, 64, 4, 2, 1>: Cin <= 64, Cout <= 128, two blocks per CU;
+//   <256, 64, 8, 1, 1>: Cin <= 128, Cout <= 64 (the 19-class classifier conv: Cout need not be a multiple of 8 -- e / y are read
+//   through their pitch, channels >= Cout are zeroed here, the weight-gradient row keeps the parameter's [Cout][Cin] shape);
 //   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU (opt-in: it loses to the two separate kernels)
 // TR: no pixel-major image of g at all -- the input-gradient product reads its g operand out of the channel-major image Gt with
 // the transposing LDS read of gfx950 (ds_read_b64_tr_b16: a group of 16 lanes reads a 4-row x 16-column block and lane i receives
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   if (t_end > ntiles) t_end = ntiles;
 
   // ---- staging units of this thread: 4 pixels x 8 channels of (e, y) and of x
-  const int nvG = NC >> 3, nvA = KC >> 3;
+  const int nvG = (NC + 7) >> 3, nvA = KC >> 3;
   const int pgG = tid / nvG, cvG = tid - pgG * nvG;
   const int pgA = tid / nvA, cvA = tid - pgA * nvA;
   const bool onG = pgG < NPG, onA = pgA < NPG;
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   for (int u = 0; u < NFW; ++u)
 #pragma unroll
     for (int j = 0; j < FKM; ++j) dw[u][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // bias gradient: this thread's 8 channels of g over its pixels
   float st1[FKW][4], st2[FKW][4];
 #pragma unroll
   for (int i = 0; i < FKW; ++i)
@@ -198,7 +202,15 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
         }
+        if (cvG * 8 + 8 > NC) {                   // ragged Cout: whatever sits in the pitch padding of e / y must not reach the products
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (cvG * 8 + j >= NC) v[i][j] = 0.f;
+        }
         if (!TR) V8<T>::store(Xs + (pgG * 4 + i) * RSX + cvG * 8, v[i]);
+      }
+      if (g.bias_ws) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += (v[0][j] + v[1][j]) + (v[2][j] + v[3][j]);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -357,6 +369,21 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
       }
     }
   }
+  // ---- bias-gradient row of this block: the pixel groups of every channel vector meet in LDS, summed in a fixed order
+  if (g.bias_ws) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [NPG][NCM]
+    if (onG) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[pgG * NCM + cvG * 8 + j] = bsum[j];
+    }
+    __syncthreads();
+    if (tid < NC) {
+      float t = 0.f;
+      for (int q = 0; q < NPG; ++q) t += red[q * NCM + tid];
+      g.bias_ws[(long)row * NC + tid] = t;
+    }
+  }
   // ---- statistics slab row of this block: sum over the 16 pixel lanes of a fragment row, then over the four waves
   if (g.stats) {
     __syncthreads();
@@ -413,6 +440,7 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
 
 inline bool small_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 64; }
 inline bool mid_shape(int Cin, int Cout) { return Cin <= 64 && Cout <= 128; }     // 64-pixel tiles, two blocks per CU
+inline bool tall_shape(int Cin, int Cout) { return Cin <= 128 && Cout <= 64; }    // 64-pixel tiles, two blocks per CU (classifier conv)
 // the two 128-channel instances (neither is used by default: both lose to the two separate kernels -- 139 us for the 8-wave one,
 // 209 us for the transposed-read one, which spills 69 registers, against 121 us): TSS_PW_BWD_BIG=2 selects the transposed-read one
 inline bool big_tr() { const char* s = getenv("TSS_PW_BWD_BIG"); return s && atoi(s) == 2; }
@@ -431,17 +459,20 @@ int tss_pwconv_bwd_fused_preferred(long P, int Cin, int Cout, int dtype) {
   // CU, 40 spilled registers) loses (139 vs 119 us for 128 -> 128 at 262 k pixels), so those layers keep the two kernels.
   const char* sw = getenv("TSS_PW_BWD_FUSED");
   if (sw && atoi(sw) == 0) return 0;
-  const bool inside = dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128;
+  const bool ragged_ok = (Cout % 8) == 0 || (!small_shape(Cin, Cout) && !mid_shape(Cin, Cout) && tall_shape(Cin, Cout));
+  const bool inside = dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && ragged_ok && Cin <= 128 && Cout <= 128;
   if (sw && atol(sw) > 1) return inside && P >= atol(sw);
-  return inside && ((small_shape(Cin, Cout) && P >= 50000) || (mid_shape(Cin, Cout) && P >= 200000));
+  // the classifier conv (128 -> 19 classes at 262 k pixels): 84 us through the general kernels (f32 atomics) -> one sweep
+  return inside && ((small_shape(Cin, Cout) && P >= 50000) || (mid_shape(Cin, Cout) && P >= 200000)
+                    || (!mid_shape(Cin, Cout) && tall_shape(Cin, Cout) && Cout <= 32));      // at every size: the only path without atomics for a ragged Cout
 }
 
 int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
-  const bool small = small_shape(Cin, Cout), mid = !small && mid_shape(Cin, Cout);
-  const bool big2 = !small && !mid && big_tr();
-  const long TM = (mid || big2) ? 64 : 128;
+  const bool small = small_shape(Cin, Cout), mid = !small && mid_shape(Cin, Cout), tall = !small && !mid && tall_shape(Cin, Cout);
+  const bool big2 = !small && !mid && !tall && big_tr();
+  const long TM = (mid || tall || big2) ? 64 : 128;
   long gs = ((P + TM - 1) / TM + 7) / 8;
-  const long cap = (small || mid || big2) ? 64 : 32;
+  const long cap = (small || mid || tall || big2) ? 64 : 32;
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   return (int)(8 * gs);
@@ -453,24 +484,28 @@ int tss_pwconv_bwd_fused_rows(long P, int Cin, int Cout) {
 int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
                          const float* gmu, const float* w, const void* wT_bf16, const void* x, long ldx, const float* in_mean,
                          const float* in_scale, const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei,
-                         double* bstats, float* ws, long P, int Cin, int Cout, int dtype, void* stream) {
-  TSS_REQUIRE(dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && (Cout % 8) == 0 && Cin <= 128 && Cout <= 128, TSS_ERR_SHAPE);
+                         double* bstats, float* ws, float* bias_ws, long P, int Cin, int Cout, int dtype, void* stream) {
+  const bool ragged = (Cout % 8) != 0;         // only the tall instance takes a ragged Cout (vector loads through the pitch)
+  const int CoutV = (Cout + 7) / 8 * 8;
+  TSS_REQUIRE(dtype == TSS_BF16 && Cin >= 8 && Cout >= 8 && (Cin % 8) == 0 && Cin <= 128 && Cout <= 128, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!ragged || (!small_shape(Cin, Cout) && !mid_shape(Cin, Cout) && tall_shape(Cin, Cout)), TSS_ERR_SHAPE);
   TSS_REQUIRE(P > 0 && e && x && e_in && ws && w, TSS_ERR_SHAPE);
-  TSS_REQUIRE((lde % 8) == 0 && lde >= Cout && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= Cout && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= CoutV && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= CoutV && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || x_pending, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(x) && (!yraw || tss::aligned16(yraw)) && ((uintptr_t)e_in & 7u) == 0, TSS_ERR_ALIGN);
   PbArgs g = {};
   g.P = P; g.NC = Cout; g.KC = Cin;
   g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldy = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
   g.w = w;
-  if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wT = (const T*)wT_bf16; g.ldwT = Cout; }
+  if (wT_bf16 && !ragged && tss::aligned16(wT_bf16)) { g.wT = (const T*)wT_bf16; g.ldwT = Cout; }
   g.x = (const T*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_pending = x_pending;
-  g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws;
+  g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws; g.bias_ws = bias_ws;
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0, 4.0 * (double)P * Cin * Cout);
   if (small_shape(Cin, Cout)) launch<256, 128, 4, 1, 1, false>(g, (hipStream_t)stream, 2);
   else if (mid_shape(Cin, Cout)) launch<256, 64, 4, 2, 1, false>(g, (hipStream_t)stream, 2);
+  else if (tall_shape(Cin, Cout)) launch<256, 64, 8, 1, 1, false>(g, (hipStream_t)stream, 2);
   else if (big_tr()) launch<256, 64, 8, 2, 2, true>(g, (hipStream_t)stream, 2);
   else launch<512, 128, 8, 1, 2, false>(g, (hipStream_t)stream, 1);
   return tss::check_last("pwconv_bwd_fused");

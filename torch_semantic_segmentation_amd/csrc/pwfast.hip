@@ -786,13 +786,13 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
 bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb,
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw,
+                         void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw, long red_P, int red_K, int red_N,
                          long P, int K, int N, hipStream_t stream, const void* radd, long ldr) {
   if (g_tss_disable_fast || !yraw || N > KTOT || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
   if (radd && (xraw || (ldr % 4) != 0 || ldr < K)) return false;     // the add is only folded into the unmasked epilogue
   FastArgs g = {};
-  if (red_ws && red_dw) {   // the layer's weight-gradient slots are summed by the first blocks of this launch
-    g.red = tss_wg::reduce_args(red_ws, red_dw, P, K, N);
+  if (red_ws && red_dw) {   // weight-gradient slots (of this layer or of one further up the backward pass) are summed by the first blocks of this launch
+    g.red = tss_wg::reduce_args(red_ws, red_dw, red_P, red_K, red_N);
     g.nred8 = (g.red.nred + 7) & ~7;
   }
   g.P = P; g.K = N; g.N = K;

@@ -15,6 +15,7 @@
 // accumulate onto, exactly like autograd's .grad).
 #include "common.h"
 #include "wgreduce.h"
+#include "bnfin.h"
 
 extern int g_tss_disable_fast;   // pwfast.hip
 
@@ -57,6 +58,9 @@ struct WgradArgs {
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
   float* ws;                       // wgfast: partial tiles [tile][nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
+  // wgfast: the first fin_blocks blocks of the grid finalize the BatchNorm backward of ANOTHER layer (the one the backward
+  // pass reaches next; its slab rows are complete, its coefficients are not needed by this launch): no launch of its own
+  tss_bn_bwd_job fin; int fin_blocks;
 };
 
 // transposing store of a 4-pixel x 8-channel unit: rows ch0..ch0+7, columns 4*pg .. 4*pg+3 (one 8/16-byte
@@ -319,8 +323,9 @@ __global__ __launch_bounds__(NT, 2) void wgfast_kernel(const WgradArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
 
+  if ((int)blockIdx.x < g.fin_blocks) { tss_fin::bn_bwd_finalize_block(g.fin, blockIdx.x); return; }
   const int nchn = (g.ND + TN - 1) / TN;
-  int bid = blockIdx.x;
+  int bid = (int)blockIdx.x - g.fin_blocks;
   const int split = bid % g.nsplit; bid /= g.nsplit;
   const int nc = bid % nchn; bid /= nchn;
   const int kc = bid;
@@ -593,7 +598,7 @@ void launch_fast_pt(WgradArgs& g, hipStream_t stream, bool defer_reduce) {
   if (attr.first()) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgfast_kernel<PT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
-  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(sp.tiles * g.nsplit), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL(wgfast_kernel<PT>, dim3(sp.tiles * g.nsplit + g.fin_blocks), dim3(NT), smem, stream, g);
   if (g.ws && !defer_reduce) {
     const tss_wg::ReduceArgs r = reduce_args(g.ws, g.dw, g.P, g.KD, g.ND);
     hipLaunchKernelGGL(wg_reduce_kernel, dim3(r.nred), dim3(NT), 0, stream, r);
@@ -640,8 +645,10 @@ extern "C" {
 int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           const float* ga, const float* gb, const float* gce, const float* gmu,
                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, void* stream) {
+                          float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, const tss_bn_bwd_job* fin,
+                          void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(!fin || (fin->C > 0 && fin->count >= 1.0 && fin->bstats && fin->invstd && fin->ga && fin->gb && fin->gce), TSS_ERR_SHAPE);
   TSS_REQUIRE(K > 0 && N > 0 && (K % 8) == 0 && (lde % 8) == 0 && lde >= (N + 7) / 8 * 8 && (ldx % 8) == 0 && ldx >= K, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= (N + 7) / 8 * 8 && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw), TSS_ERR_ALIGN);
@@ -655,11 +662,23 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   if (dtype == TSS_BF16 && !g_tss_disable_fast && yraw && (N % 8) == 0 && P > 0) {   // lean pipelined kernel
     tss::ProfScope prof(TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes, 2.0 * (double)P * N * K);
     g.ws = ws;
+    if (fin) { g.fin = *fin; g.fin_blocks = tss_fin::fin_blocks(fin->C); }
     if (tss_wg::split_for(P, K, N).pt == 128) launch_fast_pt<128>(g, (hipStream_t)stream, ws && defer_reduce);
     else launch_fast_pt<64>(g, (hipStream_t)stream, ws && defer_reduce);
     return tss::check_last("wgfast");
   }
+  if (fin) {   // the general kernel carries nothing: the finalize runs as the launch of its own it would otherwise have been
+    const int rc = tss_bn_bwd_finalize(fin->bstats, fin->count, fin->invstd, fin->gamma, fin->training, fin->accumulate, fin->dgamma,
+                                       fin->dbeta, fin->ga, fin->gb, fin->gce, fin->C, stream);
+    if (rc != TSS_OK) return rc;
+  }
   return launch(g, dtype, TSS_K_PWCONV_BWD_WEIGHT, (hipStream_t)stream, bytes);
+}
+
+int tss_pwconv_wg_reduce(const float* ws, float* dw, long P, int K, int N, void* stream) {
+  TSS_REQUIRE(ws && dw && P > 0 && K > 0 && N > 0 && (K % 8) == 0 && (N % 8) == 0, TSS_ERR_SHAPE);
+  tss_wg_reduce_standalone(ws, dw, P, K, N, (hipStream_t)stream);
+  return tss::check_last("wg_reduce");
 }
 
 long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype) {

@@ -179,6 +179,8 @@ class Trainer:
         # staged batch in place -- no device-to-device copy between the H2D copy and the step
         self._graphs = {}
         self._statics = {}
+        self._next_slot = 1           # slot 0 is the trainer's own; new_slots() hands out the rest, never twice
+        self._pool = None             # one private memory pool shared by the captured steps of all slots (they never run concurrently)
         self.iteration = 0
         self.last_loss = None
 
@@ -218,10 +220,28 @@ class Trainer:
                         p.grad.div_(self.world_size)
         self.optimizer.step()
 
+    def new_slots(self, n):
+        """`n` fresh input-slot numbers (for a loader that captures one step per staging buffer).  Slot numbers are never
+        reused, so a pipeline created after another one was dropped can not inherit its captured steps."""
+        first = self._next_slot
+        self._next_slot += int(n)
+        return list(range(first, first + int(n)))
+
+    def release_slot(self, slot):
+        """Drop the captured step and the static input buffers of `slot` (its activations go back to the shared pool)."""
+        self._graphs.pop(slot, None)
+        self._statics.pop(slot, None)
+
     def static_batch(self, x, y, slot=0, adopt=False):
         """The (image, target) device buffers the captured step of `slot` reads.  A loader can fill them in place (H2D copy
         straight into them) and pass them to step_async, which then skips its own device-to-device copy.  adopt=True:
-        x and y (device tensors) BECOME the static buffers of a slot that has none yet."""
+        x and y (device tensors) BECOME the static buffers of a slot that has none yet; for a slot that already has
+        buffers they must BE those buffers (a captured step reads fixed addresses)."""
+        if adopt and slot in self._statics and x.is_cuda and y.is_cuda:
+            sx, sy = self._statics[slot]
+            if sx.data_ptr() != x.data_ptr() or sy.data_ptr() != y.data_ptr():
+                raise RuntimeError('Trainer.static_batch(adopt=True): slot %d already has other input buffers; take fresh '
+                                   'slot numbers from Trainer.new_slots() or release_slot() it first' % slot)
         if slot not in self._statics:
             dev = self.device if self.device is not None else x.device
             if adopt and x.is_cuda and y.is_cuda:
@@ -253,10 +273,12 @@ class Trainer:
             for b, v in saved:
                 b.copy_(v)
         graph = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
         # with a live RCCL process group its watchdog thread polls events while we capture: in the default 'global' capture
         # mode that aborts the capture (seen as a flaky crash); only this thread's calls are checked in 'thread_local' mode
         mode = 'thread_local' if (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl') else 'global'
-        with torch.cuda.graph(graph, capture_error_mode=mode):
+        with torch.cuda.graph(graph, pool=self._pool, capture_error_mode=mode):
             loss = self._forward_backward(sx, sy, prologue).detach()
         self._graphs[slot] = (graph, loss)
 
@@ -355,7 +377,7 @@ class HostBatchPipeline:
         else:
             self.stage = [f32() for _ in range(depth)]
             self.decoded = None
-        self.slot0 = 1000 + id(self) % 1000 * 16      # private slot numbers of this pipeline inside the trainer
+        self.slots = trainer.new_slots(depth)         # private slot numbers of this pipeline inside the trainer, never reused
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.ready = [torch.cuda.Event() for _ in range(depth)]
         self.consumed = [torch.cuda.Event() for _ in range(depth)]
@@ -384,6 +406,15 @@ class HostBatchPipeline:
             self.ready[slot].record(self.copy_stream)
         self._count += 1
 
+    def close(self):
+        """Release this pipeline's captured steps and input slots in the trainer (call when the loader is re-created, e.g. per
+        epoch); the pipeline can not be used afterwards."""
+        torch.cuda.current_stream(self.device).synchronize()
+        self.copy_stream.synchronize()
+        for s in self.slots:
+            self.trainer.release_slot(s)
+        self.slots, self.stage, self.decoded, self._keep, self._count = [], [], None, [], 0
+
     def _decode(self, slot):
         sx, sy = self.stage[slot]
         dx, dy = self.decoded
@@ -398,7 +429,7 @@ class HostBatchPipeline:
         slot = self._head
         main = torch.cuda.current_stream(self.device)
         main.wait_event(self.ready[slot])
-        tslot = self.slot0 + slot
+        tslot = self.slots[slot]
         if self.wire == 'u8':
             dx, dy = self.decoded
             self.trainer.static_batch(dx, dy, tslot, adopt=True)

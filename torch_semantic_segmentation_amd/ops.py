@@ -60,6 +60,88 @@ batch_dw_reductions = os.environ.get('TSS_BATCH_DW_REDUCE', '1') == '1'
 fuse_pw_backward = os.environ.get('TSS_PW_BWD_FUSED', '1') != '0'     # csrc/pwbwd.hip, for the layers it prefers
 _pending_dw = []
 
+# Backward-pass scheduling ("launch count"): every dependent launch costs >= 4.7 us in the replayed step, so
+#   * the weight gradient of a 1x1 layer -- which nothing downstream in the backward pass depends on -- is POSTPONED until the
+#     next BatchNorm-backward finalize is due, and that finalize rides in front of its grid (tss_pwconv_bwd_weight's `fin`);
+#   * the slot reduction of a launched weight gradient rides in front of the next backward-data grid of ANY 1x1 layer.
+# State of the running backward pass; everything left over is flushed by the end-of-pass callback, so gradients are complete
+# when backward() returns (and not before: see direct_grads).
+postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
+_pending_wg = []       # <= 1 entry: (launch(fin_job or None), device)
+_pending_red = []      # <= 1 entry: (ws, dw, P, K, N, device)
+_cb_task = [None]
+
+
+class BnBwdJob(ctypes.Structure):
+    """tss_bn_bwd_job of include/tss_hip.h."""
+    _fields_ = [('bstats', ctypes.c_void_p), ('count', ctypes.c_double), ('invstd', ctypes.c_void_p), ('gamma', ctypes.c_void_p),
+                ('training', ctypes.c_int), ('accumulate', ctypes.c_int), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
+                ('ga', ctypes.c_void_p), ('gb', ctypes.c_void_p), ('gce', ctypes.c_void_p), ('C', ctypes.c_int)]
+
+
+def _backward_task():
+    """Id of the running autograd graph task (-1: none).  The first call of a pass queues the end-of-pass flush; state left over
+    from a pass that raised before its callback ran is void and dropped."""
+    try:
+        task = torch._C._current_graph_task_id()
+    except AttributeError:          # private API gone: nothing is deferred
+        return -1
+    if task != -1 and _cb_task[0] != task:
+        del _pending_dw[:], _pending_wg[:], _pending_red[:]
+        try:
+            torch.autograd.variable.Variable._execution_engine.queue_callback(_end_of_backward)
+        except Exception:           # noqa: BLE001 -- no callback, no deferral
+            return -1
+        _cb_task[0] = task
+    return task
+
+
+def _flush_wg():
+    while _pending_wg:
+        launch, dev = _pending_wg.pop()
+        with torch.cuda.device(dev):
+            launch(None)
+
+
+def _flush_red():
+    while _pending_red:
+        ws, dw, P, K, Nn, dev = _pending_red.pop()
+        with torch.cuda.device(dev):
+            call('tss_pwconv_wg_reduce', ptr(ws), ptr(dw), P, K, Nn, stream())
+
+
+def _take_red(dev):
+    """(ws ptr, dw ptr, P, K, N) of a slot reduction waiting for a carrier on this device (else NULLs); keeps its tensors alive in `hold`."""
+    if _pending_red and _pending_red[-1][5] == dev:
+        ws, dw, P, K, Nn, _ = _pending_red.pop()
+        return (ptr(ws), ptr(dw), P, K, Nn), (ws, dw)
+    _flush_red()
+    return (None, None, 0, 0, 0), None
+
+
+def _end_of_backward():
+    _cb_task[0] = None
+    _flush_wg()
+    _flush_red()
+    _flush_dw_reductions()
+
+
+def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
+    """BatchNorm-backward coefficients + d(gamma), d(beta) of `link`: in front of a postponed weight-gradient grid when there is
+    one (no launch of its own), else tss_bn_bwd_finalize."""
+    training = int(link.training if training is None else training)
+    if _pending_wg:
+        launch, dev = _pending_wg[-1]
+        if dev == link.bstats.device and _backward_task() != -1 and _pending_wg:
+            _pending_wg.pop()
+            job = BnBwdJob(ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
+                           ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), int(C))
+            launch(job)
+            return
+        _flush_wg()
+    call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
+         ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
+
 
 def _flush_dw_reductions():
     jobs = list(_pending_dw)
@@ -81,14 +163,13 @@ def _reduce_rows_now(ws, dw, ncols, nrows):
 
 
 def _defer_dw_reduction(ws, dw, ncols, nrows):
-    task = torch._C._current_graph_task_id()
-    if _pending_dw and _pending_dw[0][4] != task:
-        del _pending_dw[:]       # left over from a backward pass that raised before its callback ran: those gradients are void
-    if not _pending_dw:          # first job of this backward pass: flush when the engine has run every node
-        torch.autograd.variable.Variable._execution_engine.queue_callback(_flush_dw_reductions)
-    elif _pending_dw[0][0].device != ws.device:
+    """Queue the row reduction of a one-sweep backward for the single launch at the end of the pass (now, if nothing can be deferred)."""
+    task = _backward_task()
+    if task == -1:
+        _reduce_rows_now(ws, dw, ncols, nrows)
+        return
+    if _pending_dw and _pending_dw[0][0].device != ws.device:
         _flush_dw_reductions()
-        torch.autograd.variable.Variable._execution_engine.queue_callback(_flush_dw_reductions)
     _pending_dw.append((ws, dw, ncols, nrows, task))
 
 
@@ -676,13 +757,12 @@ class ConvUnitFn(Function):
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
             if link.sync is not None:
+                _flush_wg()
                 gs = _allreduce_stats(link.bstats, link.count, Cout, link.sync, st)
                 call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), acc,
                      ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
             else:
-                call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd),
-                     ptr(link.gamma), int(link.training), acc, ptr(dgamma), ptr(dbeta),
-                     ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
+                _bn_bwd_finalize(link, Cout, acc, dgamma, dbeta, st)
             if acc:
                 dgamma = dbeta = None
             ga, gb, gce, gmu = link.ga, link.gb, link.gce, link.mean
@@ -710,6 +790,8 @@ class ConvUnitFn(Function):
         if side is not None:
             side.wait_stream(main)
             wst = side.cuda_stream
+        fused_pw = False
+        fused_dbias = None
         if cfg.kind == 'stem':
             ws = torch.empty((N.stat_slabs(), Cout * 28), dtype=torch.float32, device=dev)
             call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw), ptr(ws),
@@ -719,18 +801,23 @@ class ConvUnitFn(Function):
         else:
             xargs = (ptr(x), ld(x), *_aff(il), int(cfg.in_relu))
             deferred_in = il is not None or cfg.in_relu
-            fused_pw = False
             if cfg.kind == 'pw':
                 # few channels, many pixels: input gradient and weight gradient in ONE sweep (csrc/pwbwd.hip): e, y, x read once
                 fused_pw = bool(fuse_pw_backward and need_dx and side is None and e.dtype == torch.bfloat16
                                 and not N.fast_paths_disabled() and N.lib().tss_pwconv_bwd_fused_preferred(P, Cin, Cout, dt))
+            postponed = False
             if fused_pw:
                 pass
             elif cfg.kind == 'pw':
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
-                defer = 1 if (ws is not None and need_dx and side is None) else 0   # backward-data carries the reduce
-                call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, P, Cin, Cout, dt, wst)
+                defer = 1 if (ws is not None and need_dx and side is None) else 0   # a backward-data launch carries the reduce
+                # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _pending_wg)
+                postponed = bool(defer and postpone_wgrad and dw_ret is None and _backward_task() != -1)
+                if not postponed:
+                    _flush_wg()
+                    _flush_red()
+                    call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, P, Cin, Cout, dt, None, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
                 defer = 1 if (need_dx and side is None) else 0      # backward-data carries the row reduction
@@ -751,7 +838,7 @@ class ConvUnitFn(Function):
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin * 9, Cout, dt)
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
                 call('tss_pwconv_bwd_weight', *gargs, ptr(col), Cin * 9, None, None, None, 0, ptr(dw), ptr(ws), 0,
-                     P, Cin * 9, Cout, dt, wst)
+                     P, Cin * 9, Cout, dt, None, wst)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
             if need_dx:
@@ -761,23 +848,48 @@ class ConvUnitFn(Function):
                 if fused_pw:
                     rows = N.lib().tss_pwconv_bwd_fused_rows(P, Cin, Cout)
                     ws = torch.empty((rows, Cout * Cin), dtype=torch.float32, device=dev)
+                    bws = dbias = None
+                    if ctx.has_bias:          # the bias gradient leaves the same sweep as per-block rows (no colsum launch, no atomics)
+                        bws = torch.empty((rows, Cout), dtype=torch.float32, device=dev)
+                        dbias = _direct_target(p_bias)
+                        if dbias is None:
+                            dbias = fused_dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
                     call('tss_pwconv_bwd_fused', *gargs, ptr(weight), _shadow(weight, 1), *xargs, int(bool(deferred_in)),
-                         ptr(e_in), ld(e_in), bst, ptr(ws), P, Cin, Cout, dt, st)
-                    if dw_ret is None and batch_dw_reductions:
+                         ptr(e_in), ld(e_in), bst, ptr(ws), ptr(bws), P, Cin, Cout, dt, st)
+                    if dw_ret is None and fused_dbias is None and batch_dw_reductions:
                         _defer_dw_reduction(ws, dw, Cout * Cin, rows)       # summed with the depthwise rows, at the end of the pass
+                        if bws is not None:
+                            _defer_dw_reduction(bws, dbias, Cout, rows)
                     else:
                         _reduce_rows_now(ws, dw, Cout * Cin, rows)
+                        if bws is not None:
+                            _reduce_rows_now(bws, dbias, Cout, rows)
                 elif cfg.kind == 'pw':
                     fork = getattr(cfg, 'res_fork', None)
                     radd = fork.g2 if fork is not None else None
+                    if postponed:      # this launch carries the slot reduction of an EARLIER layer's weight gradient, if one waits
+                        red, hold = _take_red(dev)
+                    else:
+                        red, hold = ((ptr(ws), ptr(dw), 0, 0, 0) if defer else (None, None, 0, 0, 0)), None
                     if (radd is not None and not deferred_in and y is not None and e.dtype == torch.bfloat16 and radd.dtype == e.dtype
                             and tuple(radd.shape) == tuple(e_in.shape) and N.lib().tss_pwconv_bwd_data_radd_supported(P, Cin, Cout, dt)):
                         call('tss_pwconv_bwd_data_radd', *gargs, ptr(weight), _shadow(weight, 1), ptr(e_in), ld(e_in),
-                             ptr(ws) if defer else None, ptr(dw) if defer else None, ptr(radd), ld(radd), P, Cin, Cout, dt, st)
+                             *red, ptr(radd), ld(radd), P, Cin, Cout, dt, st)
                         fork.consumed = True
                     else:
                         call('tss_pwconv_bwd_data', *gargs, ptr(weight), _shadow(weight, 1), *margs, ptr(e_in), ld(e_in), bst,
-                             ptr(ws) if defer else None, ptr(dw) if defer else None, P, Cin, Cout, dt, st)
+                             *red, P, Cin, Cout, dt, st)
+                    del hold
+                    if postponed:
+                        _flush_wg()            # at most one weight gradient waits at a time
+
+                        def launch_wg(fin, _keep=(e, y, x, link, il, ws, dw), _args=(gargs, xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt)):
+                            ga_, xa_, dwp, wsp, P_, K_, N_, dt_ = _args
+                            call('tss_pwconv_bwd_weight', *ga_, *xa_, dwp, wsp, 1, P_, K_, N_, dt_,
+                                 ctypes.byref(fin) if fin is not None else None, stream())
+                            _flush_red()
+                            _pending_red.append((_keep[5], _keep[6], P_, K_, N_, _keep[0].device))
+                        _pending_wg.append((launch_wg, dev))
                 elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
                     # the rows of per-block partial sums stay in ws; they are added to the (direct) gradient together with
                     # those of every other depthwise layer, in one launch at the end of this backward pass
@@ -808,8 +920,8 @@ class ConvUnitFn(Function):
                         call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
                     call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), ptr(w_tcn16), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cin, Cout, d, dt, st)
-        dbias_ret = None
-        if ctx.has_bias:
+        dbias_ret = fused_dbias
+        if ctx.has_bias and not (fused_pw and need_dx):
             dbias = _direct_target(p_bias)
             if dbias is None:
                 dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
@@ -908,8 +1020,7 @@ class ExpandDwFn(Function):
         if not acc:
             dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
             dgamma, dbeta = dgb[0], dgb[1]
-        call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), 1, acc,
-             ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
+        _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=1)
         return (None, None) if acc else (dgamma, dbeta)
 
     @staticmethod
@@ -1553,32 +1664,30 @@ class OHEMLoss(torch.nn.Module):
 
 class UpsampleCrossEntropyFn(Function):
     """cross_entropy(F.interpolate(low, scale, bilinear, align_corners=True), target) without the full-res logits:
-    one pass yields the loss and the unscaled low-res gradient, backward scales it by grad_out / #valid."""
+    one pass yields the loss and the unscaled low-res gradient (per-block tiles in a workspace, no atomics, nothing to
+    zero-fill), backward gathers the tiles in a fixed order and scales by grad_out / #valid: bit-identical from run to run."""
 
     @staticmethod
     def forward(ctx, low, target, ho, wo, ignore_index):
         B, C, h, w = low.shape
         dev = low.device
         target = target.contiguous()
-        # one zero-fill for both accumulators: [loss sum, #valid] as f64 in front (16 bytes), the f32 low-res gradient behind
-        n = B * h * w * ld(low)
-        zbuf = torch.zeros(4 + n, dtype=torch.float32, device=dev)
-        acc = zbuf[:4].view(torch.float64)
-        dacc = zbuf[4:].view(B, h, w, ld(low))
+        nws = N.lib().tss_upsample_ce_ws(B, C, h, w, ho, wo)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
         scal = torch.empty(2, dtype=torch.float32, device=dev)
-        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(dacc), ptr(acc), ptr(scal[0:1]),
+        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(ws), ptr(scal[0:1]),
              ptr(scal[1:2]), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
-        ctx.geom = (B, C, h, w, ld(low), low.dtype)
-        ctx.save_for_backward(dacc, scal)
+        ctx.geom = (B, C, h, w, ho, wo, ld(low), low.dtype)
+        ctx.save_for_backward(ws, scal)
         return scal[0].clone()
 
     @staticmethod
     def backward(ctx, gout):
-        dacc, scal = ctx.saved_tensors
-        B, C, h, w, ldl, dtype = ctx.geom
+        ws, scal = ctx.saved_tensors
+        B, C, h, w, ho, wo, ldl, dtype = ctx.geom
         gout = gout.to(torch.float32).contiguous()
-        base = torch.empty((B, h, w, ldl), dtype=dtype, device=dacc.device)   # pad channels of dacc are zero
-        call('tss_upsample_ce_bwd', ptr(dacc), ptr(scal[1:2]), ptr(gout), ptr(base), base.numel(),
+        base = torch.empty((B, h, w, ldl), dtype=dtype, device=ws.device)   # pad channels are written as zeros
+        call('tss_upsample_ce_bwd', ptr(ws), ptr(scal[1:2]), ptr(gout), ptr(base), ldl, B, C, h, w, ho, wo,
              N.dtype_code(dtype), stream())
         return base.permute(0, 3, 1, 2)[:, :C], None, None, None, None
 
