@@ -344,6 +344,22 @@ int tss_ppm_concat_bwd(const void* dout, long lddo, const void* const* raw, cons
                        const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
                        double* const* bstats, void* const* e, const long* lde, int narms,
                        int B, int H, int W, int C, int ca, int dtype, void* stream);
+/* The arms of a pyramid pooling module between the pools and the concat, ALL arms in one launch, one block per arm
+ * (replaces, per arm: nn.Conv2d(in, in / 4, 1) + nn.BatchNorm2d of Conv2dBlock TSS/models/fastscnn.py:106-112 -- i.e.
+ * tss_pwconv_fwd + tss_bn_finalize forward, tss_bn_bwd_finalize + tss_pwconv_bwd_weight + tss_pwconv_bwd_data backward).
+ * x[a]: pooled map [P[a]][C] (P[a] = B * bins^2 <= 512), w[a]: [Ca][C] f32, y[a]: raw conv output [P[a]][Ca],
+ * vec[a]: [6][Ca] f32 = mean | invstd | gamma * invstd | ga | gb | gce (forward writes the first three in training mode and
+ * updates the running statistics as tss_bn_finalize does; backward reads them and writes the last three).
+ * Backward: e[a] = d(loss)/d(BatchNorm output), masked; dw / dgamma / dbeta are overwritten, or added to when accumulate = 1;
+ * e_in[a] [P[a]][C] = gradient of the pooled map.  bf16 only; C <= 128 and a multiple of 32, Ca 16 or 32. */
+int tss_ppm_arms_supported(int narms, int C, int Ca, const int* P, int dtype);
+int tss_ppm_arms_fwd(const void* const* x, const long* ldx, const float* const* w, const float* const* gamma, float* const* running_mean,
+                     float* const* running_var, long long* const* num_batches_tracked, void* const* y, const long* ldy, float* const* vec,
+                     const int* P, int narms, int C, int Ca, int training, float eps, float momentum, int dtype, void* stream);
+int tss_ppm_arms_bwd(const void* const* e, const long* lde, const void* const* y, const long* ldy, const void* const* x, const long* ldx,
+                     const float* const* w, const float* const* gamma, float* const* vec, float* const* dw, float* const* dgamma,
+                     float* const* dbeta, int accumulate, void* const* e_in, const long* ldei, const int* P, int narms, int C, int Ca,
+                     int training, int dtype, void* stream);
 int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream);
 
 /* ---- caller side: loss and evaluation metrics --------------------------------------------------------

@@ -101,7 +101,10 @@ class PyramidPoolingModule(nn.Module):
             and isinstance(a[0].output_size, int) and not has_hooks(a) for a in arms)
         if plain:
             pooled = ops.adaptive_avg_pool_multi(x, [a[0].output_size for a in arms])
-            ds = [run(a[1], Deferred(p)) for a, p in zip(arms, pooled)]
+            # the arms' 1x1 convolutions + BatchNorm statistics: one launch for all arms (csrc/ppm.hip), else unit by unit
+            ds = ops.ppm_arms([a[1] for a in arms], pooled)
+            if ds is None:
+                ds = [run(a[1], Deferred(p)) for a, p in zip(arms, pooled)]
             if ops.ppm_arms_fusable(x, ds):
                 return self.conv(ops.concat_upsampled_arms(x, ds))
             return self.conv(ops.concat_upsampled(x, ds))

@@ -445,13 +445,16 @@ class BNLink:
     __slots__ = ('C', 'count', 'training', 'gamma', 'beta', 'vec', 'scale', 'mean', 'invstd',
                  'ga', 'gb', 'gce', 'stats', 'bstats', 'consumed', 'sync')
 
-    def __init__(self, C, count, training, gamma, beta, device):
+    def __init__(self, C, count, training, gamma, beta, device, slabs=True):
         self.C, self.count, self.training, self.gamma, self.beta = C, count, training, gamma, beta
         self.vec = torch.empty((6, C), dtype=torch.float32, device=device)
         self.mean, self.invstd, self.scale, self.ga, self.gb, self.gce = self.vec.unbind(0)
-        # [forward | backward][slab rows][sum, second moment]: written in full by the kernels, never cleared here
-        both = torch.empty((2, N.stat_slabs(), 2 * C), dtype=torch.float64, device=device)
-        self.stats, self.bstats = both[0], both[1]
+        if slabs:
+            # [forward | backward][slab rows][sum, second moment]: written in full by the kernels, never cleared here
+            both = torch.empty((2, N.stat_slabs(), 2 * C), dtype=torch.float64, device=device)
+            self.stats, self.bstats = both[0], both[1]
+        else:       # a unit that keeps its statistics on chip (ppm_arms): nobody writes slab rows for it
+            self.stats = self.bstats = None
         self.consumed = False
         self.sync = None          # process group of a cross-replica (Sync) BatchNorm, see SyncBatchNorm below
 
@@ -1551,9 +1554,108 @@ class PpmConcatFn(Function):
         dout = to_nhwc(dout)
         es = [new_nhwc(B, ca, b, b, dout.dtype, dout.device) for b in bins]
         call('tss_ppm_concat_bwd', ptr(dout), ld(dout), _hp(raws), _hl([ld(r) for r in raws]), _hi(bins),
-             *PpmConcatFn._tables(ctx.cfg), _hp([l.bstats if l is not None else None for l in ctx.cfg.links]),
+             *PpmConcatFn._tables(ctx.cfg), _hp([l.bstats if l is not None else None for l in ctx.cfg.links]),   # (None: sums taken on chip by ppm_arms)
              _hp(es), _hl([ld(e) for e in es]), len(raws), B, H, W, C, ca, N.dtype_code(dout.dtype), stream())
         return (dout[:, :C], None, *es)
+
+
+# the arms themselves (1x1 convolution + BatchNorm statistics + finalize per arm): one launch for all of them, forward and backward
+ppm_arms_fused = os.environ.get('TSS_PPM_ARMS', '1') != '0'    # '0': every arm through conv_unit (A/B checks)
+
+
+def ppm_arms(blocks, pooled):
+    """[block_i(pooled_i)] for the arms of a pyramid pooling module, each block = (Conv2d 1x1, BatchNorm2d[, ReLU]) -> list of
+    Deferred (raw conv output + pending BatchNorm + ReLU), from ONE launch (csrc/ppm.hip); None when the arms are outside that
+    kernel's envelope (the caller then runs them one by one)."""
+    if not ppm_arms_fused or N.fast_paths_disabled() or not 1 <= len(blocks) <= 4:
+        return None
+    convs, bns, relus = [], [], []
+    for blk in blocks:
+        mods = list(blk)
+        if len(mods) not in (2, 3) or not isinstance(mods[0], torch.nn.Conv2d) or not isinstance(mods[1], _BatchNorm):
+            return None
+        if len(mods) == 3 and not isinstance(mods[2], torch.nn.ReLU):
+            return None
+        c, bn = mods[0], mods[1]
+        if (c.kernel_size != (1, 1) or c.groups != 1 or c.bias is not None or c.stride != (1, 1) or c.padding != (0, 0)
+                or c.weight.dtype != torch.float32 or bn.weight is None or bn.weight.dtype != torch.float32
+                or (bn.training and (bn.momentum is None or not bn.track_running_stats)) or _sync_group(bn) is not None
+                or (bn.running_mean is not None and bn.running_mean.dtype != torch.float32)
+                or getattr(blk, 'act_dtype', None) not in (None, torch.bfloat16)):
+            return None
+        convs.append(c); bns.append(bn); relus.append(len(mods) == 3)
+    ps = [p.raw if isinstance(p, Deferred) and p.link is None and not p.relu else p for p in pooled]
+    if any(not torch.is_tensor(p) or p.dtype != torch.bfloat16 or not is_nhwc(p) for p in ps):
+        return None
+    C, Ca = convs[0].in_channels, convs[0].out_channels
+    training = bns[0].training
+    if any(c.in_channels != C or c.out_channels != Ca for c in convs) or any(p.shape[1] != C for p in ps) \
+            or any(bn.training != training or bn.eps != bns[0].eps or bn.momentum != bns[0].momentum for bn in bns):
+        return None
+    counts = [npix(p) for p in ps]
+    if training and min(counts) <= 1:
+        return None                     # conv_unit raises torch's "Expected more than 1 value per channel"
+    if not N.lib().tss_ppm_arms_supported(len(ps), C, Ca, _hi(counts), N.TSS_BF16):
+        return None
+    cfg = JoinCfg()
+    cfg.links = [None] * len(ps)
+    cfg.relus = (convs, bns)
+    ys = PpmArmsFn.apply(cfg, *ps, *[c.weight for c in convs], *[bn.weight for bn in bns], *[bn.bias for bn in bns])
+    return [Deferred(y, link, relu) for y, link, relu in zip(ys, cfg.links, relus)]
+
+
+class PpmArmsFn(Function):
+    @staticmethod
+    def forward(ctx, cfg, *ts):
+        convs, bns = cfg.relus
+        n = len(convs)
+        ps, ws, gammas, betas = ts[:n], ts[n:2 * n], ts[2 * n:3 * n], ts[3 * n:4 * n]
+        dev = ps[0].device
+        C, Ca = convs[0].in_channels, convs[0].out_channels
+        training = bns[0].training
+        ys = [new_nhwc(p.shape[0], Ca, p.shape[2], p.shape[3], p.dtype, dev) for p in ps]
+        counts = [npix(p) for p in ps]
+        links = [BNLink(Ca, cnt, training, g_, b_, dev, slabs=False) for cnt, g_, b_ in zip(counts, gammas, betas)]
+        run = [(bn.running_mean, bn.running_var, bn.num_batches_tracked) if training else (None, None, None) for bn in bns]
+        call('tss_ppm_arms_fwd', _hp(ps), _hl([ld(p) for p in ps]), _hp(ws), _hp(gammas), _hp([r[0] for r in run]),
+             _hp([r[1] for r in run]), _hp([r[2] for r in run]), _hp(ys), _hl([ld(y) for y in ys]), _hp([l.vec for l in links]),
+             _hi(counts), n, C, Ca, int(training), float(bns[0].eps), float(bns[0].momentum if bns[0].momentum is not None else 0.0),
+             N.TSS_BF16, stream())
+        if not training:
+            for bn, link in zip(bns, links):
+                pre = _EVAL_AFFINES.get(id(bn)) if _EVAL_AFFINES else None
+                if pre is not None:
+                    link.mean, link.invstd, link.scale = pre.unbind(0)
+                else:
+                    call('tss_bn_eval_affine', ptr(bn.weight), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps),
+                         ptr(link.mean), ptr(link.invstd), ptr(link.scale), Ca, stream())
+        cfg.links = links
+        ctx.cfg, ctx.n, ctx.geom = cfg, n, (C, Ca, counts, training)
+        ctx.save_for_backward(*ps, *ws, *ys)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *es):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        ps, ws, ys = saved[:n], saved[n:2 * n], saved[2 * n:3 * n]
+        convs, bns = ctx.cfg.relus
+        links = ctx.cfg.links
+        C, Ca, counts, training = ctx.geom
+        dev = ps[0].device
+        es = [to_nhwc(e) if e is not None else new_nhwc(*y.shape, y.dtype, dev).zero_() for e, y in zip(es, ys)]
+        targets = [(_direct_target(c.weight), _direct_target(bn.weight), _direct_target(bn.bias)) for c, bn in zip(convs, bns)]
+        direct = all(t is not None for tr in targets for t in tr)
+        if not direct:
+            targets = [(torch.empty_like(c.weight), torch.empty_like(bn.weight), torch.empty_like(bn.bias)) for c, bn in zip(convs, bns)]
+        eins = [new_nhwc(p.shape[0], C, p.shape[2], p.shape[3], p.dtype, dev) for p in ps]
+        call('tss_ppm_arms_bwd', _hp(es), _hl([ld(e) for e in es]), _hp(ys), _hl([ld(y) for y in ys]), _hp(ps), _hl([ld(p) for p in ps]),
+             _hp(ws), _hp([l.gamma for l in links]), _hp([l.vec for l in links]), _hp([t[0] for t in targets]),
+             _hp([t[1] for t in targets]), _hp([t[2] for t in targets]), int(direct), _hp(eins), _hl([ld(t) for t in eins]),
+             _hi(counts), n, C, Ca, int(training), N.TSS_BF16, stream())
+        if direct:
+            return (None, *eins, *([None] * (3 * n)))
+        return (None, *eins, *[t[0] for t in targets], *[t[1] for t in targets], *[t[2] for t in targets])
 
 
 # ----------------------------------------------------------------------------- loss / metrics (caller side)
