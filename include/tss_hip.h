@@ -297,11 +297,16 @@ int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float
                 const unsigned long long* seed_slot, int dtype, void* stream);
 int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtype, void* stream);
 /* bf16 shadows of 1x1 weights, all layers in one launch.  table: njobs x 5 int64 on the device:
- * (f32 source [N][K], bf16 copy [N][K], bf16 transpose [K][N], N, K); blocks_per_job x njobs blocks of 256 threads. */
-int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, void* stream);
+ * (f32 source [N][K], bf16 copy [N][K], bf16 transpose [K][N], N, K); blocks_per_job x njobs blocks of 256 threads.
+ * zero / zero_n (optional): a float buffer cleared by the same launch -- the step's flat gradient buffer (optimizer.zero_grad()
+ * of TSS/engine.py:28), which is due at the same point of the step. */
+int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, float* zero, long zero_n, void* stream);
+/* torch.optim.AdamW.step() on one flat buffer.  state != NULL: [step, 1 - beta1^step, sqrt(1 - beta2^step)] and the learning
+ * rate *lr live on the device (a tick kernel advances them: the step can be replayed from a captured graph); state == NULL:
+ * lr_host and step_host (1-based) are used instead and the whole step is ONE launch. */
 int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                    const float* lr, float beta1, float beta2, float eps, float weight_decay,
-                   float* state, float grad_scale, void* stream);
+                   float* state, float grad_scale, float lr_host, long step_host, void* stream);
 
 /* ---- resampling -------------------------------------------------------------------------------------
  * replaces: F.interpolate(mode='bilinear', align_corners=True) TSS/models/fastscnn.py:63-64,119-120,
@@ -335,8 +340,10 @@ int tss_ppm_pool_slices(int B, int ncells);   /* S: row slices per window pool_f
 int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms,
                      float* ws /* NULL, or B * sum(bins^2) * S * C floats (partial sums, no initialisation needed) */,
                      int B, int H, int W, int C, int dtype, void* stream);
+/* radd (optional, [B][H][W] pixels of C channels, pitch ldr): another gradient of the pooled-from map, added to dx here (the map
+ * feeds the pools AND the concat, TSS/models/fastscnn.py:118-121; autograd would add the two gradients with a launch of its own) */
 int tss_ppm_pool_bwd(const void* const* dy, const long* lddy, const int* bins, int narms, void* dx, long lddx,
-                     int B, int H, int W, int C, int dtype, void* stream);
+                     const void* radd, long ldr, int B, int H, int W, int C, int dtype, void* stream);
 int tss_ppm_concat_fwd(const void* x, long ldx, const void* const* raw, const long* ldr, const int* bins,
                        const float* const* mean, const float* const* scale, const float* const* beta, const int* relu,
                        int narms, void* out, long ldo, int B, int H, int W, int C, int ca, int dtype, void* stream);

@@ -197,12 +197,20 @@ def test_flat_adamw_state_dict_round_trip_and_detached_gradients_raise():
     from torch_semantic_segmentation_amd import engine as E
     m = nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4))
     opt = E.FlatAdamW(m.parameters(), lr=1e-3)
-    opt.exp_avg.fill_(0.5); opt.exp_avg_sq.fill_(0.25); opt.state_vec.copy_(torch.tensor([3.0, 0.1, 0.2]))
+    opt.exp_avg.fill_(0.5); opt.exp_avg_sq.fill_(0.25); opt.step_count = 3
     sd = opt.state_dict()
+    assert float(sd['flat']['state_vec'][0]) == 3.0 and abs(float(sd['flat']['state_vec'][1]) - (1 - 0.9 ** 3)) < 1e-6
     opt2 = E.FlatAdamW(nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4)).parameters(), lr=1e-3)
     opt2.load_state_dict(sd)
     assert torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
-    assert torch.equal(opt2.state_vec, opt.state_vec)
+    assert opt2.step_count == 3 and torch.equal(opt2.state_vec, sd['flat']['state_vec'])
+    # a torch.optim.AdamW checkpoint (per-parameter state, no flat moments) must not load silently
+    ref = torch.optim.AdamW(nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4)).parameters(), lr=1e-3)
+    for p_ in ref.param_groups[0]['params']:
+        p_.grad = torch.zeros_like(p_)
+    ref.step()
+    with pytest.raises(ValueError, match='no flat moments'):
+        opt2.load_state_dict(ref.state_dict())
     opt._check_aliases()
     m.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError, match='no longer aliases'):

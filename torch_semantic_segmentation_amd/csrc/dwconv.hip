@@ -420,7 +420,7 @@ __global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_kernel(const float* 
 // the row reductions of several layers in ONE launch (blockIdx.y = layer): the one-sweep backward of a depthwise layer leaves
 // its per-block rows in a workspace, and a training step has 13-17 such layers whose 5 us reductions nobody waits for
 // before the optimizer -- they are collected and summed together at the end of the backward pass
-constexpr int RED_MANY = 16;
+constexpr int RED_MANY = 40;
 struct ReduceJobs { const float* ws[RED_MANY]; float* dw[RED_MANY]; int n[RED_MANY]; int rows[RED_MANY]; };
 __global__ __launch_bounds__(RED_WAVES * 64) void dw_reduce_many_kernel(const ReduceJobs j) {
   __shared__ float part[RED_WAVES * 64];

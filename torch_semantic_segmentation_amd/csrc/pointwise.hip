@@ -470,9 +470,12 @@ __global__ void adamw_tick_kernel(float* state, float beta1, float beta2) {
 
 __global__ __launch_bounds__(NT) void adamw_kernel(float* p, const float* g, float* m, float* v, long n,
                                                    const float* lr_ptr, float beta1, float beta2, float eps,
-                                                   float weight_decay, const float* state, float grad_scale) {
-  const float lr = *lr_ptr;
-  const float bc1 = state[1], bc2s = state[2];
+                                                   float weight_decay, const float* state, float grad_scale,
+                                                   float lr_host, float bc1_host, float bc2s_host) {
+  // device-side step counter / learning rate (state, lr_ptr: the step can be replayed from a captured graph), or both as
+  // kernel arguments computed on the host (one launch instead of three when the optimizer step is launched eagerly)
+  const float lr = state ? *lr_ptr : lr_host;
+  const float bc1 = state ? state[1] : bc1_host, bc2s = state ? state[2] : bc2s_host;
   const float step_size = lr / bc1;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const float gi = g[i] * grad_scale;
@@ -490,9 +493,17 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 // bf16 shadows of the 1x1 convolution weights, all layers in one launch: job j = (f32 source [N][K], bf16 copy [N][K],
 // bf16 transpose [K][N]).  The pointwise kernels stage their weight tiles from these with plain 16-byte copies
 // (forward reads the copy, backward-data the transpose) instead of converting f32 per block.
-__global__ __launch_bounds__(256) void cast_weights_kernel(const long long* table, int njobs) {
+// blockIdx.y == njobs (when zero_n > 0): these blocks clear a float buffer instead -- the flat gradient buffer of the step, whose
+// zero-fill would otherwise be a launch of its own at the same point of the step (16-byte stores; zero_n % 4 == 0 or a scalar tail)
+__global__ __launch_bounds__(256) void cast_weights_kernel(const long long* table, int njobs, float* zero, long zero_n) {
   const int job = blockIdx.y;
-  if (job >= njobs) return;
+  if (job >= njobs) {
+    const long n4 = zero_n >> 2;
+    float4* z4 = reinterpret_cast<float4*>(zero);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (blockIdx.x == 0 && (long)threadIdx.x < zero_n - n4 * 4) zero[n4 * 4 + threadIdx.x] = 0.f;
+    return;
+  }
   const long long* t = table + (long)job * 5;
   const float* src = reinterpret_cast<const float*>(t[0]);
   bf16_t* dst = reinterpret_cast<bf16_t*>(t[1]);
@@ -695,24 +706,27 @@ int tss_channel_shuffle(const void* x, long ldx, void* y, long ldy, long P, int 
   return tss::check_last("channel_shuffle");
 }
 
-int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, void* stream) {
-  TSS_REQUIRE(njobs >= 0 && blocks_per_job >= 1, TSS_ERR_SHAPE);
-  if (njobs == 0) return TSS_OK;
-  hipLaunchKernelGGL(cast_weights_kernel, dim3(blocks_per_job, njobs), dim3(256), 0, (hipStream_t)stream, table, njobs);
+int tss_cast_weights(const long long* table, int njobs, int blocks_per_job, float* zero, long zero_n, void* stream) {
+  TSS_REQUIRE(njobs >= 0 && blocks_per_job >= 1 && zero_n >= 0 && (zero_n == 0 || (zero && tss::aligned16(zero))), TSS_ERR_SHAPE);
+  if (njobs == 0 && zero_n == 0) return TSS_OK;
+  hipLaunchKernelGGL(cast_weights_kernel, dim3(blocks_per_job, njobs + (zero_n > 0 ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, table,
+                     njobs, zero, zero_n);
   return tss::check_last("cast_weights");
 }
 
 int tss_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                    const float* lr, float beta1, float beta2, float eps, float weight_decay,
-                   float* state /*[3]: step, bc1, sqrt(bc2)*/, float grad_scale, void* stream) {
-  TSS_REQUIRE(n >= 0, TSS_ERR_SHAPE);
-  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+                   float* state /*[3]: step, bc1, sqrt(bc2)*/, float grad_scale, float lr_host, long step_host, void* stream) {
+  TSS_REQUIRE(n >= 0 && (state ? lr != nullptr : step_host >= 1), TSS_ERR_SHAPE);
+  float bc1 = 1.f, bc2s = 1.f;
+  if (state) hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, beta1, beta2);
+  else { bc1 = 1.f - powf(beta1, (float)step_host); bc2s = sqrtf(1.f - powf(beta2, (float)step_host)); }   // as adamw_tick_kernel
   if (n == 0) return tss::check_last("adamw_tick");
   long grid = (n + NT - 1) / NT;
   if (grid > 2048) grid = 2048;
   tss::ProfScope prof(TSS_K_ADAMW, (hipStream_t)stream, 28.0 * n, 12.0 * n);
   hipLaunchKernelGGL(adamw_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, params, grads, exp_avg,
-                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale);
+                     exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, state, grad_scale, lr_host, bc1, bc2s);
   return tss::check_last("adamw");
 }
 

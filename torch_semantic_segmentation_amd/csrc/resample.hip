@@ -484,6 +484,12 @@ __global__ __launch_bounds__(NT) void ppm_pool_bwd_kernel(const PpmArgs g) {
         }
       }
     }
+    if (g.x) {      // the other consumer of the pooled-from map (the concat's own copy of x): its gradient is added here, not by a launch of its own
+      float r[8];
+      V8<T>::load(reinterpret_cast<const T*>(g.x) + ((b * H + yy) * (long)W + xx) * g.ldx + cv * 8, r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += r[j];
+    }
     V8<T>::store(dx + ((b * H + yy) * (long)W + xx) * g.ldo + cv * 8, acc);
   }
 }
@@ -850,13 +856,14 @@ int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, c
 }
 
 int tss_ppm_pool_bwd(const void* const* dy, const long* lddy, const int* bins, int narms, void* dx, long lddx,
-                     int B, int H, int W, int C, int dtype, void* stream) {
+                     const void* radd, long ldr, int B, int H, int W, int C, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE((lddx % 8) == 0 && lddx >= C && tss::aligned16(dx), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!radd || ((ldr % 8) == 0 && ldr >= C && tss::aligned16(radd)), TSS_ERR_SHAPE);
   PpmArgs g = {};
   const int rc = ppm_fill(g, narms, bins, B, H, W, C, C);
   if (rc) return rc;
-  g.out = dx; g.ldo = lddx;
+  g.out = dx; g.ldo = lddx; g.x = radd; g.ldx = ldr;
   for (int a = 0; a < narms; ++a) {
     TSS_REQUIRE(dy[a] && (lddy[a] % 8) == 0 && lddy[a] >= C && tss::aligned16(dy[a]), TSS_ERR_SHAPE);
     g.raw[a] = dy[a]; g.ldr[a] = lddy[a];

@@ -57,7 +57,11 @@ class FlatAdamW(torch.optim.Optimizer):
                 off += k
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
-        self.state_vec = torch.zeros(3, dtype=torch.float32, device=dev)  # step, bias corrections
+        # step counter and learning rate: on the host (kernel arguments of ONE launch per step) unless device_state=True, which
+        # keeps them in device memory behind a tick kernel so that step() itself can be captured in a HIP graph
+        self.device_state = False
+        self.step_count = 0
+        self.state_vec = torch.zeros(3, dtype=torch.float32, device=dev)  # device_state: step, bias corrections
         self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.grad_scale = 1.0
 
@@ -69,9 +73,10 @@ class FlatAdamW(torch.optim.Optimizer):
         `p.grad = ...` detaches it; stepping would then silently apply zero gradients)."""
         off = 0
         base = self.flat_grad.data_ptr()
+        esz = self.flat_grad.element_size()
         for p in self.param_groups[0]['params']:
             g = p.grad
-            if g is None or g.data_ptr() != base + 4 * off:
+            if g is None or g.data_ptr() != base + esz * off:
                 raise RuntimeError('FlatAdamW: a parameter gradient no longer aliases the flat gradient buffer (was '
                                    'model.zero_grad(set_to_none=True) called?); use optimizer.zero_grad() or reattach()')
             off += p.numel()
@@ -87,19 +92,29 @@ class FlatAdamW(torch.optim.Optimizer):
     def state_dict(self):
         """torch.optim state_dict plus the flat moments and the device-side step counter (checkpoint / resume)."""
         sd = super().state_dict()
-        sd['flat'] = {'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(),
-                      'state_vec': self.state_vec.clone()}
+        sv = self.state_vec.clone()
+        if not self.device_state:
+            b1, b2 = self.param_groups[0]['betas']
+            k = float(self.step_count)
+            sv = torch.tensor([k, 1.0 - b1 ** k, (1.0 - b2 ** k) ** 0.5], dtype=torch.float32, device=sv.device)
+        sd['flat'] = {'exp_avg': self.exp_avg.clone(), 'exp_avg_sq': self.exp_avg_sq.clone(), 'state_vec': sv}
         return sd
 
     def load_state_dict(self, state_dict):
         state_dict = dict(state_dict)
         flat = state_dict.pop('flat', None)
+        if flat is None and state_dict.get('state'):
+            # a torch.optim.AdamW checkpoint (per-parameter exp_avg / exp_avg_sq / step): its moments would land in self.state and
+            # never be read -- a resume would silently restart the bias correction
+            raise ValueError('FlatAdamW.load_state_dict: this state_dict has per-parameter state but no flat moments (it was not '
+                             'written by FlatAdamW.state_dict()); pack it into the flat buffers before loading')
         super().load_state_dict(state_dict)
         if flat is not None:
             with torch.no_grad():
                 self.exp_avg.copy_(flat['exp_avg'])
                 self.exp_avg_sq.copy_(flat['exp_avg_sq'])
                 self.state_vec.copy_(flat['state_vec'])
+            self.step_count = int(round(float(flat['state_vec'][0])))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -107,12 +122,15 @@ class FlatAdamW(torch.optim.Optimizer):
         if not self.flat_param.is_cuda:
             raise RuntimeError('FlatAdamW runs on the HIP path only (no CPU fallback)')
         self._check_aliases()
-        self.lr_dev.fill_(float(g['lr']))
         b1, b2 = g['betas']
+        self.step_count += 1
+        if self.device_state:
+            self.lr_dev.fill_(float(g['lr']))
         N.call('tss_adamw_step', N.ptr(self.flat_param), N.ptr(self.flat_grad), N.ptr(self.exp_avg),
-               N.ptr(self.exp_avg_sq), self.flat_param.numel(), N.ptr(self.lr_dev), float(b1), float(b2),
-               float(g['eps']), float(g['weight_decay']), N.ptr(self.state_vec), float(self.grad_scale),
-               N.stream())
+               N.ptr(self.exp_avg_sq), self.flat_param.numel(), N.ptr(self.lr_dev) if self.device_state else None,
+               float(b1), float(b2), float(g['eps']), float(g['weight_decay']),
+               N.ptr(self.state_vec) if self.device_state else None, float(self.grad_scale), float(g['lr']),
+               int(self.step_count), N.stream())
 
 
 # ----------------------------------------------------------------------------- distributed helpers
@@ -179,6 +197,7 @@ class Trainer:
         # staged batch in place -- no device-to-device copy between the H2D copy and the step
         self._graphs = {}
         self._statics = {}
+        self._one = None
         self._next_slot = 1           # slot 0 is the trainer's own; new_slots() hands out the rest, never twice
         self._pool = None             # one private memory pool shared by the captured steps of all slots (they never run concurrently)
         self.iteration = 0
@@ -194,10 +213,14 @@ class Trainer:
         if prologue is not None:      # device-side preparation of (x, y), e.g. the uint8 decode: part of the captured step
             prologue()
         self.model.train()
-        self.optimizer.zero_grad()
         if self.shadows is None:
             self.shadows = ops.WeightShadows(self.model)
-        self.shadows.refresh()                       # the optimizer step of the previous iteration changed the weights
+        # the optimizer step of the previous iteration changed the weights: one launch rewrites their bf16 shadows AND clears the
+        # flat gradient buffer (optimizer.zero_grad() of TSS/engine.py:28)
+        if not self.shadows.refresh(zero=self.optimizer.flat_grad if self.flat else None):
+            self.optimizer.zero_grad()
+        if self._one is None or self._one.device != x.device:
+            self._one = torch.ones((), dtype=torch.float32, device=x.device)     # d(loss)/d(loss): no fill launch per step
         with ops.direct_grads(self.flat), self.shadows:
             if self.fuse_head_loss and not (self.model._forward_hooks or self.model._forward_pre_hooks):
                 low = self.model.forward_lowres(x)
@@ -206,7 +229,7 @@ class Trainer:
             else:
                 y_pred = self.model(x)
                 loss = self.loss_fn(y_pred, y)
-            loss.backward()
+            loss.backward(self._one if (loss.dtype == torch.float32 and loss.dim() == 0 and loss.device == self._one.device) else None)
         return loss
 
     def _reduce_and_step(self):

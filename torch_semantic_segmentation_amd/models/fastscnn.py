@@ -100,14 +100,20 @@ class PyramidPoolingModule(nn.Module):
             isinstance(a, FusedSequential) and len(a) == 2 and isinstance(a[0], nn.AdaptiveAvgPool2d)
             and isinstance(a[0].output_size, int) and not has_hooks(a) for a in arms)
         if plain:
-            pooled = ops.adaptive_avg_pool_multi(x, [a[0].output_size for a in arms])
+            # x feeds the pools and the concat: the concat's gradient of x is added inside the pools' backward kernel (ops.fork_two)
+            xp, xc, fork = ops.fork_two(x)
+            pooled = ops.adaptive_avg_pool_multi(xp, [a[0].output_size for a in arms])
+            x = xc
             # the arms' 1x1 convolutions + BatchNorm statistics: one launch for all arms (csrc/ppm.hip), else unit by unit
             ds = ops.ppm_arms([a[1] for a in arms], pooled)
             if ds is None:
                 ds = [run(a[1], Deferred(p)) for a, p in zip(arms, pooled)]
             if ops.ppm_arms_fusable(x, ds):
-                return self.conv(ops.concat_upsampled_arms(x, ds))
-            return self.conv(ops.concat_upsampled(x, ds))
+                cat = ops.concat_upsampled_arms(x, ds)
+            else:
+                cat = ops.concat_upsampled(x, ds)
+            ops.drop_fork(xp, xc)
+            return self.conv(cat)
         pools = [pool(x) for pool in arms]
         return self.conv(ops.concat_upsampled(x, pools))
 
@@ -162,11 +168,17 @@ class FastSCNN(HipModel):
         """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits.
         engine.Trainer feeds this to the fused upsample + cross-entropy operator."""
         downsample = self.downsample(self.image_in(input))
-        features = self.features(downsample)
+        # `downsample` has two consumers (the feature extractor and the fusion module's high-resolution layer): the gradient of the
+        # latter is added in the epilogue of the former's first backward-data kernel, not by an elementwise launch (ops.fork_two)
+        hooked = has_hooks(self.features) or has_hooks(self.fusion)
+        da, db, fork = (downsample, downsample, None) if hooked else ops.fork_two(downsample)
+        features = self.features(da)
         # (the fusion module's high-resolution 1x1 layer only needs `downsample` and could run on a side stream under the feature
         # extractor, as ContextNet's context branch does: measured, 5.58 vs 5.45 ms per step -- it competes with, rather than hides
         # under, the 1/16-resolution kernels; not done)
-        fusion = self.fusion(features, downsample)
+        fusion = self.fusion(features, db)
+        if fork is not None:
+            ops.drop_fork(da, db)
         return self.classifier(fusion)
 
     def forward(self, input):

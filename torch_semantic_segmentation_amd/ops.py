@@ -219,6 +219,26 @@ def residual_fork(x):
     return xa, xb, fork
 
 
+_pending_stash = {}
+
+
+def fork_two(x):
+    """(xa, xb, fork) for a materialised activation with TWO consumers whose gradients would otherwise meet in an elementwise launch of
+    autograd's: the consumer of xb (created later, so its backward runs first) leaves its input gradient in fork.g2, the 1x1 layer
+    that consumes xa adds it in the epilogue of its backward-data kernel (tss_pwconv_bwd_data_radd) -- or, for pooled maps,
+    tss_ppm_pool_bwd does.  Falls back to autograd's add whenever a side cannot take part.  (x, x, None) when nothing is folded."""
+    xa, xb, fork = residual_fork(x)
+    if fork is not None:
+        _pending_stash[id(xb)] = fork          # picked up by the operator that consumes xb
+    return xa, xb, fork
+
+
+def drop_fork(xa, xb):
+    """Forget fork registrations nobody picked up (a consumer outside the envelope): ids may be recycled."""
+    _pending_forks.pop(id(xa), None)
+    _pending_stash.pop(id(xb), None)
+
+
 # independent branches of a model (ContextNet's spatial / context branches) on two streams: parallel branches of the captured graph
 overlap_branches = os.environ.get('TSS_OVERLAP_BRANCHES', '1') != '0'     # measured: ContextNet14 step 6.34 -> 6.27 ms
 
@@ -279,12 +299,18 @@ class WeightShadows:
         self.table = torch.tensor(table, dtype=torch.int64, device=dev)
         self.blocks = max(1, min(64, (max(n * k for _, _, n, k in rows) + 255) // 256))
 
-    def refresh(self):
+    def refresh(self, zero=None):
+        """Rewrite the shadows from the live weights.  `zero` (a contiguous float32 tensor, e.g. the flat gradient buffer) is
+        cleared by the same launch.  Returns True when `zero` was cleared here."""
         if self.table is not None:
             for p in self.weights:                                        # parameters re-pointed since construction?
                 if p.data_ptr() not in self.entries:
                     raise RuntimeError('WeightShadows: a parameter was reallocated; rebuild the shadows')
-            call('tss_cast_weights', ptr(self.table), self.table.shape[0], self.blocks, stream())
+            fold = zero is not None and zero.dtype == torch.float32 and zero.is_contiguous() and zero.device == self.table.device
+            call('tss_cast_weights', ptr(self.table), self.table.shape[0], self.blocks, ptr(zero) if fold else None,
+                 zero.numel() if fold else 0, stream())
+            return fold
+        return False
 
     def __enter__(self):
         self.prev = dict(_SHADOWS)
@@ -542,7 +568,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params', 'res_fork')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork')
 
 
 def _classify(conv, x_is_image):
@@ -594,7 +620,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         cfg.in_link, cfg.in_relu = None, False
         cfg.image_f32 = x_raw.dtype == torch.float32
         cfg.out_dtype = out_dtype or x_raw.dtype
-        cfg.res_fork = None
+        cfg.res_fork = cfg.stash_fork = None
     else:
         d = as_deferred(x).take()
         x_raw = d.raw
@@ -602,6 +628,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         cfg.image_f32 = False
         cfg.out_dtype = x_raw.dtype
         cfg.res_fork = _pending_forks.pop(id(x_raw), None) if _pending_forks else None
+        cfg.stash_fork = _pending_stash.pop(id(x_raw), None) if _pending_stash else None
     if x_raw.shape[1] != conv.in_channels:
         raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
     cfg.bn = bn
@@ -923,6 +950,9 @@ class ConvUnitFn(Function):
                         call('tss_permute_w3x3', ptr(weight), None, ptr(w_tcn), Cout, Cin, st)
                     call('tss_conv3x3_bwd_data', *gargs, ptr(w_tcn), ptr(w_tcn16), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cin, Cout, d, dt, st)
+        stash = getattr(cfg, 'stash_fork', None)
+        if stash is not None and e_in is not None and not deferred_in:
+            stash.g2 = e_in                # the other consumer of this layer's input adds it in its own backward (fork_two)
         dbias_ret = fused_dbias
         if ctx.has_bias and not (fused_pw and need_dx):
             dbias = _direct_target(p_bias)
@@ -961,6 +991,7 @@ def _plain_unit_cfg(conv, bn, kind, stride, in_link, in_relu, dtype):
     cfg.in_link, cfg.in_relu, cfg.image_f32, cfg.out_dtype = in_link, in_relu, False, dtype
     cfg.bn, cfg.training = bn, True
     cfg.params = (conv.weight, bn.weight, bn.bias, None)
+    cfg.res_fork = cfg.stash_fork = None
     return cfg
 
 
@@ -1482,12 +1513,14 @@ def _hi(vals):
 def adaptive_avg_pool_multi(x, bins):
     """[AdaptiveAvgPool2d(b)(x) for b in bins] from one launch (and one launch for the summed gradient)."""
     x = to_nhwc(materialize(x))
-    return PoolMultiFn.apply(x, tuple(int(b) for b in bins))
+    fork = _pending_forks.pop(id(x), None) if _pending_forks else None      # x has another consumer (fork_two): its gradient is added in our backward
+    return PoolMultiFn.apply(x, tuple(int(b) for b in bins), fork)
 
 
 class PoolMultiFn(Function):
     @staticmethod
-    def forward(ctx, x, bins):
+    def forward(ctx, x, bins, fork=None):
+        ctx.fork = fork
         B, C, H, W = x.shape
         ys = [new_nhwc(B, C, b, b, x.dtype, x.device) for b in bins]
         ncells = sum(b * b for b in bins)
@@ -1503,9 +1536,15 @@ class PoolMultiFn(Function):
         B, C, H, W, bins, dtype, dev = ctx.geom
         dys = [to_nhwc(d) if d is not None else new_nhwc(B, C, b, b, dtype, dev).zero_() for d, b in zip(dys, bins)]
         dx = new_nhwc(B, C, H, W, dtype, dev)
-        call('tss_ppm_pool_bwd', _hp(dys), _hl([ld(d) for d in dys]), _hi(bins), len(bins), ptr(dx), ld(dx), B, H, W, C,
-             N.dtype_code(dtype), stream())
-        return dx, None
+        fork = ctx.fork
+        radd = fork.g2 if fork is not None else None
+        if radd is not None and not (radd.dtype == dtype and tuple(radd.shape) == (B, C, H, W) and is_nhwc(radd)):
+            radd = None
+        call('tss_ppm_pool_bwd', _hp(dys), _hl([ld(d) for d in dys]), _hi(bins), len(bins), ptr(dx), ld(dx),
+             ptr(radd), ld(radd) if radd is not None else 0, B, H, W, C, N.dtype_code(dtype), stream())
+        if radd is not None:
+            fork.consumed = True
+        return dx, None, None
 
 
 def ppm_arms_fusable(x, arms):
@@ -1523,6 +1562,7 @@ def concat_upsampled_arms(x, arms):
     x = to_nhwc(materialize(x))
     ds = [a.take() for a in arms]
     cfg = JoinCfg()
+    cfg.res_fork = _pending_stash.pop(id(x), None) if _pending_stash else None
     cfg.links = [d.link for d in ds]
     cfg.relus = [bool(d.relu) for d in ds]
     return PpmConcatFn.apply(x, cfg, *[d.raw for d in ds])
@@ -1556,6 +1596,9 @@ class PpmConcatFn(Function):
         call('tss_ppm_concat_bwd', ptr(dout), ld(dout), _hp(raws), _hl([ld(r) for r in raws]), _hi(bins),
              *PpmConcatFn._tables(ctx.cfg), _hp([l.bstats if l is not None else None for l in ctx.cfg.links]),   # (None: sums taken on chip by ppm_arms)
              _hp(es), _hl([ld(e) for e in es]), len(raws), B, H, W, C, ca, N.dtype_code(dout.dtype), stream())
+        stash = getattr(ctx.cfg, 'res_fork', None)
+        if stash is not None:
+            stash.g2 = dout[:, :C]         # x's other consumer (the pools) adds it in tss_ppm_pool_bwd (fork_two)
         return (dout[:, :C], None, *es)
 
 
@@ -1776,20 +1819,21 @@ class UpsampleCrossEntropyFn(Function):
         target = target.contiguous()
         nws = N.lib().tss_upsample_ce_ws(B, C, h, w, ho, wo)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
-        scal = torch.empty(2, dtype=torch.float32, device=dev)
-        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(ws), ptr(scal[0:1]),
-             ptr(scal[1:2]), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
+        loss = torch.empty((), dtype=torch.float32, device=dev)        # written by the kernel: no copy launch for the return value
+        inv = torch.empty(1, dtype=torch.float32, device=dev)
+        call('tss_upsample_ce_fwd', ptr(low), ld(low), ptr(target), ptr(ws), ptr(loss),
+             ptr(inv), B, C, h, w, ho, wo, int(ignore_index), N.dtype_code(low.dtype), stream())
         ctx.geom = (B, C, h, w, ho, wo, ld(low), low.dtype)
-        ctx.save_for_backward(ws, scal)
-        return scal[0].clone()
+        ctx.save_for_backward(ws, inv)
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
-        ws, scal = ctx.saved_tensors
+        ws, inv = ctx.saved_tensors
         B, C, h, w, ho, wo, ldl, dtype = ctx.geom
         gout = gout.to(torch.float32).contiguous()
         base = torch.empty((B, h, w, ldl), dtype=dtype, device=ws.device)   # pad channels are written as zeros
-        call('tss_upsample_ce_bwd', ptr(ws), ptr(scal[1:2]), ptr(gout), ptr(base), ldl, B, C, h, w, ho, wo,
+        call('tss_upsample_ce_bwd', ptr(ws), ptr(inv), ptr(gout), ptr(base), ldl, B, C, h, w, ho, wo,
              N.dtype_code(dtype), stream())
         return base.permute(0, 3, 1, 2)[:, :C], None, None, None, None
 
