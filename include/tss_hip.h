@@ -62,6 +62,7 @@ enum {
 
 /* ---- library / diagnostics --------------------------------------------------------------------------- */
 int tss_version(void);                 /* ABI version of this header */
+int tss_memset_zero(void* p, long bytes, void* stream);   /* diagnostic: hipMemsetAsync (a memset NODE under capture), see DESIGN.md section 4 */
 const char* tss_last_error(void);      /* text of the last HIP error seen by this library (thread-local) */
 const char* tss_arch(void);            /* "gfx950" */
 #define TSS_OPT_DISABLE_FAST_PATHS 1   /* value 1: bf16 calls use the general kernels only (A/B checks of the lean ones) */

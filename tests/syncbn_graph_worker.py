@@ -40,7 +40,21 @@ if __name__ == '__main__':
         if mode == 'sync':
             captured = tr._graph is not None and tr.use_graph
             warning = '; '.join(str(w.message) for w in caught)
+    # the gradient all-reduce captured INSIDE the step (Trainer(graph_allreduce=True)): the replayed step must give
+    # the trajectory of the eager-collective trainer, with the collective gone from the host side of the step
+    ar = {}
+    for mode in ('graph_allreduce', 'eager_allreduce'):
+        torch.manual_seed(0)
+        m = fastscnn(3, 19).to(dev)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        tssa.set_compute_dtype(m, torch.bfloat16)      # the benchmarked kernels: no atomics, so the two trajectories must be bit-identical
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=True, graph_allreduce=(mode == 'graph_allreduce'))
+        ar[mode] = [tr.step_async(x, y).item() for _ in range(4)]
+        ar[mode + '_captured'] = bool(tr.use_graph and tr._reduce_captured)
     torch.save({'losses_sync': curves['sync'], 'losses_local': curves['local'], 'captured': captured, 'warning': warning,
-                'sync_layers': n_sync}, sys.argv[1])
+                'sync_layers': n_sync, 'allreduce': ar}, sys.argv[1])
     dist.barrier()
     dist.destroy_process_group()

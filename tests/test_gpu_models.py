@@ -220,8 +220,9 @@ def test_flat_adamw_and_graph_replay_match_eager():
         assert other[3] == base[3] == 3
 
 
+@pytest.mark.parametrize('hw', [(128, 256), (64, 128)])
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
-def test_captured_step_is_bit_reproducible_and_scheduling_is_exact(name):
+def test_captured_step_is_bit_reproducible_and_scheduling_is_exact(name, hw):
     """the benchmarked step (bf16, fused head + loss, HIP-graph replay) has no atomics and no
     order-dependent sums left -- two replays on the same batch from the same weights give BIT-IDENTICAL flat gradients,
     losses and BatchNorm statistics; and the backward-pass scheduling (weight gradients postponed so that the next
@@ -230,7 +231,7 @@ def test_captured_step_is_bit_reproducible_and_scheduling_is_exact(name):
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import engine as E
     from torch_semantic_segmentation_amd import ops
-    x, y = synthetic_batch(2, 128, 256)
+    x, y = synthetic_batch(2, *hw)
     x, y = x.to(DEV), y.to(DEV)
 
     def run(use_graph, postpone):
@@ -374,6 +375,10 @@ def test_syncbn_step_is_captured_in_a_hip_graph_with_rccl(tmp_path):
     print('SyncBatchNorm step: captured =', got['captured'], ' losses', got['losses_sync'], got['losses_local'])
     assert np.allclose(got['losses_sync'], got['losses_local'], rtol=2e-3)
     assert got['captured'], 'the SyncBatchNorm step fell back to un-captured launches: ' + got['warning']
+    # the gradient all-reduce inside the captured step (opt-in), one-rank RCCL group: captured, replayed, same numbers
+    ar = got['allreduce']
+    assert ar['graph_allreduce_captured'] and not ar['eager_allreduce_captured']
+    assert ar['graph_allreduce'] == ar['eager_allreduce'], ar
 
 
 def test_reference_training_recipe_runs_on_the_hip_path():

@@ -86,6 +86,14 @@ ProfScope::~ProfScope() {
 extern "C" {
 
 int tss_version(void) { return 1; }
+
+// hipMemsetAsync on the launch stream (a MEMSET node when the stream is being captured).  Only used by tools/graph_memset_probe.py
+// and the engine's TSS_MEMSET_NODES=1 diagnostic: the product clears its buffers from kernels (see tss_cast_weights).
+int tss_memset_zero(void* p, long bytes, void* stream) {
+  if (!p || bytes <= 0) return TSS_OK;
+  if (hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream) != hipSuccess) return TSS_ERR_HIP;
+  return tss::check_last("memset_zero");
+}
 const char* tss_last_error(void) { return g_err; }
 const char* tss_arch(void) { return "gfx950"; }
 

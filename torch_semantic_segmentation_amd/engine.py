@@ -168,7 +168,7 @@ def allreduce_mean_(flat, world_size, group=None):
 
 class Trainer:
     def __init__(self, model, optimizer, loss_fn, device=None, use_graph=False, world_size=None,
-                 non_blocking=True, fuse_head_loss=True):
+                 non_blocking=True, fuse_head_loss=True, graph_allreduce=None):
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.device = device
         self.non_blocking = non_blocking
@@ -192,6 +192,16 @@ class Trainer:
         if self.flat:
             optimizer.grad_scale = 1.0 / world_size
         self.shadows = None
+        # The gradient all-reduce INSIDE the captured step (RCCL collectives on the capturing stream are recorded into the HIP
+        # graph): the step is then replay + optimizer, nothing else on the host.  Opt-in (argument or TSS_GRAPH_ALLREDUCE=1):
+        # validated on hardware with a one-rank RCCL group only -- a multi-GPU node was never available to this repo -- so the
+        # default keeps the collective an ordinary eager launch behind the replay, which is the form the 8-GPU run depends on.
+        if graph_allreduce is None:
+            graph_allreduce = os.environ.get('TSS_GRAPH_ALLREDUCE') == '1'
+        self.graph_allreduce = bool(graph_allreduce) and self.flat and dist.is_available() and dist.is_initialized() \
+            and dist.get_backend() == 'nccl'
+        self._reduce_captured = False
+        self._collectives_in_graph = False
         # captured steps, one per input slot: slot -> (graph, loss tensor).  Slot 0 is the ordinary one; a loader that
         # double-buffers its batches (HostBatchPipeline) captures one step per staging slot so that the step reads the
         # staged batch in place -- no device-to-device copy between the H2D copy and the step
@@ -217,7 +227,12 @@ class Trainer:
             self.shadows = ops.WeightShadows(self.model)
         # the optimizer step of the previous iteration changed the weights: one launch rewrites their bf16 shadows AND clears the
         # flat gradient buffer (optimizer.zero_grad() of TSS/engine.py:28)
-        if not self.shadows.refresh(zero=self.optimizer.flat_grad if self.flat else None):
+        if self.flat and os.environ.get('TSS_MEMSET_NODES') == '1':
+            # diagnostic only (tools/graph_memset_probe.py): the gradient buffer cleared by a memset NODE
+            g = self.optimizer.flat_grad
+            N.call('tss_memset_zero', N.ptr(g), g.numel() * g.element_size(), N.stream())
+            self.shadows.refresh()
+        elif not self.shadows.refresh(zero=self.optimizer.flat_grad if self.flat else None):
             self.optimizer.zero_grad()
         if self._one is None or self._one.device != x.device:
             self._one = torch.ones((), dtype=torch.float32, device=x.device)     # d(loss)/d(loss): no fill launch per step
@@ -232,8 +247,10 @@ class Trainer:
             loss.backward(self._one if (loss.dtype == torch.float32 and loss.dim() == 0 and loss.device == self._one.device) else None)
         return loss
 
-    def _reduce_and_step(self):
-        if self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
+    def _reduce_and_step(self, captured_reduce=False):
+        if captured_reduce:
+            pass                # the all-reduce of the flat gradient buffer was replayed with the step
+        elif self.world_size > 1 or (dist.is_available() and dist.is_initialized()):
             if self.flat:
                 allreduce_mean_(self.optimizer.flat_grad, self.world_size)
             else:
@@ -295,7 +312,8 @@ class Trainer:
         with torch.no_grad():
             for b, v in saved:
                 b.copy_(v)
-        graph = torch.cuda.CUDAGraph()
+        dot = getattr(self, 'debug_dot', None)       # tools/graph_memset_probe.py: hipGraphDebugDotPrint of the captured step
+        graph = torch.cuda.CUDAGraph(keep_graph=True) if dot else torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         # with a live RCCL process group its watchdog thread polls events while we capture: in the default 'global' capture
@@ -303,7 +321,21 @@ class Trainer:
         mode = 'thread_local' if (dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl') else 'global'
         with torch.cuda.graph(graph, pool=self._pool, capture_error_mode=mode):
             loss = self._forward_backward(sx, sy, prologue).detach()
+            if self.graph_allreduce:
+                allreduce_mean_(self.optimizer.flat_grad, self.world_size)
         self._graphs[slot] = (graph, loss)
+        self._reduce_captured = self.graph_allreduce
+        if dot:
+            try:        # the captured hipGraph_t straight to the runtime's own printer
+                import ctypes
+                hip = ctypes.CDLL('libamdhip64.so')
+                hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+                rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(graph.raw_cuda_graph()), dot.encode(), 1)   # 1 = verbose
+                if rc != 0:
+                    raise RuntimeError('hipGraphDebugDotPrint returned %d' % rc)
+            except Exception as exc:      # noqa: BLE001
+                import warnings
+                warnings.warn('graph dot dump failed: %s' % exc)
 
     def step_async(self, x, y, slot=0, prologue=None):
         """One training iteration; returns the loss as a device tensor (no host sync).  `slot` selects one of several
@@ -322,24 +354,31 @@ class Trainer:
                 warnings.warn('SyncBatchNorm over the %s backend: the training step is not captured in a HIP graph' % backend)
                 self.use_graph = False
             else:
+                self._collectives_in_graph = True
+        if self.use_graph and slot not in self._graphs:
+            if self._collectives_in_graph or self.graph_allreduce:
+                # a step with RCCL collectives inside: if ANY slot's capture fails, every slot runs un-captured from then on
+                # (correct, ~10^3 host launches per step) -- one decision per trainer, taken by whichever slot captures first
                 try:
                     self._capture(x, y, slot, prologue)
                 except Exception as exc:      # noqa: BLE001 -- any capture failure: fall back, loudly
-                    warnings.warn('SyncBatchNorm: HIP-graph capture of the step failed (%s: %s); running un-captured'
+                    import warnings
+                    warnings.warn('HIP-graph capture of a step with RCCL collectives failed (%s: %s); running un-captured'
                                   % (type(exc).__name__, exc))
-                    self._graphs.pop(slot, None)
+                    self._graphs.clear()
                     self.use_graph = False
+                    self._reduce_captured = False
                     torch.cuda.synchronize()
-        if self.use_graph:
-            if slot not in self._graphs:
-                self._capture(x, y, slot, prologue)
             else:
-                self.static_batch(x, y, slot)
+                self._capture(x, y, slot, prologue)
+        elif self.use_graph:
+            self.static_batch(x, y, slot)
+        if self.use_graph:
             graph, loss = self._graphs[slot]
             graph.replay()
         else:
             loss = self._forward_backward(x, y, prologue).detach()
-        self._reduce_and_step()
+        self._reduce_and_step(captured_reduce=self.use_graph and self._reduce_captured)
         self.iteration += 1
         return loss
 

@@ -140,7 +140,8 @@ class ContextNet(HipModel):
         # all-reduces would be issued from two streams onto one communicator, in an order that can differ between the ranks
         if has_hooks(self.context) or has_hooks(self.spatial):
             return False
-        return not any(isinstance(m, ops.SyncBatchNorm) for m in self.modules())
+        # (torch.nn.SyncBatchNorm too: ops._sync_group activates cross-replica statistics for both classes)
+        return not any(isinstance(m, (ops.SyncBatchNorm, torch.nn.SyncBatchNorm)) for m in self.modules())
 
     def forward_lowres(self, input):
         """Everything up to (not including) the final x8 upsample: (B, classes, H/8, W/8) logits."""
