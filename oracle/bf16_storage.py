@@ -39,20 +39,47 @@ def round_bf16(x):
     return _RoundBF16.apply(x)
 
 
+# ---- noise model of the storage format.  Which of its two bf16 neighbours a stored value lands on depends on accumulation
+# order (a kernel sums its f32 products in another order than this oracle sums its f64 ones), i.e. for the purpose of a bound
+# it is a coin that is the more biased the closer the exact value sits to one neighbour.  Dithered rounding draws exactly that
+# coin: bf16(x + u * ulp(x)), u uniform in (-1/2, 1/2).  Two oracle runs with independent draws differ by what two CORRECT
+# implementations of the same storage format may differ by -- including the ReLU masks that flip where a pre-activation
+# rounds across zero -- and tests/test_gpu_lean_vs_oracle.py bounds every kernel by a multiple of that distance, tensor by
+# tensor, instead of by a cap read off a previous run.
+class _DitherBF16(torch.autograd.Function):
+    @staticmethod
+    def _dither(x, gen):
+        ax = x.abs().clamp_min(torch.finfo(torch.float64).tiny if x.dtype == torch.float64 else 1e-38)
+        ulp = torch.exp2(torch.floor(torch.log2(ax)) - 7.0)           # bf16: 8 significant bits
+        u = torch.rand(x.shape, generator=gen, dtype=x.dtype) - 0.5
+        return (x + u * ulp).to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def forward(ctx, x, gen):
+        ctx.gen = gen
+        return _DitherBF16._dither(x, gen)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _DitherBF16._dither(g, ctx.gen), None
+
+
 _STORED = (nn.Conv2d, nn.AdaptiveAvgPool2d, nn.UpsamplingBilinear2d, nn.Upsample,
            nets.InvertedResidual, nets.Pyramid, nets.FastFusion, nets.CtxFusion)
 
 
-def emulate_bf16_storage(module, root=True):
+def emulate_bf16_storage(module, root=True, dither=None):
     """Register forward hooks on `module` (an oracle module tree) that round the tensors the bf16 HIP path stores.
+    `dither`: a torch.Generator -- round with the noise model above (independent draws per tensor) instead of to nearest.
     Returns the hook handles (call .remove() on each to undo)."""
     handles = []
+    rnd = round_bf16 if dither is None else (lambda t: _DitherBF16.apply(t, dither))
 
     def hook(_m, _inp, out):
-        return round_bf16(out) if torch.is_tensor(out) else out
+        return rnd(out) if torch.is_tensor(out) else out
 
     def pre_hook(_m, inp):
-        return tuple(round_bf16(t) if torch.is_tensor(t) and t.is_floating_point() else t for t in inp)
+        return tuple(rnd(t) if torch.is_tensor(t) and t.is_floating_point() else t for t in inp)
     for m in module.modules():
         if isinstance(m, _STORED) or (root and m is module):
             handles.append(m.register_forward_hook(hook))

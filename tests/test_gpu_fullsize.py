@@ -128,6 +128,89 @@ def test_config1_fastscnn_train_step_gradients_vs_f64_oracle():
     assert e_hip <= max(2e-3, 3 * e_ref32), (e_hip, e_ref32)
 
 
+def test_config1_contextnet14_train_step_gradients_vs_f64_oracle():
+    """ContextNet14 had no whole-gradient check at config 1.  Forward + CE + backward in f32 against the f64
+    oracle: the loss to 1e-5; the whole 1.1 M-element gradient within 3x the f32 oracle's own distance from f64 (its 40-layer
+    context branch amplifies rounding: that distance is ~0.1 and is printed -- the yardstick, not a tolerance we chose); and the
+    part of the gradient that does NOT pass through the context branch (classifier, fusion module, spatial branch: the
+    well-conditioned tensors) under an absolute 5e-3."""
+    import torch_semantic_segmentation_amd as tssa
+    x, y = synthetic_batch(4, 512, 1024)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=255)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(0)
+        m = O.build('contextnet14')
+        cases.zero_dropout(m)
+        m.to(dt).train()
+        loss = loss_fn(m(x.to(dt)), y)
+        loss.backward()
+        grads[dt] = ({n: p.grad.double() for n, p in m.named_parameters()}, loss.item())
+    _, hip = _pair('contextnet14')
+    hip.train()
+    loss_h = tssa.cross_entropy(hip(x.to(DEV)), y.to(DEV), ignore_index=255)
+    loss_h.backward()
+    gh = {n: p.grad.double().cpu() for n, p in hip.named_parameters()}
+    g32, g64 = grads[torch.float32][0], grads[torch.float64][0]
+    cat = lambda d, keys: torch.cat([d[k].flatten() for k in keys])      # noqa: E731
+    allk = list(g64)
+    e_ref32 = ((cat(g32, allk) - cat(g64, allk)).norm() / cat(g64, allk).norm()).item()
+    e_hip = ((cat(gh, allk) - cat(g64, allk)).norm() / cat(g64, allk).norm()).item()
+    good = [k for k in allk if k.startswith(('classifier.', 'feature_fusion.', 'spatial.'))]
+    e_ref32_good = ((cat(g32, good) - cat(g64, good)).norm() / cat(g64, good).norm()).item()
+    e_hip_good = ((cat(gh, good) - cat(g64, good)).norm() / cat(g64, good).norm()).item()
+    print('config-1 ContextNet14 gradients: whole |hip - f64| %.3e (oracle f32: %.3e); without the context branch (%d tensors) '
+          '|hip - f64| %.3e (oracle f32: %.3e)' % (e_hip, e_ref32, len(good), e_hip_good, e_ref32_good))
+    assert abs(loss_h.item() / grads[torch.float64][1] - 1) < 1e-5
+    assert e_hip <= max(2e-3, 3 * e_ref32), (e_hip, e_ref32)
+    assert e_hip_good <= max(5e-3, 3 * e_ref32_good), (e_hip_good, e_ref32_good)
+
+
+def test_config2_full_size_f32_train_step_vs_cpu_oracle():
+    """the full-size anchor.  BASELINE config 2's workload, 8 x 3 x 1024 x 2048, in f32 through the general
+    kernels (the path the bf16 full-size test uses as ITS reference) against the CPU oracle itself, one step: the loss to 1e-5
+    of the f64 oracle, and every `classifier.*` gradient (the well-conditioned end of the network) against the f64 oracle within
+    max(1e-3, 3 x the f32 oracle's own distance from f64) -- two f32 implementations of a 16.8 M-pixel sum differ by ~1e-3 from
+    each other, measured here and printed, so the yardstick is the reference's own rounding, not a number we picked.  BatchNorm
+    biases in front of (linear conv -> BatchNorm) have an analytically zero gradient: errors are measured against at least 1 %
+    of the largest gradient RMS of the same kind.  ~50 GB of host memory and ~60 s of CPU time for the oracle's two steps."""
+    import torch_semantic_segmentation_amd as tssa
+    x, y = synthetic_batch(8, 1024, 2048)
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(0)
+        m = O.build('fastscnn')
+        cases.zero_dropout(m)
+        m.to(dt).train()
+        loss = nn.functional.cross_entropy(m(x.to(dt)), y, ignore_index=255)
+        loss.backward()
+        grads[dt] = ({n: p.grad.double().clone() for n, p in m.named_parameters() if n.startswith('classifier.')}, loss.item())
+        del m, loss
+    _, hip = _pair('fastscnn')
+    hip.train()
+    loss_h = tssa.cross_entropy(hip(x.to(DEV)), y.to(DEV), ignore_index=255)
+    loss_h.backward()
+    g32, g64 = grads[torch.float32][0], grads[torch.float64][0]
+    assert abs(loss_h.item() / grads[torch.float64][1] - 1) < 1e-5, (loss_h.item(), grads[torch.float64][1])
+    kind = lambda n, t: 'w' if t.dim() == 4 else ('gamma' if n.endswith('weight') else 'beta')      # noqa: E731
+    top = {}
+    for n, t in g64.items():
+        top[kind(n, t)] = max(top.get(kind(n, t), 0.0), (t.norm() / t.numel() ** 0.5).item())
+    rows, bad = [], []
+    for n, p in hip.named_parameters():
+        if n in g64:
+            den = max(g64[n].norm().item(), 1e-2 * top[kind(n, g64[n])] * g64[n].numel() ** 0.5)
+            e_hip = ((p.grad.double().cpu() - g64[n]).norm() / den).item()
+            e_ref = ((g32[n] - g64[n]).norm() / den).item()
+            rows.append((e_hip, e_ref, n))
+            if e_hip > max(1e-3, 3 * e_ref):
+                bad.append((n, e_hip, e_ref))
+    rows.sort(reverse=True)
+    print('config-2 (8 x 3 x 1024 x 2048) f32 vs the f64 CPU oracle: loss %.6f vs %.6f; classifier gradients (hip, oracle-f32), worst first: %s'
+          % (loss_h.item(), grads[torch.float64][1], ['%s %.2e %.2e' % (n, a, b) for a, b, n in rows[:6]]))
+    assert len(rows) >= 10 and not bad, bad
+
+
 # Parameters whose gradients are WELL CONDITIONED at this size: everything downstream of the last tiny-sample BatchNorm.
 # FastSCNN's pyramid arm with bin 1 normalises over B = 8 values per channel, ContextNet's context branch is a 40-layer
 # chain of batch-statistics BatchNorms on 1/32-1/128 maps: gradients that flow back through them amplify rounding by

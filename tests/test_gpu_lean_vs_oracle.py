@@ -49,6 +49,11 @@ DIRECT = 5e-3       # lean against general on the same operands: accumulation or
 # BatchNorm-per-tap upsample is approximate.  Looser caps, same yardstick rule.
 CAP_BLOCK = {'out': 1e-2, 'dx': 6e-2, 'dw': 6e-2, 'dgamma': 8e-2, 'dbeta': 8e-2, 'stat': 1e-3}
 DIRECT_BLOCK = 6e-2
+# the derived bound: NOISE_K x the oracle-vs-oracle distance under dithered bf16 storage (+ a floor for tensors the noise model
+# leaves exactly equal: running statistics are f32 sums of identical numbers on both oracle runs only up to the dither)
+NOISE_K = 3.0
+NOISE_FLOOR = {'out': 2e-4, 'dx': 2e-4, 'dw': 2e-4, 'dgamma': 2e-4, 'dbeta': 2e-4, 'stat': 2e-5}
+_NOISE = [None]
 _ROWS = []
 
 
@@ -119,6 +124,16 @@ def run_case(spec, shape, seed=0):
     cot = bf16_round_(torch.randn(*out_r.shape, generator=g) * 0.5 + 0.1)
     out_r.backward(cot.double())
 
+    def noisy(noise_seed):      # the same oracle with the storage format's noise model (oracle/bf16_storage.py, dithered rounding)
+        r2 = oracle_chain(spec)
+        r2.load_state_dict(state, strict=True)
+        r2.double().train()
+        emulate_bf16_storage(r2, dither=torch.Generator().manual_seed(noise_seed))
+        x2 = x.double().requires_grad_(shape[1] % 8 == 0)
+        o2 = r2(x2)
+        o2.backward(cot.double())
+        return r2, o2, x2
+
     def collect(model, out, xg):
         res = {'out': out.detach().double().cpu().numpy()}
         if xg is not None:
@@ -131,6 +146,8 @@ def run_case(spec, shape, seed=0):
                 res['stat:' + n] = b.detach().double().cpu().numpy()
         return res
     want = collect(ref, out_r, xr.grad)
+    (ra, oa, xa), (rb, ob, xb) = noisy(1001 + seed), noisy(2002 + seed)
+    _NOISE[0] = (collect(ra, oa, xa.grad), collect(rb, ob, xb.grad))
 
     def hip(disable_fast):
         m = product_chain(spec)
@@ -152,8 +169,12 @@ def run_case(spec, shape, seed=0):
 
 
 def check(case, want, lean, general, cap=None, direct=None):
+    """Per tensor: err_lean <= NOISE_K x (distance of two oracle runs under the storage format's noise model) -- a bound DERIVED
+    for this case and this tensor, not a cap read off an earlier run; the caps stay as a ceiling, the
+    general kernels' error as a printed yardstick, lean against general as before."""
     cap = cap or CAP
     direct = DIRECT if direct is None else direct
+    noise_a, noise_b = _NOISE[0]
     bad = []
     # a BatchNorm bias in front of (linear conv -> BatchNorm) has an analytically zero gradient: whatever the three runs
     # hold there is rounding noise.  Errors of dgamma / dbeta are therefore measured against at least 1 % of the largest
@@ -169,10 +190,11 @@ def check(case, want, lean, general, cap=None, direct=None):
     for k in want:
         kind = k.split(':')[0]
         e_lean, e_gen, e_dir = l2f(lean[k], want[k], kind), l2f(general[k], want[k], kind), l2f(lean[k], general[k], kind)
-        bound = min(2.0 * e_gen + FLOOR, cap[kind])
+        e_noise = l2f(noise_a[k], noise_b[k], kind)
+        bound = min(NOISE_K * e_noise + NOISE_FLOOR[kind], cap[kind])
         ok = e_lean <= bound and e_dir <= direct
-        _ROWS.append('%-30s %-30s lean %.3e  general %.3e  bound %.3e  lean-vs-general %.3e%s'
-                     % (case, k, e_lean, e_gen, bound, e_dir, '' if ok else '  <-- FAIL'))
+        _ROWS.append('%-30s %-30s lean %.3e  general %.3e  noise %.3e  bound %.3e  lean-vs-general %.3e%s'
+                     % (case, k, e_lean, e_gen, e_noise, bound, e_dir, '' if ok else '  <-- FAIL'))
         if not ok:
             bad.append((k, e_lean, e_gen, bound, e_dir))
     return bad
@@ -187,8 +209,8 @@ def teardown_module(module):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         os.makedirs(os.path.join(root, 'gpurun_out'), exist_ok=True)
         with open(os.path.join(root, 'gpurun_out', 'lean_parity.txt'), 'w') as f:
-            f.write('# relative L2 error against the f64 CPU oracle on bf16-representable operands; bound = min(2*general + %.1e, cap)\n'
-                    % FLOOR)
+            f.write('# relative L2 error against the f64 CPU oracle on bf16-representable operands; noise = distance of two oracle runs with '
+                    'dithered bf16 storage; bound = min(%.0f * noise + floor, cap)\n' % NOISE_K)
             f.write(text + '\n')
     except OSError:
         pass
@@ -324,6 +346,18 @@ def test_blocks_bf16_vs_f64_oracle_with_yardstick(name):
             res['%s:%s' % (kind, n)] = p.grad.detach().double().cpu().numpy()
         return res
     want = collect(ref, out_r, xr)
+
+    def noisy(noise_seed):
+        r2 = cases.oracle_block(name)
+        r2.load_state_dict(state, strict=True)
+        cases.zero_dropout(r2)
+        r2.double().train()
+        emulate_bf16_storage(r2, dither=torch.Generator().manual_seed(noise_seed))
+        x2 = [x.double().requires_grad_(True) for x in xs]
+        o2 = r2(*x2)
+        o2.backward(cot.double())
+        return collect(r2, o2, x2)
+    _NOISE[0] = (noisy(1003), noisy(2005))
 
     def hip(disable):
         m = cases.product_block(name)

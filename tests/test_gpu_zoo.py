@@ -141,3 +141,36 @@ def test_fastscnn_aspp_eval_logits_and_argmax_vs_torch():
         tssa.set_compute_dtype(m, torch.float32)
         low32 = m.forward_lowres(x.to(DEV))
     assert ((low16 - low32).norm() / low32.norm()).item() < 3e-2
+
+
+def test_fastscnn_aspp_config5_size_vs_oracle():
+    """BASELINE config 5 with the DeepLab-style head at its real size, 1 x 3 x 2048 x 4096, eval mode: f32
+    logits within 1e-3 of oracle/aspp.py (pinned to torch, not to the reference -- the reference has no ASPP head), argmax
+    exact outside sub-resolution ties; the bf16 forward the benchmark times within bf16 noise of it."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd.models.aspp import fastscnn_aspp
+    torch.manual_seed(0)
+    ref = OA.FastSCNNASPP(3, 19)
+    m = fastscnn_aspp(3, 19)
+    m.load_state_dict(ref.state_dict(), strict=True)
+    ref.eval(); m.eval().to(DEV)
+    x, _ = synthetic_batch(1, 2048, 4096)
+    with torch.no_grad():
+        want = ref(x)
+        got = m(x.to(DEV))
+        pred, _ = tssa.argmax_confusion(got)
+    rel = cases.rel_err(got.cpu().numpy(), want.numpy())
+    top2 = want.topk(2, dim=1).values
+    mism = pred.cpu().long() != want.argmax(1)
+    err = (got.cpu() - want).abs().max()
+    print('fastscnn_aspp 1 x 3 x 2048 x 4096 eval: logits rel err %.2e, argmax mismatch fraction %.2e' % (rel, mism.float().mean().item()))
+    assert rel < 1e-3, rel
+    assert ((top2[:, 0] - top2[:, 1])[mism] <= 2 * err + 1e-7).all()
+    assert mism.float().mean().item() < 1e-4
+    del want, got
+    tssa.set_compute_dtype(m, torch.bfloat16)
+    with torch.no_grad():
+        low16 = m.forward_lowres(x.to(DEV)).float()
+        tssa.set_compute_dtype(m, torch.float32)
+        low32 = m.forward_lowres(x.to(DEV))
+    assert ((low16 - low32).norm() / low32.norm()).item() < 3e-2
