@@ -642,6 +642,47 @@ def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
             assert rel(g1[k], g0[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('cin,cout,dil,shape', [(128, 128, 6, (1, 40, 72)), (128, 128, 18, (2, 37, 53)), (128, 128, 1, (1, 16, 16)),
+                                                (128, 128, 12, (1, 64, 128)), (64, 32, 2, (2, 19, 33)), (96, 48, 5, (1, 30, 41)),
+                                                (32, 128, 3, (3, 9, 70))])
+@pytest.mark.parametrize('train', [False, True])
+def test_dense3x3_streamed_mfma_kernel_vs_torch(cin, cout, dil, shape, train):
+    """csrc/atrous.hip (dense 3x3, stride 1, any dilation, activations streamed from global memory into the MFMA operand
+    registers; the atrous branches of BASELINE config 5's ASPP head) through the C ABI against an f32 torch evaluation on the
+    same bf16 operands: ragged last tile, image borders at every dilation, several images, the generic-channel instance, and
+    (train) the statistics slab rows of a training-mode BatchNorm behind it; and against the general tap loop it replaces."""
+    from torch_semantic_segmentation_amd import _native as N
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(cin + dil)
+    B, H, W = shape
+    x = ops.new_nhwc(B, cin, H, W, torch.bfloat16, DEV)
+    x.copy_(torch.randn(B, cin, H, W, device=DEV))
+    w = (torch.randn(cout, cin, 3, 3, device=DEV) * 0.05)
+    w16 = torch.empty((9, cout, cin), dtype=torch.bfloat16, device=DEV)
+    w32 = torch.empty((9, cout, cin), dtype=torch.float32, device=DEV)
+    st = N.stream()
+    N.call('tss_permute_w3x3_bf16', N.ptr(w), N.ptr(w16), None, cout, cin, st)
+    N.call('tss_permute_w3x3', N.ptr(w), N.ptr(w32), None, cout, cin, st)
+    S = N.stat_slabs()
+
+    def run(streamed):
+        y = ops.new_nhwc(B, cout, H, W, torch.bfloat16, DEV)
+        stats = torch.full((S, 2 * cout), float('nan'), dtype=torch.float64, device=DEV) if train else None
+        N.call('tss_conv3x3_fwd', N.ptr(x), x.stride(3), None, None, None, 0, N.ptr(w32), N.ptr(w16) if streamed else None,
+               N.ptr(y), y.stride(3), N.ptr(stats), B, H, W, cin, cout, 1, dil, 1, st)
+        torch.cuda.synchronize()
+        return y.float(), (stats.sum(0) if train else None)
+    y1, s1 = run(True)
+    y0, s0 = run(False)
+    ref = torch.nn.functional.conv2d(x.float(), w.bfloat16().float(), padding=dil, dilation=dil)
+    assert torch.isfinite(y1).all()
+    assert rel(y1, ref) < 4e-3 and maxrel(y1, ref) < 2e-2, (rel(y1, ref), maxrel(y1, ref))
+    assert rel(y1, y0) < 4e-3
+    if train:
+        assert torch.isfinite(s1).all()
+        assert rel(s1[:cout], y1.double().sum((0, 2, 3))) < 1e-6 and rel(s1[cout:], (y1.double() ** 2).sum((0, 2, 3))) < 1e-6
+
+
 @pytest.mark.parametrize('B,H,W', [(8, 32, 64), (2, 16, 32), (3, 13, 21)])
 @pytest.mark.parametrize('train', [True, False])
 def test_pyramid_arms_in_one_launch_match_the_unit_by_unit_path(B, H, W, train):

@@ -829,7 +829,9 @@ int tss_ppm_pool_slices(int B, int ncells) {   // row slices per window: > 1 onl
   const long w = (long)B * ncells;
   if (w <= 0 || w > 128) return 1;
   long S = (1024 + w - 1) / w;
-  return (int)(S > 16 ? 16 : S);
+  // (one window of one image -- global average pooling of a 256 x 512 map, the image-pooling branch of an ASPP head at 2048 x 4096 --
+  //  was 1.05 ms through 16 slices of 2 MB each: up to 256 slices, the kernel clamps a slice to at least one row)
+  return (int)(S > 256 ? 256 : S);
 }
 
 int tss_ppm_pool_fwd(const void* x, long ldx, void* const* y, const long* ldy, const int* bins, int narms, float* ws,

@@ -392,6 +392,15 @@ def _conv3x3_lean(dtype, k, n, stride, dil):
             and not N.fast_paths_disabled())
 
 
+conv3x3_stream = os.environ.get('TSS_CONV3X3_STREAM', '1') != '0'
+
+
+def _conv3x3_stream(dtype, k, n, stride, in_link, in_relu):
+    """Domain of the register-streamed dense 3x3 kernel (atrous.hip): materialised bf16 input, stride 1, any dilation."""
+    return (conv3x3_stream and dtype == torch.bfloat16 and stride == 1 and in_link is None and not in_relu and k % 32 == 0
+            and 32 <= k <= 128 and n % 16 == 0 and 16 <= n <= 128 and not N.fast_paths_disabled())
+
+
 def _shadow(weight, which):
     ent = _SHADOWS.get(weight.data_ptr()) if _SHADOWS else None
     return ptr(ent[which]) if ent is not None else None
@@ -713,7 +722,8 @@ class ConvUnitFn(Function):
             if bias is not None:
                 raise NotImplementedError('HIP path: dense 3x3 convolution with bias')
             w_tnc = w_tnc16 = None
-            if _conv3x3_lean(x.dtype, cfg.cin, Cout, s, d):      # bf16 tap-major copy: the LDS-halo kernel (conv3x3.hip)
+            if _conv3x3_stream(x.dtype, cfg.cin, Cout, s, cfg.in_link, cfg.in_relu) or _conv3x3_lean(x.dtype, cfg.cin, Cout, s, d):
+                # bf16 tap-major copy: the register-streamed kernel (atrous.hip) / the LDS-halo kernel (conv3x3.hip)
                 w_tnc16 = torch.empty((9, Cout, cfg.cin), dtype=torch.bfloat16, device=dev)
                 call('tss_permute_w3x3_bf16', ptr(weight), ptr(w_tnc16), None, Cout, cfg.cin, st)
             else:
@@ -1314,8 +1324,14 @@ class UpsampleHeadFn(Function):
 
 
 def adaptive_avg_pool(x, bins):
+    """nn.AdaptiveAvgPool2d(bins).  Few, large windows (global average pooling: the image-pooling branch of an ASPP head pools ONE
+    256 x 512 window per image at 2048 x 4096 -- 1.05 ms through the one-block-per-window kernel) go through the row-sliced
+    pyramid-pooling kernel; many small windows through the one-block-per-window kernel."""
     x = to_nhwc(materialize(x))
-    return AdaptivePoolFn.apply(x, int(bins))
+    bins = int(bins)
+    if x.shape[0] * bins * bins <= 128 and x.shape[2] * x.shape[3] >= 4096:
+        return PoolMultiFn.apply(x, (bins,), None)[0]
+    return AdaptivePoolFn.apply(x, bins)
 
 
 class AdaptivePoolFn(Function):
