@@ -260,9 +260,40 @@ def extra_eval(model_name, h, w, device, steps, warmup):
     res = {'workload': '%s eval-mode forward incl. x8 head, 1 x 3 x %d x %d, bf16' % (model_name, h, w),
            'ms_per_step': round(ms, 3), 'images_per_sec': round(steps / elapsed, 2), 'steps': steps, 'chunks': chunks,
            'step_roofline': roofline_block(a, ms)}
+    if model_name == 'fastscnn_aspp':
+        rf = mfma_roofline(model, x)
+        if rf:
+            res['roofline'] = rf
     del fwd, model
     torch.cuda.empty_cache()
     return res
+
+
+def mfma_roofline(model, x):
+    """The dominant MATRIX kernel of an eval forward (the dense 3x3 convolutions of an ASPP head: 1152 FLOP per output byte, the only
+    MFMA-bound launches of the repository): algorithmic FLOPs per launch / average launch time, measured live with HIP events on
+    the launch stream (in-library profiler) over un-captured forwards, against the dense bf16 MFMA peak."""
+    from torch_semantic_segmentation_amd import _native as N
+    from torch_semantic_segmentation_amd import engine as E
+    prep = E.EvalPrep(model)
+    with torch.no_grad():
+        with prep:
+            model(x)
+        torch.cuda.synchronize()
+        N.prof_reset()
+        N.prof_enable(True)
+        for _ in range(3):
+            with prep:
+                model(x)
+        torch.cuda.synchronize()
+        N.prof_enable(False)
+    r = N.prof_table().get('conv3x3_fwd')
+    if not r or not r['launches'] or r['flops'] <= 0:
+        return None
+    tf = r['flops'] / (r['ms'] * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv3x3_stream_kernel|' + r['symbol'], 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TF,
+            'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TF, 4), 'traffic': None, 'launches_per_forward': r['launches'] // 3,
+            'avg_launch_us': round(1e3 * r['ms'] / r['launches'], 2), 'alg_flops_per_launch': round(r['flops'] / r['launches'])}
 
 
 def roofline_block(alg_bytes, ms):
@@ -308,6 +339,10 @@ def main_eval(args):
     if S_ref:   # A = (sum over blocks of in + out elements + full-resolution logits) * b
         a = (S_ref * args.batch * args.height * args.width / (8.0 * 1024 * 2048) + args.batch * 19.0 * args.height * args.width) * esz
         res['step_roofline'] = roofline_block(a, ms)
+    if args.model == 'fastscnn_aspp' and dtype == torch.bfloat16:
+        rf = mfma_roofline(model, x)
+        if rf:
+            res['roofline'] = rf
     print(json.dumps(res))
 
 

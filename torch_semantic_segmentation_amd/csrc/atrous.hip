@@ -106,7 +106,15 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
 
     // all 16-byte activation fragments of a tap (4 pixel fragments x nks k-steps: 64 registers): requested one whole tap ahead
     // (~2000 MFMA cycles: an L2 or HBM round trip hides under them; a single wave per SIMD has nobody else to hide it)
-    auto load_tap = [&](int tap, uint4 (&dst)[4][4]) {
+    // taps are visited in a per-block rotation (t + block) % 9: every CU restages the same 32 KB of weights per tap, and all of them
+    // asking for the SAME tap at the same moment queues on the few L2 channels that hold it (104 -> 95 us per launch; with the weight
+    // traffic removed altogether -- wrong results, timing only -- 64 us: what is left of the gap to the matrix pipe's 15.5 us is the
+    // one-tap prefetch distance at one wave per SIMD.  A two-tiles-per-tap variant (half the weight traffic, 256 accumulators)
+    // spilled 250 registers and took 220 us; not kept.)
+    const int rot = (int)(blockIdx.x % 9);
+    auto wtap = [&](int t) { const int v = t + rot; return v >= 9 ? v - 9 : v; };
+    auto load_tap = [&](int t, uint4 (&dst)[4][4]) {
+      const int tap = wtap(t);
       const int ky = tap / 3, kx = tap - ky * 3;
       const int dy = (ky - 1) * D, dx = (kx - 1) * D;
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
       const T* wbuf = Ws + (tap & 1) * NCH * RS + fr * RS + fq * 8;
       mfma_step(wbuf, 0, cur);
       __builtin_amdgcn_sched_barrier(0);
-      if (tap + 1 < 9) { w_issue(tap + 1); load_tap(tap + 1, nxt); }
+      if (tap + 1 < 9) { w_issue(wtap(tap + 1)); load_tap(tap + 1, nxt); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k2 = 1; k2 < 4; ++k2)
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
     };
     uint4 xa[4][4], xb[4][4];
     load_tap(0, xa);
-    w_issue(0);
+    w_issue(wtap(0));
     w_store(0);
     __syncthreads();
 #pragma unroll 1
@@ -236,8 +244,8 @@ bool tss_conv3x3_stream_fwd(const void* x, long ldx, const float* in_scale, int 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
-  const int grid = tss::persistent_blocks(g.ntiles, TSS_STAT_SLABS);
   const bool full = Cin == 128 && N == 128;
+  const int grid = tss::persistent_blocks(g.ntiles, TSS_STAT_SLABS);
   if (full && !stats) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, false>), dim3(grid), dim3(NT), smem, stream, g);
   else if (full) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, true>), dim3(grid), dim3(NT), smem, stream, g);
   else if (!stats) hipLaunchKernelGGL((conv3x3_stream_kernel<0, false, false>), dim3(grid), dim3(NT), smem, stream, g);
