@@ -67,8 +67,11 @@ _pending_dw = []
 # State of the running backward pass; everything left over is flushed by the end-of-pass callback, so gradients are complete
 # when backward() returns (and not before: see direct_grads).
 postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
-_pending_wg = []       # <= 1 entry: (launch(fin_job or None), device)
-_pending_red = []      # <= 1 entry: (ws, dw, P, K, N, device)
+# Both are keyed by the stream the postponed work belongs to: a model whose branches run on two streams (ContextNet) has two
+# independent backward chains, and a launch postponed on one stream must neither ride on nor carry work of the other (its
+# operands are ordered on its own stream only).
+_pending_wg = {}       # stream id -> (launch(fin_job or None), device, stream)
+_pending_red = {}      # stream id -> (ws, dw, P, K, N, device, stream)
 _cb_task = [None]
 
 
@@ -87,7 +90,9 @@ def _backward_task():
     except AttributeError:          # private API gone: nothing is deferred
         return -1
     if task != -1 and _cb_task[0] != task:
-        del _pending_dw[:], _pending_wg[:], _pending_red[:]
+        del _pending_dw[:]
+        _pending_wg.clear()
+        _pending_red.clear()
         try:
             torch.autograd.variable.Variable._execution_engine.queue_callback(_end_of_backward)
         except Exception:           # noqa: BLE001 -- no callback, no deferral
@@ -96,26 +101,31 @@ def _backward_task():
     return task
 
 
-def _flush_wg():
-    while _pending_wg:
-        launch, dev = _pending_wg.pop()
-        with torch.cuda.device(dev):
-            launch(None)
+def _flush_wg(sid=None):
+    """Launch postponed weight gradients now, without a rider, each on the stream it belongs to (sid: only that stream's)."""
+    for k in ([sid] if sid is not None else list(_pending_wg)):
+        ent = _pending_wg.pop(k, None)
+        if ent is not None:
+            launch, dev, st_ = ent
+            with torch.cuda.device(dev), torch.cuda.stream(st_):
+                launch(None)
 
 
-def _flush_red():
-    while _pending_red:
-        ws, dw, P, K, Nn, dev = _pending_red.pop()
-        with torch.cuda.device(dev):
-            call('tss_pwconv_wg_reduce', ptr(ws), ptr(dw), P, K, Nn, stream())
+def _flush_red(sid=None):
+    for k in ([sid] if sid is not None else list(_pending_red)):
+        ent = _pending_red.pop(k, None)
+        if ent is not None:
+            ws, dw, P, K, Nn, dev, st_ = ent
+            with torch.cuda.device(dev), torch.cuda.stream(st_):
+                call('tss_pwconv_wg_reduce', ptr(ws), ptr(dw), P, K, Nn, stream())
 
 
 def _take_red(dev):
-    """(ws ptr, dw ptr, P, K, N) of a slot reduction waiting for a carrier on this device (else NULLs); keeps its tensors alive in `hold`."""
-    if _pending_red and _pending_red[-1][5] == dev:
-        ws, dw, P, K, Nn, _ = _pending_red.pop()
+    """(ws ptr, dw ptr, P, K, N) of a slot reduction waiting for a carrier on THIS stream (else NULLs) + its tensors (kept alive by the caller)."""
+    ent = _pending_red.pop(stream(), None)
+    if ent is not None:
+        ws, dw, P, K, Nn = ent[:5]
         return (ptr(ws), ptr(dw), P, K, Nn), (ws, dw)
-    _flush_red()
     return (None, None, 0, 0, 0), None
 
 
@@ -123,22 +133,26 @@ def _end_of_backward():
     _cb_task[0] = None
     _flush_wg()
     _flush_red()
+    # the row reductions below run on the current stream: order it behind the side streams whose kernels wrote some of the rows
+    # (the autograd engine joins its leaf streams only AFTER the final callbacks)
+    if _pending_dw and _side_streams:
+        cur = torch.cuda.current_stream()
+        for s_ in _side_streams.values():
+            if s_.device == cur.device:
+                cur.wait_stream(s_)
     _flush_dw_reductions()
 
 
 def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
-    """BatchNorm-backward coefficients + d(gamma), d(beta) of `link`: in front of a postponed weight-gradient grid when there is
-    one (no launch of its own), else tss_bn_bwd_finalize."""
+    """BatchNorm-backward coefficients + d(gamma), d(beta) of `link`: in front of a postponed weight-gradient grid of the same
+    stream when there is one (no launch of its own), else tss_bn_bwd_finalize."""
     training = int(link.training if training is None else training)
-    if _pending_wg:
-        launch, dev = _pending_wg[-1]
-        if dev == link.bstats.device and _backward_task() != -1 and _pending_wg:
-            _pending_wg.pop()
-            job = BnBwdJob(ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
-                           ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), int(C))
-            launch(job)
-            return
-        _flush_wg()
+    ent = _pending_wg.get(st)
+    if ent is not None and ent[1] == link.bstats.device and _backward_task() != -1 and _pending_wg.pop(st, None) is not None:
+        job = BnBwdJob(ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
+                       ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), int(C))
+        ent[0](job)
+        return
     call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
          ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
 
@@ -797,7 +811,7 @@ class ConvUnitFn(Function):
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
             if link.sync is not None:
-                _flush_wg()
+                _flush_wg(st)
                 gs = _allreduce_stats(link.bstats, link.count, Cout, link.sync, st)
                 call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), acc,
                      ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
@@ -855,8 +869,8 @@ class ConvUnitFn(Function):
                 # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _pending_wg)
                 postponed = bool(defer and postpone_wgrad and dw_ret is None and _backward_task() != -1)
                 if not postponed:
-                    _flush_wg()
-                    _flush_red()
+                    _flush_wg(st)
+                    _flush_red(st)
                     call('tss_pwconv_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, P, Cin, Cout, dt, None, wst)
             elif cfg.kind == 'dw':
                 ws = torch.empty((N.stat_slabs(), Cout * 9), dtype=torch.float32, device=dev)
@@ -921,15 +935,17 @@ class ConvUnitFn(Function):
                              *red, P, Cin, Cout, dt, st)
                     del hold
                     if postponed:
-                        _flush_wg()            # at most one weight gradient waits at a time
+                        _flush_wg(st)          # at most one weight gradient waits per stream
+                        own = torch.cuda.current_stream(dev)
 
-                        def launch_wg(fin, _keep=(e, y, x, link, il, ws, dw), _args=(gargs, xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt)):
+                        def launch_wg(fin, _keep=(e, y, x, link, il, ws, dw), _args=(gargs, xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt),
+                                      _sid=st, _own=own):
                             ga_, xa_, dwp, wsp, P_, K_, N_, dt_ = _args
                             call('tss_pwconv_bwd_weight', *ga_, *xa_, dwp, wsp, 1, P_, K_, N_, dt_,
-                                 ctypes.byref(fin) if fin is not None else None, stream())
-                            _flush_red()
-                            _pending_red.append((_keep[5], _keep[6], P_, K_, N_, _keep[0].device))
-                        _pending_wg.append((launch_wg, dev))
+                                 ctypes.byref(fin) if fin is not None else None, _sid)
+                            _flush_red(_sid)
+                            _pending_red[_sid] = (_keep[5], _keep[6], P_, K_, N_, _keep[0].device, _own)
+                        _pending_wg[st] = (launch_wg, dev, own)
                 elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
                     # the rows of per-block partial sums stay in ws; they are added to the (direct) gradient together with
                     # those of every other depthwise layer, in one launch at the end of this backward pass
