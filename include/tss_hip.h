@@ -413,38 +413,6 @@ int tss_argmax_confusion(const void* logits, const long long* target, unsigned c
                          unsigned long long* confusion, long B, int C, long HW, int ignore_index,
                          int dtype, void* stream);
 
-/* ---- fused backward of the expand half of an inverted residual -------------------------------------------------------
- * replaces: the autograd backward of conv1 (1x1, Cin -> M) + conv2 (depthwise 3x3, stride 1|2) of BottleneckBlock
- *           (TSS/models/fastscnn.py:143-148, TSS/models/contextnet.py:133-139) as ONE group of operators: the two M-channel
- *           tensors of the pair (conv1's output y1, the gradient e1 between the two layers) are neither read nor written;
- *           y1 is recomputed per 8x8-pixel tile from the block input x on the matrix cores (bit-identical to the stored
- *           forward tensor) and e1 by a stencil over g2 = BN2'(e2, y2).  bf16 only; H, W multiples of 8; Cin <= 128.
- *   x [B][H][W][Cin] materialised block input; w1_bf16 [M][Cin] / w1t_bf16 [Cin][M] current bf16 copies of conv1's weight;
- *   mean1/scale1/beta1 BatchNorm-1 forward constants (a1 = relu((y1 - mean1) scale1 + beta1)); wdw [M][9];
- *   e2 = d(loss)/d(BN2 output), ReLU-masked, and y2 = conv2's raw output, both [B][Ho][Wo][M]; ga2..gmu2 from tss_bn_bwd_finalize.
- *   stats : BatchNorm-1 backward slab rows (sum e1, sum e1 (y1 - mean1))
- *   weight: dw1[M][Cin] += conv1 weight gradient and dwdw[M][9] += depthwise weight gradient; needs ga1/gb1/gce1
- *           (tss_bn_bwd_finalize on the rows `stats` wrote); workspaces of tss_bneck_bwd_ws(.., 1) and (.., 0) floats
- *   data  : dx[B][H][W][Cin] = gradient with respect to the block input through this path (no mask: x is a real tensor) */
-int tss_bneck_bwd_supported(int B, int H, int W, int Cin, int M, int stride, int dtype);
-long tss_bneck_bwd_ws(int B, int H, int W, int Cin, int M, int stride, int which /* 0: depthwise rows, 1: conv1 slots (floats) */);
-int tss_bneck_bwd_stats(const void* x, long ldx, const void* w1_bf16, const float* mean1, const float* scale1, const float* beta1,
-                        const float* wdw, const void* e2, long lde2, const void* y2, long ldy2,
-                        const float* ga2, const float* gb2, const float* gce2, const float* gmu2,
-                        double* bstats1, int B, int H, int W, int Cin, int M, int stride, void* stream);
-int tss_bneck_bwd_weight(const void* x, long ldx, const void* w1_bf16, const float* mean1, const float* scale1, const float* beta1,
-                         const float* wdw, const void* e2, long lde2, const void* y2, long ldy2,
-                         const float* ga2, const float* gb2, const float* gce2, const float* gmu2,
-                         const float* ga1, const float* gb1, const float* gce1,
-                         float* ws_dw1, float* dw1, float* ws_dwdw, float* dwdw,
-                         int B, int H, int W, int Cin, int M, int stride, void* stream);
-int tss_bneck_bwd_data(const void* x, long ldx, const void* w1_bf16, const void* w1t_bf16,
-                       const float* mean1, const float* scale1, const float* beta1,
-                       const float* wdw, const void* e2, long lde2, const void* y2, long ldy2,
-                       const float* ga2, const float* gb2, const float* gce2, const float* gmu2,
-                       const float* ga1, const float* gb1, const float* gce1,
-                       void* dx, long lddx, int B, int H, int W, int Cin, int M, int stride, void* stream);
-
 /* ---- host side of the step: the batch on the wire ----------------------------------------------------------------------
  * replaces: the float32 image / int64 target the reference's DataLoader produces (albumentations.Normalize + ToTensor,
  *           scripts/train_fastscnn.py:62-68) and copies to the device every iteration (TSS/engine.py:27).  The loader may ship

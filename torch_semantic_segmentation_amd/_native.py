@@ -75,7 +75,6 @@ def lib():
         handle.tss_prof_records.restype = ctypes.c_long
         handle.tss_pwconv_bwd_weight_ws.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         handle.tss_pwconv_bwd_weight_ws.restype = ctypes.c_long
-        handle.tss_bneck_bwd_ws.restype = ctypes.c_long
         handle.tss_upsample_ce_ws.argtypes = [ctypes.c_int] * 6
         handle.tss_upsample_ce_ws.restype = ctypes.c_long
         handle.tss_ohem_workspace_bytes.argtypes = []

@@ -62,11 +62,7 @@ class BottleneckBlock(nn.Module):
         c1, c2, c3 = self.conv1[0], self.conv2[0], self.conv3[0]
         residual = tuple(c2.stride) == (1, 1) and c1.in_channels == c3.out_channels and not has_hooks(self.conv1)
         xa, xb, fork = ops.residual_fork(x) if residual else (x, x, None)
-        d = None
-        if not (has_hooks(self.conv1) or has_hooks(self.conv2)):
-            d = ops.expand_dw_unit(xa, self.conv1, self.conv2)       # one autograd node: the backward never touches the 6x tensors
-        if d is None:
-            d = run(self.conv2, run(self.conv1, xa))
+        d = run(self.conv2, run(self.conv1, xa))
         if fork is not None:
             ops._pending_forks.pop(id(xa), None)
         d = run(self.conv3, d)

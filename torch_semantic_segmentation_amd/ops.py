@@ -990,140 +990,6 @@ class ConvUnitFn(Function):
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
 
 
-# ----------------------------------------------------------------------------- fused backward of (1x1 expand, depthwise 3x3)
-
-# BottleneckBlock: conv1 (1x1, Cin -> 6 Cin) + conv2 (depthwise 3x3) as ONE autograd node whose backward neither reads the
-# expanded tensor y1 nor materialises the gradient e1 between the two layers (csrc/bneck.hip: both are recomputed per tile
-# from the 6x smaller block input).  The forward is the two ordinary units; y1 is dropped as soon as conv2 has consumed it.
-# OPT-IN (TSS_FUSE_BNECK=1: stride-2 blocks, =all: every block): numerically validated (tests/test_gpu_blocks.py), but as
-# measured on MI355X in round 2 (profiles/README.md) its three recompute sweeps are VALU / latency bound and lose to the
-# layer-by-layer kernels (features.0.0 of FastSCNN at 8 x 1024 x 2048: 140 + 250 + 277 us against 433 us), so it is off.
-fuse_bottleneck_backward = os.environ.get('TSS_FUSE_BNECK', '0') in ('1', 'all')
-fuse_bottleneck_strides = (1, 2) if os.environ.get('TSS_FUSE_BNECK') == 'all' else (2,)
-
-
-class _Capture:
-    """Stands in for an autograd ctx when a Function's forward is reused inside another Function."""
-    needs_input_grad = (True,)
-
-    def save_for_backward(self, *ts):
-        self.saved = ts
-
-
-def _plain_unit_cfg(conv, bn, kind, stride, in_link, in_relu, dtype):
-    cfg = UnitCfg()
-    cfg.kind, cfg.stride, cfg.dil = kind, stride, 1
-    cfg.cin, cfg.cout = conv.in_channels, conv.out_channels
-    cfg.in_link, cfg.in_relu, cfg.image_f32, cfg.out_dtype = in_link, in_relu, False, dtype
-    cfg.bn, cfg.training = bn, True
-    cfg.params = (conv.weight, bn.weight, bn.bias, None)
-    cfg.res_fork = cfg.stash_fork = None
-    return cfg
-
-
-def expand_dw_unit(x, block1, block2):
-    """[Conv2d 1x1, BatchNorm2d, ReLU] + [depthwise Conv2d 3x3, BatchNorm2d, ReLU] on a materialised bf16 activation ->
-    Deferred (conv2's raw output + its pending BatchNorm + ReLU), or None when the pair is outside the fused operator's
-    envelope (the caller then runs the two units separately)."""
-    if not fuse_bottleneck_backward or N.fast_paths_disabled() or not torch.is_grad_enabled():
-        return None
-    if isinstance(x, Deferred) or not torch.is_tensor(x) or x.dtype != torch.bfloat16 or not is_nhwc(x):
-        return None
-    m1, m2 = list(block1), list(block2)
-    if len(m1) != 3 or len(m2) != 3:
-        return None
-    c1, bn1, r1 = m1
-    c2, bn2, r2 = m2
-    ok = (isinstance(c1, torch.nn.Conv2d) and isinstance(c2, torch.nn.Conv2d) and isinstance(bn1, _BatchNorm) and isinstance(bn2, _BatchNorm)
-          and isinstance(r1, torch.nn.ReLU) and isinstance(r2, torch.nn.ReLU)
-          and c1.kernel_size == (1, 1) and c1.groups == 1 and c1.bias is None and c1.stride == (1, 1) and c1.padding == (0, 0)
-          and c2.kernel_size == (3, 3) and c2.groups == c2.in_channels == c2.out_channels == c1.out_channels and c2.bias is None
-          and c2.stride in ((1, 1), (2, 2)) and c2.dilation == (1, 1) and c2.padding == (1, 1) and c2.padding_mode == 'zeros'
-          and bn1.training and bn2.training and bn1.momentum is not None and bn2.momentum is not None
-          and bn1.weight is not None and bn2.weight is not None
-          and c1.weight.dtype == torch.float32 and c2.weight.dtype == torch.float32 and bn1.weight.dtype == torch.float32
-          and _sync_group(bn1) is None and _sync_group(bn2) is None
-          and getattr(block1, 'act_dtype', None) in (None, torch.bfloat16) and getattr(block2, 'act_dtype', None) in (None, torch.bfloat16))
-    if not ok or x.shape[1] != c1.in_channels:
-        return None
-    B, Cin, H, W = x.shape
-    s = c2.stride[0]
-    if s not in fuse_bottleneck_strides:
-        return None
-    if not N.lib().tss_bneck_bwd_supported(B, H, W, Cin, c1.out_channels, s, N.TSS_BF16):
-        return None
-    if (bn1.training and B * H * W <= 1):
-        return None
-    cfg1 = _plain_unit_cfg(c1, bn1, 'pw', 1, None, False, x.dtype)
-    cfg2 = _plain_unit_cfg(c2, bn2, 'dw', s, None, True, x.dtype)
-    y2 = ExpandDwFn.apply(x, c1.weight, bn1.weight, bn1.bias, c2.weight, bn2.weight, bn2.bias, cfg1, cfg2)
-    return Deferred(y2, cfg2.out_link, True)
-
-
-class ExpandDwFn(Function):
-    @staticmethod
-    def forward(ctx, x, w1, g1, b1, wdw, g2, b2, cfg1, cfg2):
-        y1 = ConvUnitFn.forward(_Capture(), x, w1, g1, b1, None, cfg1)
-        cfg2.in_link = cfg1.out_link
-        y2 = ConvUnitFn.forward(_Capture(), y1, wdw, g2, b2, None, cfg2)
-        del y1                                   # the 6x-expanded tensor is not kept for backward
-        ctx.cfg1, ctx.cfg2 = cfg1, cfg2
-        ctx.save_for_backward(x, w1, wdw, y2)
-        return y2
-
-    @staticmethod
-    def _bn_bwd_finalize(link, p_gamma, p_beta, C, dev, st):
-        """BatchNorm backward coefficients + d(gamma), d(beta) of one layer (as in ConvUnitFn.backward) -> (dgamma, dbeta) to
-        hand to autograd (None when accumulated straight into .grad)."""
-        dgamma, dbeta = _direct_target(p_gamma), _direct_target(p_beta)
-        acc = 1 if (dgamma is not None and dbeta is not None) else 0
-        if not acc:
-            dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
-            dgamma, dbeta = dgb[0], dgb[1]
-        _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=1)
-        return (None, None) if acc else (dgamma, dbeta)
-
-    @staticmethod
-    def backward(ctx, e2):
-        x, w1, wdw, y2 = ctx.saved_tensors
-        cfg1, cfg2 = ctx.cfg1, ctx.cfg2
-        l1, l2 = cfg1.out_link, cfg2.out_link
-        dev, st = x.device, stream()
-        e2 = to_nhwc(e2)
-        B, Cin, H, W = x.shape
-        M, s = cfg1.cout, cfg2.stride
-        dg2, db2 = ExpandDwFn._bn_bwd_finalize(l2, cfg2.params[1], cfg2.params[2], M, dev, st)
-        w1b, w1tb = _shadow(w1, 0), _shadow(w1, 1)
-        keep = None
-        if w1b is None or w1tb is None:          # no current bf16 shadows: make them here (boundary plumbing)
-            wb = w1.detach().reshape(M, Cin).to(torch.bfloat16)
-            keep = (wb, wb.t().contiguous())
-            w1b, w1tb = ptr(keep[0]), ptr(keep[1])
-        common = (ptr(l1.mean), ptr(l1.scale), ptr(l1.beta), ptr(wdw), ptr(e2), ld(e2), ptr(y2), ld(y2),
-                  ptr(l2.ga), ptr(l2.gb), ptr(l2.gce), ptr(l2.mean))
-        call('tss_bneck_bwd_stats', ptr(x), ld(x), w1b, *common, ptr(l1.bstats), B, H, W, Cin, M, s, st)
-        dg1, db1 = ExpandDwFn._bn_bwd_finalize(l1, cfg1.params[1], cfg1.params[2], M, dev, st)
-        dw1 = _direct_target(cfg1.params[0])
-        dw1_ret = None
-        if dw1 is None:
-            dw1 = dw1_ret = torch.zeros_like(w1)
-        dwd = _direct_target(cfg2.params[0])
-        dwd_ret = None
-        if dwd is None:
-            dwd = dwd_ret = torch.zeros_like(wdw)
-        lib = N.lib()
-        ws0 = torch.empty(lib.tss_bneck_bwd_ws(B, H, W, Cin, M, s, 0), dtype=torch.float32, device=dev)
-        ws1 = torch.empty(lib.tss_bneck_bwd_ws(B, H, W, Cin, M, s, 1), dtype=torch.float32, device=dev)
-        bwd1 = (ptr(l1.ga), ptr(l1.gb), ptr(l1.gce))
-        call('tss_bneck_bwd_weight', ptr(x), ld(x), w1b, *common, *bwd1, ptr(ws1), ptr(dw1), ptr(ws0), ptr(dwd), B, H, W, Cin, M, s, st)
-        e_x = None
-        if ctx.needs_input_grad[0]:
-            e_x = new_nhwc(B, Cin, H, W, x.dtype, dev)
-            call('tss_bneck_bwd_data', ptr(x), ld(x), w1b, w1tb, *common, *bwd1, ptr(e_x), ld(e_x), B, H, W, Cin, M, s, st)
-        del keep
-        return e_x, dw1_ret, dg1, db1, dwd_ret, dg2, db2, None, None
-
-
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
 
 class JoinCfg:
