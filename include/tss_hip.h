@@ -370,6 +370,18 @@ int tss_ppm_arms_bwd(const void* const* e, const long* lde, const void* const* y
                      int training, int dtype, void* stream);
 int tss_copy_nhwc(const void* x, long ldx, void* y, long ldy, long P, int C, int dtype, void* stream);
 
+/* ---- channel-attention gates (BiSeNet) ---------------------------------------------------------
+ * replaces: `x * sigmoid(conv(pool(x)))` of AttentionRefinementModule TSS/models/bisenet.py:144-148 (add_one = 0) and
+ *           `x * (1. + attention)` of FeatureFusionModule TSS/models/bisenet.py:128-131 (add_one = 1).
+ * x, out, g, dx: [B][HW][C] NHWC maps; a, da: [B][C] (one value per image and channel: the 1x1 convolution's output on the
+ * pooled map, BEFORE the sigmoid).  Backward: dx = g * (sigmoid(a) + add_one), da = sigmoid'(a) * sum_pixels(g * x), summed
+ * per row slice into ws (B * tss_gate_slices(B, HW) * C floats, not initialised) and then in slice order: no atomics. */
+int tss_gate_slices(int B, long HW);
+int tss_gate_fwd(const void* x, long ldx, const void* a, long lda, void* out, long ldo, int B, long HW, int C, float add_one,
+                 int dtype, void* stream);
+int tss_gate_bwd(const void* g, long ldg, const void* x, long ldx, const void* a, long lda, void* dx, long lddx, void* da, long ldda,
+                 float* ws, int B, long HW, int C, float add_one, int dtype, void* stream);
+
 /* ---- caller side: loss and evaluation metrics --------------------------------------------------------
  * replaces: nn.CrossEntropyLoss(ignore_index=255) scripts/train_fastscnn.py:132 as called by TSS/engine.py:30;
  *           argmax + ConfusionMatrix update of create_segmentation_evaluator TSS/engine.py:65-77. */

@@ -114,3 +114,36 @@ class SSnbt(nn.Module):
         y = torch.cat([self.left(left), self.right(right)], dim=1)
         y = self.dropout(y)
         return shuffle(self.activation(x + y), 2)
+
+
+# ---- BiSeNet's attention blocks (TSS/models/bisenet.py:112-148), pinned to the imported reference by tests/golden/pspnet.npz
+class ChannelGateFusion(nn.Module):
+    """FeatureFusionModule, TSS/models/bisenet.py:112-131: a 3x3 conv block, then the map is scaled by 1 + a sigmoid gate computed
+    from its own global average (pool -> 1x1 conv block -> biased 1x1 conv -> sigmoid).  Same attribute names / keys."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, padding=1, bias=False), nn.BatchNorm2d(out_channels),
+                                  nn.ReLU(inplace=True))
+        self.attention = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1),
+            nn.Sequential(nn.Conv2d(out_channels, out_channels, 1, bias=False), nn.BatchNorm2d(out_channels), nn.ReLU(inplace=True)),
+            nn.Conv2d(out_channels, out_channels, 1),
+            nn.Sigmoid())
+
+    def forward(self, x):
+        y = self.conv(x)
+        return y * (1. + self.attention(y))
+
+
+class ChannelGateRefine(nn.Module):
+    """AttentionRefinementModule, TSS/models/bisenet.py:134-148: the input scaled by a sigmoid gate from its global average."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.pool = nn.AdaptiveAvgPool2d(1)
+        self.conv = nn.Conv2d(channels, channels, 1)
+        self.activation = nn.Sigmoid()
+
+    def forward(self, x):
+        return self.activation(self.conv(self.pool(x))) * x

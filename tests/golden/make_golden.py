@@ -251,6 +251,11 @@ def pspnet_cases():
         'led_ssnbt_d1': (lambda: ref_led.SSnbtBlock(64, 64, dilation=1), [(2, 64, 12, 20)]),
         'led_ssnbt_d5': (lambda: ref_led.SSnbtBlock(128, 128, dilation=5), [(2, 128, 12, 20)]),
         'led_ssnbt_d9': (lambda: ref_led.SSnbtBlock(32, 32, dilation=9), [(2, 32, 24, 10)]),
+        # BiSeNet's attention blocks (TSS/models/bisenet.py:112-148)
+        'bise_arm': (lambda: importlib.import_module('torch_semantic_segmentation.models.bisenet').AttentionRefinementModule(64, 64),
+                     [(2, 64, 12, 20)]),
+        'bise_ffm': (lambda: importlib.import_module('torch_semantic_segmentation.models.bisenet').FeatureFusionModule(96, 64),
+                     [(2, 96, 12, 20)]),
     }
 
 

@@ -1386,6 +1386,44 @@ class ConcatJoinFn(Function):
         return (None, *grads)
 
 
+# ----------------------------------------------------------------------------- channel-attention gate (BiSeNet)
+
+def gate(x, a, add_one=False):
+    """x * (sigmoid(a) + add_one) with a = one value per image and channel ([B, C, 1, 1], the 1x1 convolution's output on the
+    pooled map before the sigmoid): TSS/models/bisenet.py:128-131 (add_one) and :144-148."""
+    x = to_nhwc(materialize(x))
+    a = to_nhwc(materialize(a))
+    if a.shape != (x.shape[0], x.shape[1], 1, 1) or a.dtype != x.dtype:
+        raise RuntimeError('gate: attention must be (B, C, 1, 1) of the map\'s dtype, got %s %s for %s %s'
+                           % (tuple(a.shape), a.dtype, tuple(x.shape), x.dtype))
+    if x.shape[1] % 8:
+        raise NotImplementedError('HIP path: gate needs a channel count that is a multiple of 8')
+    return GateFn.apply(x, a, 1.0 if add_one else 0.0)
+
+
+class GateFn(Function):
+    @staticmethod
+    def forward(ctx, x, a, add_one):
+        B, C, H, W = x.shape
+        out = new_nhwc(B, C, H, W, x.dtype, x.device)
+        call('tss_gate_fwd', ptr(x), ld(x), ptr(a), ld(a), ptr(out), ld(out), B, H * W, C, add_one, N.dtype_code(x.dtype), stream())
+        ctx.add_one = add_one
+        ctx.save_for_backward(x, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = to_nhwc(g)
+        dx = new_nhwc(B, C, H, W, x.dtype, x.device)
+        da = new_nhwc(B, C, 1, 1, x.dtype, x.device)
+        ws = torch.empty(B * N.lib().tss_gate_slices(B, H * W) * C, dtype=torch.float32, device=x.device)
+        call('tss_gate_bwd', ptr(g), ld(g), ptr(x), ld(x), ptr(a), ld(a), ptr(dx), ld(dx), ptr(da), ld(da), ptr(ws), B, H * W, C,
+             ctx.add_one, N.dtype_code(x.dtype), stream())
+        return dx, da, None
+
+
 # ----------------------------------------------------------------------------- pyramid pooling, all arms per launch
 
 fuse_dropout = True    # nn.Dropout after a pending BatchNorm + ReLU rides in the join that materialises it (False: own pass)
