@@ -150,10 +150,11 @@ class ContextNet(HipModel):
             main, side = torch.cuda.current_stream(dev), ops._side_stream(dev)
             side.wait_stream(main)
             input.record_stream(side)
-            with torch.cuda.stream(side):
-                context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
-                context = self.context(context)
-            spatial = self.spatial(input)
+            with ops.overlap_region():
+                with torch.cuda.stream(side):
+                    context = ops.resize_image(input, scale_factor=1 / self.scale_factor)
+                    context = self.context(context)
+                spatial = self.spatial(input)
             main.wait_stream(side)
             for t in ops.tensors_of(context):
                 t.record_stream(main)      # allocated on the side stream, consumed (and later freed) under the main one

@@ -70,6 +70,10 @@ postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
 # Both are keyed by the stream the postponed work belongs to: a model whose branches run on two streams (ContextNet) has two
 # independent backward chains, and a launch postponed on one stream must neither ride on nor carry work of the other (its
 # operands are ordered on its own stream only).
+# Layers that run inside a two-stream region of the forward pass (ContextNet's branches, `overlap_region`) are not postponed: there
+# the other stream's kernels already fill the launch gaps, and what postponing leaves for the end of the pass (a weight gradient and
+# its slot reduction per stream, un-overlapped) costs more than the finalize launches it saves (measured: 6.32 vs 6.21 ms per step).
+_overlap_depth = [0]
 _pending_wg = {}       # stream id -> (launch(fin_job or None), device, stream)
 _pending_red = {}      # stream id -> (ws, dw, P, K, N, device, stream)
 _cb_task = [None]
@@ -255,6 +259,18 @@ def drop_fork(xa, xb):
 
 # independent branches of a model (ContextNet's spatial / context branches) on two streams: parallel branches of the captured graph
 overlap_branches = os.environ.get('TSS_OVERLAP_BRANCHES', '1') != '0'     # measured: ContextNet14 step 6.34 -> 6.27 ms
+
+
+class overlap_region:
+    """Marks the part of a forward pass whose layers run on two streams at once (see _overlap_depth)."""
+
+    def __enter__(self):
+        _overlap_depth[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _overlap_depth[0] -= 1
+        return False
 
 
 def tensors_of(x):
@@ -591,7 +607,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped')
 
 
 def _classify(conv, x_is_image):
@@ -634,6 +650,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
     kind, stride, dil = _classify(conv, is_image)
     cfg = UnitCfg()
     cfg.kind, cfg.stride, cfg.dil = kind, stride, dil
+    cfg.overlapped = _overlap_depth[0] > 0
     cfg.cin, cfg.cout = conv.in_channels, conv.out_channels
     if kind == 'stem':
         _check_device(x)
@@ -867,7 +884,8 @@ class ConvUnitFn(Function):
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
                 defer = 1 if (ws is not None and need_dx and side is None) else 0   # a backward-data launch carries the reduce
                 # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _pending_wg)
-                postponed = bool(defer and postpone_wgrad and dw_ret is None and _backward_task() != -1)
+                postponed = bool(defer and postpone_wgrad and dw_ret is None and not getattr(cfg, 'overlapped', False)
+                                 and _backward_task() != -1)
                 if not postponed:
                     _flush_wg(st)
                     _flush_red(st)
