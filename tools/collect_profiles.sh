@@ -23,15 +23,29 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/mfma --output-f
 python3 $root/tools/pmc_mfma.py $out/mfma > $out/${tag}_pmc_mfma.txt
 rm -rf $out/mfma
 echo "mfma done"
+# 2c. BASELINE config 5 with the ASPP head: per-kernel time of the eval forward, and MFMA busy of its matrix kernels
+rocprofv3 --kernel-trace --stats -d $out/aspp --output-format csv -- python3 $root/bench.py --mode eval --model fastscnn_aspp --steps 20 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_eval_c5_aspp_under_rocprof.json 2> $out/aspp.err
+cp $out/aspp/*/*kernel_stats.csv $out/${tag}_eval_c5_aspp_kernel_stats.csv
+rm -rf $out/aspp
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $out/mfma2 --output-format csv -- python3 $root/bench.py --mode eval --model fastscnn_aspp --steps 2 --warmup 1 --graph off --no-cpu-baseline > /dev/null 2> $out/mfma2.err
+python3 $root/tools/pmc_mfma.py $out/mfma2 > $out/${tag}_pmc_mfma_eval_c5_aspp.txt
+rm -rf $out/mfma2
+echo "aspp done"
 cd $root
 # 3. the timeline of one captured step
 tools/trace_step.sh
 cp gpurun_out/gaps.txt $out/${tag}_step_kernels.txt
+cp gpurun_out/timeline.txt $out/${tag}_step_timeline.txt
+tools/trace_step.sh --model contextnet14
+cp gpurun_out/gaps.txt $out/${tag}_step_kernels_contextnet14.txt
+TRACE_MARK=upsample_head tools/trace_step.sh --mode eval --model fastscnn_aspp
+cp gpurun_out/gaps.txt $out/${tag}_eval_c5_aspp_kernels.txt
 echo "trace done"
 # 4. the bench lines themselves
 python3 bench.py --host-batch > $out/${tag}_bench_default.json 2> $out/default.err     # the driver's command + the PCIe-inclusive legs; extras = configs 3 and 5
 python3 bench.py --model contextnet14 --no-cpu-baseline --no-extras > $out/${tag}_bench_contextnet14.json 2> $out/ctx.err
 python3 bench.py --mode eval --model fastscnn_aspp --steps 50 --warmup 5 > $out/${tag}_bench_eval_c5_aspp.json 2> $out/eval3.err
 TSS_SYNCBN_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --syncbn --no-cpu-baseline --no-extras --no-roofline > $out/${tag}_bench_syncbn_1rank.json 2> $out/syncbn.err
-python3 bench.py --stock --steps 50 --no-cpu-baseline --no-extras --no-roofline > $out/${tag}_bench_stock.json 2> $out/stock.err
+python3 tools/graph_memset_probe.py > $out/${tag}_memset_probe.log 2>&1; cp gpurun_out/memset_probe.txt $out/${tag}_memset_probe.txt
+python3 tools/micro_atrous.py > $out/${tag}_micro_atrous.txt 2>&1
 echo "bench done"
