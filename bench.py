@@ -216,14 +216,16 @@ def timed_steps(step_fn, steps, device, barrier=None, chunk=10):
     return elapsed, chunks, out
 
 
-def extra_train(model_name, batch, h, w, device, steps, warmup):
-    """One more BASELINE config in the same run (N = 1): same Trainer path as the headline, different model."""
+def extra_train(model_name, batch, h, w, device, steps, warmup, loss='ce'):
+    """One more BASELINE config in the same run (N = 1): same Trainer path as the headline, different model (or the recipe's
+    OHEM loss, scripts/train_fastscnn.py, instead of the plain cross-entropy)."""
     from torch_semantic_segmentation_amd import engine as E
     model, tssa = build_model(model_name)
     model.to(device)
     tssa.set_compute_dtype(model, torch.bfloat16)
     opt = E.FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
-    tr = E.Trainer(model, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=True)
+    loss_fn = tssa.OHEMLoss(ignore_index=255, numel_frac=0.1) if loss == 'ohem' else tssa.CrossEntropyLoss(ignore_index=255)
+    tr = E.Trainer(model, opt, loss_fn, use_graph=True)
     x, y = synthetic(batch, h, w, 1234, device)
     tr.step_async(x, y)
     x, y = tr.static_batch(x, y)
@@ -232,7 +234,8 @@ def extra_train(model_name, batch, h, w, device, steps, warmup):
     elapsed, chunks, loss = timed_steps(lambda: tr.step_async(x, y), steps, device)
     ms = 1e3 * elapsed / steps
     a = algorithmic_step_bytes(model_name, batch, h, w, 2)
-    res = {'workload': '%s train step, %d x 3 x %d x %d, bf16' % (model_name, batch, h, w), 'ms_per_step': round(ms, 3),
+    res = {'workload': '%s train step, %d x 3 x %d x %d, bf16%s' % (model_name, batch, h, w, ', OHEM loss' if loss == 'ohem' else ''),
+           'ms_per_step': round(ms, 3),
            'images_per_sec': round(batch * steps / elapsed, 2), 'steps': steps, 'chunks': chunks, 'final_loss': round(float(loss), 4)}
     if a:
         res['step_roofline'] = roofline_block(a, ms)
@@ -531,6 +534,7 @@ def main():
             torch.cuda.empty_cache()
             n_extra = max(50, min(args.steps, 100))
             out['extra'] = {'contextnet14': extra_train('contextnet14', 8, 1024, 2048, device, n_extra, 5),
+                            'fastscnn_ohem': extra_train('fastscnn', 8, 1024, 2048, device, n_extra, 5, loss='ohem'),
                             'eval_c5': extra_eval('fastscnn', 2048, 4096, device, n_extra, 5),
                             'eval_c5_aspp': extra_eval('fastscnn_aspp', 2048, 4096, device, n_extra, 5)}
         if args.stock:

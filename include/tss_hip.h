@@ -396,6 +396,9 @@ int tss_cross_entropy_bwd(const void* logits, const long long* target, const flo
  * numel_frac).  The (n_top+1)-th largest per-pixel loss is found by a device-side radix select (no sort, no host read-back);
  * workspace = tss_ohem_workspace_bytes() bytes, zeroed once by the caller (left zeroed by every call). */
 long tss_ohem_workspace_bytes(void);
+/* the selection alone, on n per-pixel losses that already exist (n % 4 == 0) */
+int tss_ohem_select(const float* pixel_loss, void* workspace, float* loss, float* params, long n, float thresh_loss, long n_top,
+                    void* stream);
 int tss_ohem_fwd(const void* logits, const long long* target, float* lse, float* pixel_loss, void* workspace,
                  float* loss, float* params, long B, int C, long HW, int ignore_index, float thresh_loss,
                  long n_top, int dtype, void* stream);
@@ -414,6 +417,13 @@ int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, floa
                         int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream);
 int tss_upsample_ce_bwd(const float* ws, const float* inv_count, const float* grad_out, void* dlow, long ldl,
                         int B, int C, int h, int w, int H, int W, int dtype, void* stream);
+/* OHEM on the fused head (TSS/losses/ohem_loss.py:10-21 on F.interpolate(low, x8) without the full-resolution logits): per-pixel
+ * cross-entropy from the low-res logits -> tss_ohem_select on that array -> gradient tiles of the selected pixels
+ * (tss_upsample_ohem_grad; ws as for tss_upsample_ce_fwd) -> tss_upsample_ce_bwd with *inv_count = 1 gathers them. */
+int tss_upsample_pixel_ce(const void* low, long ldl, const long long* target, float* pix, int B, int C, int h, int w, int H, int W,
+                          int ignore_index, int dtype, void* stream);
+int tss_upsample_ohem_grad(const void* low, long ldl, const long long* target, const float* pix, const float* sel, float* ws,
+                           int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream);
 int tss_upsample_head_bwd_cols(const float* tmp, void* dlow, long ldl, int B, int N, int h, int w, int W,
                                int dtype, void* stream);
 /* Fused evaluation head: argmax of the bilinearly upsampled logits (+ confusion matrix, rows = truth) from the low-res

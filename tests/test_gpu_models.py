@@ -220,6 +220,29 @@ def test_flat_adamw_and_graph_replay_match_eager():
         assert other[3] == base[3] == 3
 
 
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_trainer_fuses_the_head_with_the_ohem_loss_of_the_reference_recipe(use_graph):
+    """scripts/train_fastscnn.py trains with OHEMLoss: Trainer(model, opt, OHEMLoss) computes it from the low-res logits
+    (ops.upsample_ohem_loss) -- same trajectory as the unfused model(x) -> OHEMLoss pair, eagerly and as a captured graph."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    x, y = synthetic_batch(2, 64, 128)
+    x, y = x.to(DEV), y.to(DEV)
+    results = []
+    for fused in (False, True):
+        m = cases.product_model('fastscnn')
+        m.load_state_dict(formula_state(m), strict=True)
+        cases.zero_dropout(m)
+        m.to(DEV)
+        opt = E.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+        tr = E.Trainer(m, opt, tssa.OHEMLoss(ignore_index=255, numel_frac=0.1), use_graph=(use_graph and fused), fuse_head_loss=fused)
+        assert tr.fuse_head_loss == fused
+        losses = [tr.step_async(x, y).item() for _ in range(4)]
+        results.append((losses, torch.cat([p.detach().flatten() for p in m.parameters()]).double().cpu()))
+    assert np.allclose(results[1][0], results[0][0], rtol=1e-3), (results[0][0], results[1][0])
+    assert ((results[1][1] - results[0][1]).norm() / results[0][1].norm()).item() < 2e-3
+
+
 @pytest.mark.parametrize('hw', [(128, 256), (64, 128)])
 @pytest.mark.parametrize('name', ['fastscnn', 'contextnet14'])
 def test_captured_step_is_bit_reproducible_and_scheduling_is_exact(name, hw):

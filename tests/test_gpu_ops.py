@@ -604,6 +604,56 @@ def test_ohem_loss_matches_reference_formula(case, dtype):
     assert rel(a.grad, b.grad) < tol
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', ['threshold', 'top_n', 'many_ignored'])
+@pytest.mark.parametrize('geom', [(2, 19, 16, 32, 8), (1, 19, 9, 13, 4), (3, 21, 12, 20, 8)])
+def test_upsample_ohem_from_lowres_logits_matches_the_unfused_pair(geom, case, dtype):
+    """upsample_ohem_loss(low) == OHEMLoss(upsample_logits(low)) (TSS/losses/ohem_loss.py:10-21 on the x8 head of
+    TSS/models/fastscnn.py:40-43): same loss, same low-res gradient, on both selection branches, with ragged sizes and a class
+    count above 20; and the same bits from run to run (tiles + fixed-order gather)."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    from oracle.recipe import ohem
+    torch.manual_seed(23)
+    B, C, h, w, scale = geom
+    H, W = h * scale, w * scale
+    gain, frac = (3.0, 0.05) if case == 'threshold' else (0.05, 0.01)
+    low = (gain * torch.randn(B, C, h, w, device=DEV)).to(dtype)
+    target = torch.randint(0, C, (B, H, W), device=DEV)
+    thresh = 0.35667494393873245 if case == 'threshold' else 3.6
+    target[torch.rand(B, H, W, device=DEV) < (0.995 if case == 'many_ignored' else 0.1)] = 255
+    if (B * H * W) % 8:
+        pytest.skip('the unfused operator needs H*W % 8 == 0')
+
+    def fused():
+        a = low.clone().requires_grad_(True)
+        la = ops.upsample_ohem_loss(a, target, scale_factor=scale, ignore_index=255, thresh_loss=thresh, numel_frac=frac)
+        (0.7 * la).backward()
+        return la.detach().clone(), a.grad.clone()
+    la, ga = fused()
+    # the oracle: the reference's formula on an f32 interpolation of the same (rounded) low-res logits
+    b = low.float().clone().requires_grad_(True)
+    up = F.interpolate(b, scale_factor=scale, mode='bilinear', align_corners=True)
+    lb = ohem(up, target, ignore_index=255, thresh_loss=thresh, numel_frac=frac)
+    (0.7 * lb).backward()
+    per = F.cross_entropy(up.detach(), target, ignore_index=255, reduction='none').flatten()
+    nth = torch.sort(per, descending=True)[0][int(per.numel() * frac)].item()
+    assert (nth > thresh) == (case == 'threshold')
+    tol = 5e-5 if dtype == torch.float32 else 1e-2          # bf16: only the returned gradient is rounded
+    assert abs(la.item() / lb.item() - 1) < tol, (la.item(), lb.item())
+    assert rel(ga, b.grad) < tol
+    # the unfused HIP pair on the same input.  (bf16: that pair rounds the full-resolution logits to bf16 before the loss, so in the
+    # top-n branch on near-uniform logits it selects other pixels than the f32 formula does -- compared in f32 and on the threshold branch)
+    if (dtype == torch.float32 or case == 'threshold') and W % 8 == 0:      # (and the unfused upsample needs W % 8 == 0)
+        c = low.clone().requires_grad_(True)
+        lc = tssa.OHEMLoss(ignore_index=255, thresh_loss=thresh, numel_frac=frac)(ops.upsample_logits(c, scale_factor=scale), target)
+        (0.7 * lc).backward()
+        assert abs(la.item() / lc.item() - 1) < (5e-5 if dtype == torch.float32 else 2e-2)
+        assert rel(ga, c.grad) < (5e-5 if dtype == torch.float32 else 3e-2)
+    l2, g2 = fused()
+    assert torch.equal(g2, ga) and abs(l2.item() - la.item()) <= 1e-6 * abs(la.item())
+
+
 @pytest.mark.parametrize('stride', [1, 2])
 def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
     """Direct gradients (ops.direct_grads, the trainer's mode): the per-block rows of the one-sweep depthwise backward are summed

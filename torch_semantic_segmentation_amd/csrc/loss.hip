@@ -113,10 +113,15 @@ __global__ __launch_bounds__(NT) void ce_bwd_kernel(const T* logits, const long 
 //   ws = [nblocks][2] f64 loss rows, then [nblocks][tile_rows][tile_cells][CP] f32 tiles; block = (b * nband + band) * nstrip + strip
 struct CeGeom { int nstrip, nband, band_rows, tile_rows, tile_cells; };
 
-template <typename T, int CP>
+// MODE 0: mean cross-entropy (loss rows + unscaled gradient tiles).  MODE 1: the per-pixel cross-entropy only, written to `pix`
+// ([B][H][W] f32, 0 for ignored pixels) -- the input of the OHEM selection (TSS/losses/ohem_loss.py:11-12 without the 318.8 M-element
+// logits).  MODE 2: gradient tiles of a WEIGHTED sum of per-pixel losses, the weight of a pixel derived from its stored loss and
+// the selection parameters `sel` = [mode, cut, weight of l > cut, weight of l == cut] (tss_ohem_select): OHEM's backward.
+template <typename T, int CP, int MODE>
 __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_kernel(const T* low, long ldl, const long long* target,
                                                                  float* tiles, double* lossrows, int B, int C, int h, int w,
-                                                                 int H, int W, int ignore_index, const CeGeom geo) {
+                                                                 int H, int W, int ignore_index, const CeGeom geo,
+                                                                 float* pix, const float* sel) {
   const int band_rows = geo.band_rows;
   constexpr int MAXCELL = NT + 2, WTAB = 1024;
   constexpr float LOG2E = 1.44269504088896340736f;
@@ -243,12 +248,15 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
 
   const long long* trow = target + (b * H + ya) * (long)W + (xin ? x : 0);
   long long tnext = *trow;
+  float sel_cut = 0.f, sel_gt = 0.f, sel_eq = 0.f;
+  if (MODE == 2) { sel_cut = sel[1]; sel_gt = sel[2]; sel_eq = sel[0] != 0.f ? 0.f : sel[3]; }
+  float* prow = (MODE != 0) ? pix + (b * H + ya) * (long)W + (xin ? x : 0) : nullptr;
   for (int y = ya; y < yb; ++y) {
     const long long t = tnext;
     if (y + 1 < yb) tnext = trow[(long)(y + 1 - ya) * W];      // next row's target under this row's arithmetic
     const Tap ty = ac_tap(sy, y, h);                           // uniform over the block
     if (ty.i0 != rA) {                                         // row tap advanced (by exactly one: H >= h)
-      flush_row(rA, kA, gA, aA);
+      if (MODE != 1) flush_row(rA, kA, gA, aA);
       kA ^= 1;
       rA = rB;
       rB = rA + (rA < h - 1 ? 1 : 0);
@@ -257,11 +265,12 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
       load_row(rB, aB);
     }
     float z[CP];
-    float m = -TSS_INF;
+    float m = -TSS_INF, zt = 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       z[c] = (c < C) ? ty.l0 * aA[c] + ty.l1 * aB[c] : -TSS_INF;
       m = fmaxf(m, z[c]);
+      if (MODE == 1) zt = (t == (long long)c) ? z[c] : zt;    // the target's logit (log2 units): one select per class, this mode only
     }
     const bool valid = xin && t != ignore_index && t >= 0 && t < C;
     float ssum = 0.f;
@@ -270,15 +279,25 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
       z[c] = __builtin_amdgcn_exp2f(z[c] - m);          // e_c (0 for the padding classes)
       ssum += z[c];
     }
+    if (MODE == 1) {      // per-pixel loss in nats, >= 0 (rounding may give -1e-7), 0 for ignored pixels; nothing else in this mode
+      const float d = ((m - zt) + __builtin_amdgcn_logf(ssum)) * 0.69314718055994530942f;
+      if (xin) prow[(long)(y - ya) * W] = valid ? fmaxf(d, 0.f) : 0.f;
+      continue;
+    }
+    float wpx = 1.f;      // weight of this pixel's loss in the sum (MODE 2: OHEM's selection)
+    if (MODE == 2) {
+      const float pl = xin ? prow[(long)(y - ya) * W] : 0.f;
+      wpx = pl > sel_cut ? sel_gt : (pl == sel_cut ? sel_eq : 0.f);
+    }
     if (valid) {
       lsum += m + __builtin_amdgcn_logf(ssum);      // log2
       lcnt += 1.f;
       float* ha = &Hh[kA][tid * CP + (int)t];                 // this lane's own row of the table: no race
       float* hb = &Hh[kA ^ 1][tid * CP + (int)t];
-      *ha += ty.l0;
-      *hb += ty.l1;
+      *ha += ty.l0 * wpx;
+      *hb += ty.l1 * wpx;
     }
-    const float inv = valid ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+    const float inv = valid ? __builtin_amdgcn_rcpf(ssum) * wpx : 0.f;
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       const float pz = z[c] * inv;
@@ -286,10 +305,12 @@ __global__ __launch_bounds__(NT, (CP <= 20 ? 3 : 2)) void upsample_ce_onepass_ke
       gB[c] += ty.l1 * pz;
     }
   }
+  if (MODE == 1) return;
   flush_row(rA, kA, gA, aA);
   if (rB != rA) flush_row(rB, kA ^ 1, gB, aB);
   else {   // the band ended on the last low-res row (rB == rA): the l1 weights are zero there, nothing to flush
   }
+  if (MODE == 2) return;
 
   double ds = wave_sum((double)lsum * 0.69314718055994530942), dc = wave_sum((double)lcnt);   // back to nats
   const int wave = tid >> 6;
@@ -621,14 +642,55 @@ int tss_upsample_ce_fwd(const void* low, long ldl, const long long* target, floa
     tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream,
                         (double)B * h * w * C * (esz(dtype) + 8.0) + (double)B * H * W * 8.0, 0);
 #define TSS_CE_LAUNCH(TT, CPV)                                                                                   \
-    hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, \
-                       (const TT*)low, ldl, target, tiles, lossrows, B, C, h, w, H, W, ignore_index, geo)
+    hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV, 0>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, \
+                       (const TT*)low, ldl, target, tiles, lossrows, B, C, h, w, H, W, ignore_index, geo, nullptr, nullptr)
     if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_LAUNCH(bf16_t, 20); else TSS_CE_LAUNCH(bf16_t, 24); }
     else { if (C <= 20) TSS_CE_LAUNCH(float, 20); else TSS_CE_LAUNCH(float, 24); }
 #undef TSS_CE_LAUNCH
   }
   hipLaunchKernelGGL(ce_finalize_rows_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, lossrows, (int)grid, loss, inv_count);
   return tss::check_last("upsample_ce_fwd");
+}
+
+// Per-pixel cross-entropy of the upsampled logits ([B][H][W] f32, 0 for ignored pixels), straight from the low-res logits.
+int tss_upsample_pixel_ce(const void* low, long ldl, const long long* target, float* pix, int B, int C, int h, int w, int H, int W,
+                          int ignore_index, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w && pix, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(low), TSS_ERR_ALIGN);
+  if ((long)B * H * W == 0) return TSS_OK;
+  const CeGeom geo = ce_geom(B, h, w, H, W);
+  const long grid = (long)B * geo.nstrip * geo.nband;
+  tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream, (double)B * h * w * C * esz(dtype) + (double)B * H * W * 12.0, 0);
+#define TSS_CE_LAUNCH(TT, CPV)                                                                                       \
+  hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV, 1>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream,     \
+                     (const TT*)low, ldl, target, nullptr, nullptr, B, C, h, w, H, W, ignore_index, geo, pix, nullptr)
+  if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_LAUNCH(bf16_t, 20); else TSS_CE_LAUNCH(bf16_t, 24); }
+  else { if (C <= 20) TSS_CE_LAUNCH(float, 20); else TSS_CE_LAUNCH(float, 24); }
+#undef TSS_CE_LAUNCH
+  return tss::check_last("upsample_pixel_ce");
+}
+
+// Gradient tiles of sum_p weight(pix[p]) * CE_p with weight = sel[2] for pix > sel[1], sel[3] for pix == sel[1] (top-n mode only),
+// else 0 (sel = the params of tss_ohem_select).  ws as for tss_upsample_ce_fwd; tss_upsample_ce_bwd (inv_count -> 1.0) gathers.
+int tss_upsample_ohem_grad(const void* low, long ldl, const long long* target, const float* pix, const float* sel, float* ws,
+                           int B, int C, int h, int w, int H, int W, int ignore_index, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && C <= 24 && (ldl % 8) == 0 && ldl >= (C + 3) / 4 * 4 && h > 0 && w > 0 && H >= h && W >= w && pix && sel && ws,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(low) && tss::aligned16(ws), TSS_ERR_ALIGN);
+  if ((long)B * H * W == 0) return TSS_OK;
+  const CeGeom geo = ce_geom(B, h, w, H, W);
+  const long grid = (long)B * geo.nstrip * geo.nband;
+  float* tiles = ws + grid * 4;
+  tss::ProfScope prof(TSS_K_UPSAMPLE_CE_FWD, (hipStream_t)stream, (double)B * h * w * C * (esz(dtype) + 8.0) + (double)B * H * W * 12.0, 0);
+#define TSS_CE_LAUNCH(TT, CPV)                                                                                       \
+  hipLaunchKernelGGL((upsample_ce_onepass_kernel<TT, CPV, 2>), dim3((int)grid), dim3(NT), 0, (hipStream_t)stream,     \
+                     (const TT*)low, ldl, target, tiles, nullptr, B, C, h, w, H, W, ignore_index, geo, const_cast<float*>(pix), sel)
+  if (dtype == TSS_BF16) { if (C <= 20) TSS_CE_LAUNCH(bf16_t, 20); else TSS_CE_LAUNCH(bf16_t, 24); }
+  else { if (C <= 20) TSS_CE_LAUNCH(float, 20); else TSS_CE_LAUNCH(float, 24); }
+#undef TSS_CE_LAUNCH
+  return tss::check_last("upsample_ohem_grad");
 }
 
 int tss_upsample_ce_bwd(const float* ws, const float* inv_count, const float* grad_out, void* dlow, long ldl,

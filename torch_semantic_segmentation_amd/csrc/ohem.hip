@@ -219,6 +219,17 @@ int tss_ohem_fwd(const void* logits, const long long* target, float* lse, float*
     hipLaunchKernelGGL(ohem_pixel_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(NT), 0, st, (const bf16_t*)logits, target, lse, pixel_loss, B, C, HW, ignore_index);
   else
     hipLaunchKernelGGL(ohem_pixel_kernel<float>, dim3(grid_for(n / 8)), dim3(NT), 0, st, (const float*)logits, target, lse, pixel_loss, B, C, HW, ignore_index);
+  return tss_ohem_select(pixel_loss, workspace, loss, params, n, thresh_loss, n_top, stream);
+}
+
+// The selection of TSS/losses/ohem_loss.py:13-21 on an array of n per-pixel losses (>= 0; n % 4 == 0): loss value + the
+// parameters [mode, cut, weight of l > cut, weight of l == cut] the backward kernels turn into per-pixel weights.
+int tss_ohem_select(const float* pixel_loss, void* workspace, float* loss, float* params, long n, float thresh_loss, long n_top,
+                    void* stream) {
+  TSS_REQUIRE(n > 0 && (n % 4) == 0 && n_top >= 0 && n_top < n && pixel_loss && workspace && loss && params, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(pixel_loss) && tss::aligned16(workspace), TSS_ERR_ALIGN);
+  hipStream_t st = (hipStream_t)stream;
+  OhemState* ws = reinterpret_cast<OhemState*>(workspace);
   const int hgrid = grid_for(n / 4) > 1024 ? 1024 : grid_for(n / 4);
   for (int pass = 0; pass < 3; ++pass) {
     hipLaunchKernelGGL(ohem_hist_kernel, dim3(hgrid), dim3(NT), 0, st, pixel_loss, n, ws, pass);
@@ -226,7 +237,7 @@ int tss_ohem_fwd(const void* logits, const long long* target, float* lse, float*
   }
   hipLaunchKernelGGL(ohem_sum_kernel, dim3(hgrid), dim3(NT), 0, st, pixel_loss, n, ws, thresh_loss);
   hipLaunchKernelGGL(ohem_finalize_kernel, dim3(1), dim3(64), 0, st, ws, thresh_loss, (long long)n_top, loss, params);
-  return tss::check_last("ohem_fwd");
+  return tss::check_last("ohem_select");
 }
 
 int tss_ohem_bwd(const void* logits, const long long* target, const float* lse, const float* pixel_loss,

@@ -187,7 +187,7 @@ class Trainer:
         # value and gradients, but the full-resolution logits never exist (-1.3 GB and ~0.8 ms at 8x1024x2048:
         # one 0.26 ms kernel instead of five that move 3.8 GB).  Only taken when nothing can observe the difference
         # (our loss class, a model that offers forward_lowres, no hooks on the model itself).
-        self.fuse_head_loss = bool(fuse_head_loss) and isinstance(loss_fn, ops.CrossEntropyLoss) \
+        self.fuse_head_loss = bool(fuse_head_loss) and type(loss_fn) in (ops.CrossEntropyLoss, ops.OHEMLoss) \
             and hasattr(model, 'forward_lowres') and hasattr(model, 'logit_scale')
         if self.flat:
             optimizer.grad_scale = 1.0 / world_size
@@ -239,8 +239,12 @@ class Trainer:
         with ops.direct_grads(self.flat), self.shadows:
             if self.fuse_head_loss and not (self.model._forward_hooks or self.model._forward_pre_hooks):
                 low = self.model.forward_lowres(x)
-                loss = ops.upsample_cross_entropy(low, y, scale_factor=self.model.logit_scale,
-                                                  ignore_index=self.loss_fn.ignore_index)
+                if type(self.loss_fn) is ops.OHEMLoss:
+                    loss = ops.upsample_ohem_loss(low, y, scale_factor=self.model.logit_scale, ignore_index=self.loss_fn.ignore_index,
+                                                  thresh_loss=self.loss_fn.thresh_loss, numel_frac=self.loss_fn.numel_frac)
+                else:
+                    loss = ops.upsample_cross_entropy(low, y, scale_factor=self.model.logit_scale,
+                                                      ignore_index=self.loss_fn.ignore_index)
             else:
                 y_pred = self.model(x)
                 loss = self.loss_fn(y_pred, y)

@@ -1807,6 +1807,70 @@ def upsample_cross_entropy(low, target, scale_factor=None, size=None, ignore_ind
     return UpsampleCrossEntropyFn.apply(low, target, ho, wo, ignore_index)
 
 
+class UpsampleOHEMFn(Function):
+    """ohem_loss(F.interpolate(low, scale, bilinear, align_corners=True), target) (TSS/losses/ohem_loss.py:10-21 on the
+    decoder head of TSS/models/fastscnn.py:40-43) without the full-resolution logits: the per-pixel cross-entropy is computed
+    straight from the low-res logits, the radix select runs on that [B,H,W] f32 array, and backward recomputes the softmax of
+    the selected pixels from the low-res logits again (gradient tiles, fixed-order gather: no atomics)."""
+
+    @staticmethod
+    def forward(ctx, low, target, ho, wo, ignore_index, thresh_loss, numel_frac):
+        B, C, h, w = low.shape
+        dev = low.device
+        target = target.contiguous()
+        key = (dev.type, dev.index)
+        if key not in OHEMFn._ws:          # zeroed once; every call leaves it zeroed
+            OHEMFn._ws[key] = torch.zeros(N.lib().tss_ohem_workspace_bytes(), dtype=torch.uint8, device=dev)
+        pix = torch.empty((B, ho, wo), dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)              # loss, 3 pad, the 4 selection parameters (16 B aligned)
+        code = N.dtype_code(low.dtype)
+        call('tss_upsample_pixel_ce', ptr(low), ld(low), ptr(target), ptr(pix), B, C, h, w, ho, wo, int(ignore_index), code, stream())
+        call('tss_ohem_select', ptr(pix), ptr(OHEMFn._ws[key]), ptr(out[0:1]), ptr(out[4:8]), B * ho * wo, float(thresh_loss),
+             int(B * ho * wo * float(numel_frac)), stream())
+        ctx.geom = (B, C, h, w, ho, wo, ld(low), low.dtype, int(ignore_index))
+        ctx.save_for_backward(low, target, pix, out)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        low, target, pix, out = ctx.saved_tensors
+        B, C, h, w, ho, wo, ldl, dtype, ignore_index = ctx.geom
+        dev = low.device
+        gout = gout.to(torch.float32).contiguous()
+        ws = torch.empty(N.lib().tss_upsample_ce_ws(B, C, h, w, ho, wo), dtype=torch.float32, device=dev)
+        code = N.dtype_code(dtype)
+        call('tss_upsample_ohem_grad', ptr(low), ldl, ptr(target), ptr(pix), ptr(out[4:8]), ptr(ws), B, C, h, w, ho, wo,
+             ignore_index, code, stream())
+        base = torch.empty((B, h, w, ldl), dtype=dtype, device=dev)
+        call('tss_upsample_ce_bwd', ptr(ws), ptr(_unit(dev)), ptr(gout), ptr(base), ldl, B, C, h, w, ho, wo, code, stream())
+        return base.permute(0, 3, 1, 2)[:, :C], None, None, None, None, None, None
+
+
+_UNIT = {}
+
+
+def _unit(dev):
+    key = (dev.type, dev.index)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones(1, dtype=torch.float32, device=dev)
+    return _UNIT[key]
+
+
+def upsample_ohem_loss(low, target, scale_factor=None, size=None, ignore_index=-100, thresh_loss=0.35667494393873245,
+                       numel_frac=0.01):
+    """Fused decoder head + the reference recipe's loss (scripts/train_fastscnn.py with TSS/losses/ohem_loss.py):
+    ohem_loss(F.interpolate(low, scale_factor, mode='bilinear', align_corners=True), target, ...) from the low-res logits."""
+    low = to_nhwc(materialize(low))
+    ho, wo = _out_size(low, size, scale_factor)
+    B = low.shape[0]
+    if low.shape[1] > 24 or ho < low.shape[2] or wo < low.shape[3] or (B * ho * wo) % 4:
+        return ohem_loss(upsample_logits(low, size=(ho, wo)), target, ignore_index, thresh_loss, numel_frac)
+    if target.dtype != torch.int64 or tuple(target.shape) != (B, ho, wo):
+        raise RuntimeError('target must be int64 of shape (B,H,W) = %s' % ((B, ho, wo),))
+    _check_device(target)
+    return UpsampleOHEMFn.apply(low, target, ho, wo, ignore_index, thresh_loss, numel_frac)
+
+
 def upsample_argmax_confusion(low, target=None, scale_factor=None, size=None, ignore_index=255, confusion=None,
                               want_pred=True):
     """argmax_confusion(F.interpolate(low, scale, bilinear, align_corners=True), ...) without the full-resolution logits
