@@ -159,6 +159,47 @@ int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* ---- general dense convolution: kh x kw taps (odd sides), padding = dilation * (k - 1) / 2 on each axis, any stride, optional bias ---
+ * replaces: the strided 3x3 / 5x5 / 7x7 ConvBlocks of APNModule TSS/models/lednet.py:62-64, the strided 3x3 (with bias) of
+ *           DownsamplingBlock lednet.py:130-131 / esnet.py:54-56, and the 1x5 / 5x1 layers of FCUBlock esnet.py:83-113.
+ * Weights as [kh*kw][N][Cin] (fwd) / [kh*kw][Cin][N] (bwd_data) from tss_permute_wtaps(T = kh*kw); bwd_weight accumulates into the
+ * torch layout [N][Cin][kh][kw].  bwd_data: e is [B][(Hin-1)/stride+1][(Win-1)/stride+1][N], e_in is [B][Hin][Win][Cin]. */
+int tss_convkxk_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                    int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil, int dtype, void* stream);
+int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil, int dtype, void* stream);
+int tss_convkxk_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                           float* dw, int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil,
+                           int dtype, void* stream);
+
+/* ---- glue of LEDNet / ESNet (csrc/zoo.hip) -------------------------------------------------------------------------------
+ * tss_tensor_stats: BatchNorm statistics (slab rows [tss_stat_slabs()][2C], sums and raw second moments) of a materialised tensor:
+ *   the nn.BatchNorm2d after torch.cat([conv(x), pool(x)]) of DownsamplingBlock TSS/models/lednet.py:126-144, esnet.py:47-68;
+ * tss_bn_bwd_apply: that BatchNorm's input gradient dz = ga (e - gce) + gb (z - gmu) (gb NULL: ga e, frozen statistics);
+ * tss_pool_concat_*: z = cat([y1 + bias (N1 channels), max_pool2d(x, 2) (Cin channels)]); x is addressed by element strides
+ *   (an NHWC activation, or the NCHW f32 image: x_f32 = 1); bwd writes dx ([B][Hin][Win][Cin], dtype) from dz[:, N1:];
+ * tss_mul_addrows_*: out = u * a + r[image] of APNModule lednet.py:86-90; ws: B * tss_rows_slices(B, HW) * C floats;
+ * tss_scale_rows: out = x * m[image][channel] (nn.Dropout2d with the mask m drawn by the caller; its own backward). */
+int tss_tensor_stats(const void* z, long ldz, long P, int C, double* stats, int dtype, void* stream);
+int tss_bn_bwd_apply(const void* e, long lde, const void* z, long ldz, const float* ga, const float* gb, const float* gce,
+                     const float* gmu, void* dz, long lddz, long P, int C, int dtype, void* stream);
+int tss_pool_concat_fwd(const void* y1, long ld1, const float* bias, int N1, const void* x, int x_f32, long sxb, long sxc, long sxh,
+                        long sxw, int Cin, void* z, long ldz, int B, int Hin, int Win, int dtype, void* stream);
+int tss_pool_concat_bwd(const void* dz, long lddz, int N1, const void* x, int x_f32, long sxb, long sxc, long sxh, long sxw, int Cin,
+                        void* dx, long lddx, int B, int Hin, int Win, int dtype, void* stream);
+int tss_rows_slices(int B, long HW);
+int tss_mul_addrows_fwd(const void* u, long ldu, const void* a, long lda, const void* r, long ldr, void* out, long ldo, int B, long HW,
+                        int C, int dtype, void* stream);
+int tss_mul_addrows_bwd(const void* g, long ldg, const void* u, long ldu, const void* a, long lda, void* du, long lddu, void* da,
+                        long ldda, void* dr, long lddr, float* ws, int B, long HW, int C, int dtype, void* stream);
+int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream);
+
 /* channel_shuffle(x, groups) TSS/models/lednet.py:183-188: y[:, j * groups + i] = x[:, i * (C / groups) + j] (its own inverse with
  * groups' = C / groups: the backward is the same entry) */
 int tss_channel_shuffle(const void* x, long ldx, void* y, long ldy, long P, int C, int groups, int dtype, void* stream);

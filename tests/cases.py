@@ -152,3 +152,38 @@ def product_psp(name):
 def psp_inputs(name):
     from oracle.recipe import lattice_input
     return [lattice_input(*s).mul(1.0 + 0.25 * i) for i, s in enumerate(PSP_SHAPES[name])]
+
+
+# ----------------------------------------------------------------------------- LEDNet + ESNet blocks (tests/golden/zoo.npz)
+ZOO_SHAPES = {'led_down_img': [(2, 3, 16, 24)], 'led_down': [(2, 32, 12, 20)], 'led_apn': [(2, 32, 16, 24)],
+              'es_fcu3': [(2, 16, 12, 20)], 'es_fcu5': [(2, 32, 12, 20)], 'es_fpcu': [(2, 32, 12, 20)], 'es_down': [(2, 16, 12, 20)]}
+LEDNET_SHAPE = (2, 3, 64, 128)
+
+
+def oracle_zoo(name):
+    from oracle import zoo as OZ
+    return {'led_down_img': lambda: OZ.Down(3, 32), 'led_down': lambda: OZ.Down(32, 64), 'led_apn': lambda: OZ.AttentionPyramid(32, 19),
+            'es_fcu3': lambda: OZ.FactorizedUnit(16, 3), 'es_fcu5': lambda: OZ.FactorizedUnit(32, 5),
+            'es_fpcu': lambda: OZ.ParallelFactorizedUnit(32, [2, 5, 9]), 'es_down': lambda: OZ.Down(16, 64, 'activation'),
+            'led_net': lambda: OZ.LedNetOracle(3, 19)}[name]()
+
+
+def product_zoo(name):
+    import importlib
+    L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
+    E = importlib.import_module('torch_semantic_segmentation_amd.models.esnet')
+    return {'led_down_img': lambda: L.DownsamplingBlock(3, 32), 'led_down': lambda: L.DownsamplingBlock(32, 64),
+            'led_apn': lambda: L.APNModule(32, 19), 'es_fcu3': lambda: E.FCUBlock(16, 16, 3), 'es_fcu5': lambda: E.FCUBlock(32, 32, 5),
+            'es_fpcu': lambda: E.FPCUBlock(32, 32, [2, 5, 9]), 'es_down': lambda: E.DownsamplingBlock(16, 64),
+            'led_net': lambda: L.lednet(3, 19)}[name]()
+
+
+def zoo_inputs(name):
+    from oracle.recipe import lattice_input
+    return [lattice_input(*s).mul(1.0 + 0.25 * i) for i, s in enumerate(ZOO_SHAPES[name])]
+
+
+def zero_all_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout2d)):
+            mod.p = 0.0

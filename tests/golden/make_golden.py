@@ -271,6 +271,66 @@ def gen_pspnet():
     print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(blob), 'arrays')
 
 
+# ----------------------------------------------------------------------------- G6: LEDNet + ESNet blocks
+
+def zoo_cases():
+    led = importlib.import_module('torch_semantic_segmentation.models.lednet')
+    es = importlib.import_module('torch_semantic_segmentation.models.esnet')
+    return {
+        # LEDNet (TSS/models/lednet.py): encoder down-sampler on the image and on an activation, the APN decoder with 19 classes
+        'led_down_img': (lambda: led.DownsamplingBlock(3, 32), [(2, 3, 16, 24)]),
+        'led_down': (lambda: led.DownsamplingBlock(32, 64), [(2, 32, 12, 20)]),
+        'led_apn': (lambda: led.APNModule(32, 19), [(2, 32, 16, 24)]),
+        # ESNet (TSS/models/esnet.py): factorized units with K = 3 and K = 5, the parallel dilated unit, the down-sampler 16 -> 64
+        'es_fcu3': (lambda: es.FCUBlock(16, 16, 3), [(2, 16, 12, 20)]),
+        'es_fcu5': (lambda: es.FCUBlock(32, 32, 5), [(2, 32, 12, 20)]),
+        'es_fpcu': (lambda: es.FPCUBlock(32, 32, [2, 5, 9]), [(2, 32, 12, 20)]),
+        'es_down': (lambda: es.DownsamplingBlock(16, 64), [(2, 16, 12, 20)]),
+    }
+
+
+def zero_all_dropout(m):
+    for mod in m.modules():
+        if isinstance(mod, (nn.Dropout, nn.Dropout2d)):
+            mod.p = 0.0
+
+
+def gen_zoo():
+    """Blocks: forward, dX and every parameter gradient in train and eval mode (formula weights, lattice input, fixed cotangent).
+    Whole LedNet (TSS/models/lednet.py:13-55) on a 2 x 3 x 64 x 128 lattice image: eval-mode logits (every 4th pixel, f32) and
+    the full arg-max map; train-mode logits of the same (dropout p = 0: torch's Dropout2d draws cannot be reproduced elsewhere)."""
+    blob = {}
+    for mode in ('train', 'eval'):
+        for name, (make, shapes) in zoo_cases().items():
+            def make0(make=make):
+                m = make()
+                zero_all_dropout(m)
+                return m
+            rec = run_block(make0, shapes, training=(mode == 'train'))
+            for k, v in rec.items():
+                blob['%s/%s/%s' % (mode, name, k)] = v
+    led = importlib.import_module('torch_semantic_segmentation.models.lednet')
+    m = led.lednet(3, 19)
+    m.load_state_dict(formula_state(m), strict=True)
+    zero_all_dropout(m)
+    x = lattice_input(2, 3, 64, 128)
+    m.eval()
+    with torch.no_grad():
+        out = m(x)
+    blob['eval/led_net/out_sub4'] = np32(out[:, :, ::4, ::4])
+    blob['eval/led_net/argmax'] = out.argmax(1).numpy().astype(np.uint8)
+    blob['eval/led_net/lowres'] = np32(m.decoder(m.encoder(x)))
+    m.train()
+    out = m(x)
+    blob['train/led_net/out_sub4'] = np32(out[:, :, ::4, ::4].detach())
+    for n, b in m.named_buffers():
+        if n.endswith('running_mean') or n.endswith('running_var'):
+            blob['train/led_net/buf_norm.' + n] = np.array(b.double().norm().item())
+    path = os.path.join(HERE, 'zoo.npz')
+    np.savez_compressed(path, **blob)
+    print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(blob), 'arrays')
+
+
 # ----------------------------------------------------------------------------- G3c: train step, default init, f32 AND f64
 
 SEEDED_SHAPE = (2, 96, 160)
@@ -321,7 +381,9 @@ def gen_seeded():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['blocks', 'eval', 'train', 'frozen', 'seeded', 'pspnet']
+    which = sys.argv[1:] or ['blocks', 'eval', 'train', 'frozen', 'seeded', 'pspnet', 'zoo']
+    if 'zoo' in which:
+        gen_zoo()
     if 'seeded' in which:
         gen_seeded()
     if 'pspnet' in which:

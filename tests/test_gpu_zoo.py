@@ -174,3 +174,117 @@ def test_fastscnn_aspp_config5_size_vs_oracle():
         tssa.set_compute_dtype(m, torch.float32)
         low32 = m.forward_lowres(x.to(DEV))
     assert ((low16 - low32).norm() / low32.norm()).item() < 3e-2
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+@pytest.mark.parametrize('name', sorted(cases.ZOO_SHAPES))
+def test_lednet_esnet_blocks_match_reference(golden_dir, name, mode):
+    """LEDNet's DownsamplingBlock (on the image and on an activation) and APN decoder with 19 classes, ESNet's FCU (K = 3, 5) /
+    FPCU blocks and down-sampler: forward, dX and every parameter gradient against vectors of the imported reference
+    (tests/golden/zoo.npz; TSS/models/lednet.py:58-92,126-144, TSS/models/esnet.py:47-68,83-166), f32, 1e-3."""
+    import torch_semantic_segmentation_amd as tssa
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo.npz'))
+    m = cases.product_zoo(name)
+    o = cases.oracle_zoo(name)
+    assert list(m.state_dict()) == list(o.state_dict())
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_all_dropout(m)
+    m.train(mode == 'train').to(DEV)
+    tssa.set_compute_dtype(m, torch.float32)
+    image = name == 'led_down_img'
+    x = cases.zoo_inputs(name)[0].to(DEV).requires_grad_(not image)
+    out = m(x)
+    out.backward(cases.block_cotangent(out.shape).to(DEV))
+    key = '%s/%s/' % (mode, name)
+    assert tuple(out.shape) == g[key + 'out'].shape
+    assert close(out.detach().cpu().numpy(), g[key + 'out']), 'forward'
+    if not image:
+        assert close(x.grad.cpu().numpy(), g[key + 'dx0']), 'dx'
+    for pname, p in m.named_parameters():
+        ref = g[key + 'dw.' + pname]
+        if mode == 'train' and (pname.endswith('.2.bias') or pname == 'conv.bias'):
+            # a convolution bias in front of a training-mode BatchNorm: the exact gradient is 0 -- the reference returns rounding noise
+            # (1e-4 of the layer's weight gradient), the HIP path returns 0
+            wref = np.abs(g[key + 'dw.' + pname[:-4] + 'weight']).max()
+            assert np.abs(ref).max() < 1e-3 * wref, pname
+            assert p.grad is None or p.grad.abs().max().item() < 1e-3 * wref, pname
+            continue
+        # the level5 arm of the APN normalises over B = 2 values per channel (xhat = +-1): looser, as for the 1x1-bin pyramid arm
+        rel = 5e-3 if (mode == 'train' and name == 'led_apn' and pname.startswith('level5')) else 1e-3
+        assert close(p.grad.cpu().numpy(), ref, rel=rel), pname
+    if mode == 'train':
+        for bname, b in m.named_buffers():
+            if bname.endswith('running_mean') or bname.endswith('running_var'):
+                assert close(b.cpu().numpy(), g[key + 'buf.' + bname]), bname
+
+
+def test_lednet_whole_model_eval_logits_and_argmax(golden_dir):
+    """lednet(3, 19) (TSS/models/lednet.py:13-55) on the 2 x 3 x 64 x 128 lattice image: state_dict keys of the reference, eval-mode
+    logits at 1e-3 and the arg-max map (at most 0.1 % of the pixels on the other side of a near-tie) against the imported
+    reference's fixture; train-mode logits of the same weights; Dropout2d in training mode zeroes whole channels and keeps the mean."""
+    import torch_semantic_segmentation_amd as tssa
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo.npz'))
+    m = cases.product_zoo('led_net')
+    o = cases.oracle_zoo('led_net')
+    assert list(m.state_dict()) == list(o.state_dict())
+    assert all(tuple(a.shape) == tuple(b.shape) for a, b in zip(m.state_dict().values(), o.state_dict().values()))
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_all_dropout(m)
+    m.to(DEV).eval()
+    tssa.set_compute_dtype(m, torch.float32)
+    x = lattice_input(*cases.LEDNET_SHAPE).to(DEV)
+    with torch.no_grad():
+        out = m(x)
+        low = m.forward_lowres(x)
+    assert tuple(out.shape) == (2, 19, 64, 128)
+    assert close(low.float().cpu().numpy(), g['eval/led_net/lowres'])
+    assert close(out[:, :, ::4, ::4].float().cpu().numpy(), g['eval/led_net/out_sub4'])
+    mism = (out.argmax(1).cpu().numpy().astype(np.uint8) != g['eval/led_net/argmax']).mean()
+    assert mism <= 1e-3, mism
+    m.train()
+    out_t = m(x)
+    assert close(out_t[:, :, ::4, ::4].detach().float().cpu().numpy(), g['train/led_net/out_sub4'], rel=5e-3)
+    out_t.float().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    for n, b in m.named_buffers():
+        if n.endswith('running_mean') or n.endswith('running_var'):
+            assert abs(b.double().norm().item() / max(float(g['train/led_net/buf_norm.' + n]), 1e-12) - 1) < 5e-3, n
+
+
+def test_channel_dropout_zeroes_whole_channels():
+    """nn.Dropout2d in training mode (TSS/models/lednet.py:113): per (image, channel) either all zeros or x / (1 - p); backward
+    applies the same mask; eval mode and p = 0 are the identity."""
+    from torch_semantic_segmentation_amd import ops
+    torch.manual_seed(0)
+    x = (torch.randn(4, 64, 9, 11, device=DEV) + 3.0).requires_grad_(True)
+    y = ops.channel_dropout(x, 0.3, True)
+    ratio = (y / x.detach()).detach()
+    per = ratio.flatten(2)
+    assert torch.allclose(per.min(2)[0], per.max(2)[0])                        # one factor per (image, channel)
+    vals = per[:, :, 0]
+    assert torch.all((vals == 0) | ((vals - 1 / 0.7).abs() < 1e-5))
+    assert 0.1 < (vals == 0).float().mean().item() < 0.5
+    y.backward(torch.ones_like(y))
+    assert torch.allclose(x.grad.flatten(2)[:, :, 0], vals, atol=1e-6)
+    assert ops.channel_dropout(x, 0.3, False) is x and ops.channel_dropout(x, 0.0, True) is x
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_lednet_trains_under_the_trainer_in_bf16(use_graph):
+    """lednet(3, 19) with bf16 activations, Dropout2d active, the fused x8 head + cross-entropy and FlatAdamW, eagerly and as a
+    captured HIP graph: finite losses that fall on a fixed batch, BatchNorm running statistics of the padded 19-class layers updated."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import engine as E
+    torch.manual_seed(0)
+    m = cases.product_zoo('led_net').to(DEV)
+    tssa.set_compute_dtype(m, torch.bfloat16)
+    opt = E.FlatAdamW(m.parameters(), lr=2e-3, weight_decay=1e-5)
+    tr = E.Trainer(m, opt, tssa.CrossEntropyLoss(ignore_index=255), use_graph=use_graph)
+    assert tr.fuse_head_loss
+    x, y = synthetic_batch(2, 64, 128)
+    x, y = x.to(DEV), y.to(DEV)
+    losses = [tr.step_async(x, y).item() for _ in range(12)]
+    assert all(np.isfinite(losses)), losses
+    assert min(losses[-3:]) < losses[0], losses
+    bn = m.decoder.level4[1]
+    assert int(bn.num_batches_tracked) == 12 and bn.running_var.ne(1).any()

@@ -167,3 +167,41 @@ def test_pspnet_head_bit_identical(golden_dir, name, mode):
     assert np.array_equal(xs[0].grad.numpy(), g[key + 'dx0'])
     for pname, p in m.named_parameters():
         assert np.array_equal(p.grad.numpy(), g[key + 'dw.' + pname]), pname
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+@pytest.mark.parametrize('name', sorted(cases.ZOO_SHAPES))
+def test_lednet_esnet_blocks_bit_identical(golden_dir, name, mode):
+    """oracle/zoo.py restates TSS/models/lednet.py (DownsamplingBlock, APNModule) and TSS/models/esnet.py (FCUBlock, FPCUBlock,
+    DownsamplingBlock): same bits as the imported reference (make_golden.py gen_zoo) in forward, dX and every parameter gradient."""
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo.npz'))
+    m = cases.oracle_zoo(name)
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_all_dropout(m)
+    m.train(mode == 'train')
+    xs = [x.requires_grad_(True) for x in cases.zoo_inputs(name)]
+    out = m(*xs)
+    out.backward(cases.block_cotangent(out.shape))
+    key = '%s/%s/' % (mode, name)
+    assert np.array_equal(out.detach().numpy(), g[key + 'out'])
+    assert np.array_equal(xs[0].grad.numpy(), g[key + 'dx0'])
+    for pname, p in m.named_parameters():
+        assert np.array_equal(p.grad.numpy(), g[key + 'dw.' + pname]), pname
+
+
+def test_lednet_whole_model_bit_identical(golden_dir):
+    """oracle/zoo.py LedNetOracle == TSS/models/lednet.py LedNet: eval logits, arg-max and train-mode logits of the golden fixture."""
+    from oracle.recipe import lattice_input
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo.npz'))
+    m = cases.oracle_zoo('led_net')
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_all_dropout(m)
+    x = lattice_input(*cases.LEDNET_SHAPE)
+    m.eval()
+    with torch.no_grad():
+        out = m(x)
+    assert np.array_equal(out[:, :, ::4, ::4].numpy(), g['eval/led_net/out_sub4'])
+    assert np.array_equal(out.argmax(1).numpy().astype(np.uint8), g['eval/led_net/argmax'])
+    m.train()
+    out = m(x)
+    assert np.array_equal(out[:, :, ::4, ::4].detach().numpy(), g['train/led_net/out_sub4'])

@@ -55,6 +55,9 @@ struct GemmArgs {
   int a_relu, a0_f32;
   int Hin, Win, Hout, Wout, stride, dil, tap_sign, Cin;
   int tap0, tstep1;       // A_TAPS: local tap t is tap (tap0 + t * (tstep1 + 1)) of the 3x3 grid -- (0, 0): all nine; (3, 0): the 1x3 row; (1, 2): the 3x1 column
+  int gkh, gkw;           // A_TAPS, gkw > 0: a gkh x gkw tap grid instead (odd sides, centred: tap t = row t / gkw, column t % gkw)
+  int tstride;            // A_TAPS, > 1: transposed gather (backward-data of a strided convolution): the source coordinate is
+                          //   (p - off(tap)) / tstride where that division is exact, else the tap contributes nothing
   // weights: element (n, k, tap) at w[n*wrs + k*wcs + tap*wts]
   const float* w; long wrs, wcs, wts;
   const float* bias;
@@ -161,8 +164,10 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
       const bool pow_map = (NT % nvec) == 0;
       const int row0 = tid / nvec, cv0 = tid - row0 * nvec, rstep = pow_map ? NT / nvec : 0;
       if (MODE != A_STEM) {
-        const int tgrid = g.tap0 + tap * (g.tstep1 + 1);
-        const int ky = tgrid / 3, kx = tgrid - ky * 3;
+        int dy, dx;       // this tap's offset from the centre, in units of the dilation
+        if (g.gkw > 0) { const int ty = tap / g.gkw; dy = ty - (g.gkh >> 1); dx = (tap - ty * g.gkw) - (g.gkw >> 1); }
+        else { const int tgrid = g.tap0 + tap * (g.tstep1 + 1); const int ky = tgrid / 3; dy = ky - 1; dx = tgrid - ky * 3 - 1; }
+        dy *= g.tap_sign * g.dil; dx *= g.tap_sign * g.dil;
         const T* a0 = reinterpret_cast<const T*>(g.a0);
         const T* a1 = reinterpret_cast<const T*>(g.a1);
         (void)a1;
@@ -179,9 +184,15 @@ __global__ __launch_bounds__(NT, 2) void convgemm_kernel(const GemmArgs g) {
             } else {
               const long b = p / HWo; const long rem = p - b * HWo;
               const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-              const int iy = oy * g.stride + g.tap_sign * (ky - 1) * g.dil;
-              const int ix = ox * g.stride + g.tap_sign * (kx - 1) * g.dil;
-              if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
+              int iy = oy * g.stride + dy;
+              int ix = ox * g.stride + dx;
+              bool okq = iy >= 0 && ix >= 0;
+              if (g.tstride > 1) {
+                const int qy = iy / g.tstride, qx = ix / g.tstride;
+                okq = okq && qy * g.tstride == iy && qx * g.tstride == ix;
+                iy = qy; ix = qx;
+              }
+              if (okq && iy < g.Hin && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
             }
           }
           vok[i] = q >= 0;
@@ -697,6 +708,52 @@ int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream,
                 (double)g.P * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * esz(dtype));
+}
+
+// ---- general dense convolution: kh x kw taps (odd sides), padding = dilation * (k - 1) / 2 per axis, any stride, optional bias.
+// The strided 3x3 / 5x5 / 7x7 layers of LEDNet's APN decoder (TSS/models/lednet.py:62-64), the strided 3x3 of the
+// DownsamplingBlocks (lednet.py:130-131, esnet.py:54-56) and ESNet's 1x5 / 5x1 factorized layers (esnet.py:83-113): small layers
+// off the benchmarked path, on the generic implicit-GEMM kernel with a kh x kw tap grid.  Weights as [kh*kw][N][Cin] (fwd) and
+// [kh*kw][Cin][N] (bwd_data) from tss_permute_wtaps(T = kh*kw).
+int tss_convkxk_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                    int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && stride >= 1 && dil >= 1 &&
+              kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81 && w_tnc, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.tap_sign = 1; g.Cin = Cin; g.gkh = kh; g.gkw = kw;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  g.P = (long)B * g.Hout * g.Wout; g.KD = Cin; g.ND = N; g.ntaps = kh * kw; g.mode = A_TAPS;
+  g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
+  g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin; g.bias = bias;
+  g.y = y; g.ldy = ldy; g.stats = stats;
+  return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * Hin * Win * Cin + (double)g.P * N) * esz(dtype));
+}
+
+// e: [B][Hout][Wout][N] (Hout = (Hin - 1) / stride + 1), e_in: [B][Hin][Win][Cin]
+int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                         void* e_in, long ldei, double* bstats,
+                         int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (N % 8) == 0 && (Cin % 4) == 0 && (lde % 8) == 0 && lde >= N && (ldei % 4) == 0 && ldei >= Cin &&
+              stride >= 1 && dil >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81 && w_tcn, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  GemmArgs g = {};
+  g.Hin = (Hin - 1) / stride + 1; g.Win = (Win - 1) / stride + 1;      // the SOURCE grid of the gather: the layer's output
+  g.Hout = Hin; g.Wout = Win; g.stride = 1; g.tstride = stride; g.dil = dil; g.tap_sign = -1; g.Cin = N; g.gkh = kh; g.gkw = kw;
+  g.P = (long)B * Hin * Win; g.KD = N; g.ND = Cin; g.ntaps = kh * kw; g.mode = A_TAPS;
+  g.a0 = e; g.lda0 = lde; g.a1 = yraw; g.lda1 = ldyr;
+  if (yraw) { g.c0 = ga; g.c1 = gb; g.c2 = gce; g.c3 = gmu; } else { g.c0 = ga; }
+  g.w = w_tcn; g.wrs = N; g.wcs = 1; g.wts = (long)Cin * N;
+  g.y = e_in; g.ldy = ldei; g.stats = bstats;
+  g.xm = xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream,
+                ((double)B * g.Hin * g.Win * N * (yraw ? 2 : 1) + (double)g.P * Cin * (xraw ? 2 : 1)) * esz(dtype));
 }
 
 int tss_get_option(int key) { return key == TSS_OPT_DISABLE_FAST_PATHS ? g_tss_disable_fast : -1; }

@@ -214,7 +214,6 @@ int tss_ohem_fwd(const void* logits, const long long* target, float* lse, float*
   const long n = B * HW;
   if (n == 0) return TSS_OK;
   hipStream_t st = (hipStream_t)stream;
-  OhemState* ws = reinterpret_cast<OhemState*>(workspace);
   if (dtype == TSS_BF16)
     hipLaunchKernelGGL(ohem_pixel_kernel<bf16_t>, dim3(grid_for(n / 8)), dim3(NT), 0, st, (const bf16_t*)logits, target, lse, pixel_loss, B, C, HW, ignore_index);
   else

@@ -55,6 +55,7 @@ struct WgradArgs {
   const void* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_f32;
   int Hin, Win, Hout, Wout, stride, dil, Cin;
   int tap0, tstep1;               // as in convgemm.hip GemmArgs: which taps of the 3x3 grid the ntaps local taps are
+  int gkh, gkw;                   // gkw > 0: a gkh x gkw tap grid instead (odd sides, centred)
   float* dw; long drs, dcs, dts;  // dW element (n, k, tap) at dw[n*drs + k*dcs + tap*dts]
   int nsplit;
   float* ws;                       // wgfast: partial tiles [tile][nsplit][ws_dim(ND)*ws_dim(KD)] (NULL: atomics onto dw)
@@ -150,8 +151,10 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
   const T* yr = reinterpret_cast<const T*>(g.yraw);
   const T* x = reinterpret_cast<const T*>(g.x);
   const long HWo = (long)g.Hout * g.Wout;
-  const int tgrid = g.tap0 + tap * (g.tstep1 + 1);
-  const int ky = tgrid / 3, kx = tgrid - ky * 3;
+  int tdy, tdx;                   // this tap's offset from the centre, in input pixels
+  if (g.gkw > 0) { const int ty = tap / g.gkw; tdy = ty - (g.gkh >> 1); tdx = (tap - ty * g.gkw) - (g.gkw >> 1); }
+  else { const int tgrid = g.tap0 + tap * (g.tstep1 + 1); const int ky = tgrid / 3; tdy = ky - 1; tdx = tgrid - ky * 3 - 1; }
+  tdy *= g.dil; tdx *= g.dil;
 
   for (long s = s_begin; s < s_end; ++s) {
     const long p0 = s * PT;
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_kernel(const WgradArgs g) {
             } else {
               const long b = p / HWo; const long rem = p - b * HWo;
               const int oy = (int)(rem / g.Wout), ox = (int)(rem - (long)oy * g.Wout);
-              const int iy = oy * g.stride + (ky - 1) * g.dil, ix = ox * g.stride + (kx - 1) * g.dil;
+              const int iy = oy * g.stride + tdy, ix = ox * g.stride + tdx;
               if (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) q = (b * g.Hin + iy) * (long)g.Win + ix;
             }
           }
@@ -724,6 +727,27 @@ int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
   g.dw = dw; g.drs = (long)Cin * 3; g.dcs = 3; g.dts = 1;  // torch layout [N][Cin][1][3] / [N][Cin][3][1]
   return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
                 ((double)g.P * N * (yraw ? 2 : 1) + (double)g.P * Cin) * esz(dtype));
+}
+
+// general dense convolution (tss_convkxk_fwd): dw in the torch layout [N][Cin][kh][kw]
+int tss_convkxk_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gce, const float* gmu,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                           float* dw, int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil,
+                           int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (N % 8) == 0 && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin &&
+              stride >= 1 && dil >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  WgradArgs g = {};
+  g.Hin = Hin; g.Win = Win; g.stride = stride; g.dil = dil; g.Cin = Cin; g.gkh = kh; g.gkw = kw;
+  g.Hout = (Hin - 1) / stride + 1; g.Wout = (Win - 1) / stride + 1;
+  g.P = (long)B * g.Hout * g.Wout; g.ND = N; g.KD = Cin; g.ntaps = kh * kw; g.mode = A_TAPS;
+  g.e = e; g.lde = lde; g.yraw = yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.dw = dw; g.drs = (long)Cin * kh * kw; g.dcs = kh * kw; g.dts = 1;
+  return launch(g, dtype, TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream,
+                ((double)g.P * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin) * esz(dtype));
 }
 
 int tss_stem3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,

@@ -213,7 +213,7 @@ def set_compute_dtype(model, dtype):
     if dtype not in (torch.float32, torch.bfloat16):
         raise TypeError('compute dtype must be float32 or bfloat16')
     for m in model.modules():
-        if isinstance(m, FusedSequential):
+        if isinstance(m, FusedSequential) or 'act_dtype' in type(m).__dict__:
             m.act_dtype = dtype
     model.compute_dtype = dtype
     return model

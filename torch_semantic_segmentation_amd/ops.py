@@ -444,7 +444,7 @@ def _aff(link):
 
 
 def _direct_target(param):
-    g = param.grad if param is not None else None
+    g = param.grad if (param is not None and param.is_leaf) else None
     if _DIRECT[0] and g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda:
         return g
     return None
@@ -607,7 +607,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped', 'kh', 'kw')
 
 
 def _classify(conv, x_is_image):
@@ -622,6 +622,16 @@ def _classify(conv, x_is_image):
             raise NotImplementedError('HIP path: 1x3 / 3x1 convolutions must be dense, stride 1, padding = dilation on the '
                                       'kernel axis: %r' % conv)
         return 'dense1d_w' if ax == 0 else 'dense1d_h', 1, d
+    kh, kw = k
+    if conv.groups == 1 and not x_is_image and kh % 2 == 1 and kw % 2 == 1 and (kh != kw or kh > 3):
+        # general dense convolution (csrc/convgemm.hip, kh x kw tap grid): the 5x5 / 7x7 stride-2 layers of LEDNet's APN decoder
+        # (TSS/models/lednet.py:63-64), the 1x5 / 5x1 layers of ESNet's FCUBlock (TSS/models/esnet.py:83-113)
+        dd = [conv.dilation[i] for i in (0, 1) if k[i] > 1]
+        d = dd[0]
+        if (conv.padding_mode != 'zeros' or conv.stride[0] != conv.stride[1] or any(v != d for v in dd)
+                or tuple(conv.padding) != (d * (kh - 1) // 2 if kh > 1 else 0, d * (kw - 1) // 2 if kw > 1 else 0)):
+            raise NotImplementedError('HIP path: dense k x k convolutions need padding = dilation * (k - 1) / 2 and one stride: %r' % conv)
+        return 'ckk', conv.stride[0], d
     if conv.padding_mode != 'zeros' or k[0] != k[1] or conv.stride[0] != conv.stride[1] \
             or conv.dilation[0] != conv.dilation[1] or conv.padding[0] != conv.padding[1]:
         raise NotImplementedError('HIP path: square kernels/strides/dilations with zero padding only: %r' % conv)
@@ -643,15 +653,21 @@ def _classify(conv, x_is_image):
     return 'dense', s, d
 
 
-def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
+_KEEP = object()
+
+
+def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_KEEP, gamma=None, beta=None, cout=None):
     """conv -> [BatchNorm] -> [ReLU] as ONE deferred unit.  `x` is a Deferred, an NHWC/NCHW activation tensor
-    or (for the stem) the contiguous NCHW image.  Returns a Deferred."""
+    or (for the stem) the contiguous NCHW image.  Returns a Deferred.
+    weight / bias / gamma / beta / cout: run the unit with these tensors instead of the modules' own parameters (a weight padded
+    with zero output rows so that a ragged channel count fills whole 8-channel vectors, a bias that a later kernel adds)."""
     is_image = (not isinstance(x, Deferred)) and x.dim() == 4 and x.shape[1] % 8 != 0
     kind, stride, dil = _classify(conv, is_image)
     cfg = UnitCfg()
     cfg.kind, cfg.stride, cfg.dil = kind, stride, dil
     cfg.overlapped = _overlap_depth[0] > 0
-    cfg.cin, cfg.cout = conv.in_channels, conv.out_channels
+    cfg.cin, cfg.cout = conv.in_channels, (cout or conv.out_channels)
+    cfg.kh, cfg.kw = conv.kernel_size
     if kind == 'stem':
         _check_device(x)
         if x.dtype not in (torch.float32, torch.bfloat16):
@@ -673,19 +689,23 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None):
         raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
     cfg.bn = bn
     cfg.training = False
-    gamma = beta = None
+    if bn is None:
+        gamma = beta = None
     if bn is not None:
         if not isinstance(bn, _BatchNorm):
             raise TypeError('expected a BatchNorm module, got %r' % bn)
         cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
         if cfg.training and bn.momentum is None:
             raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
-        gamma, beta = bn.weight, bn.bias
-    cfg.params = (conv.weight, gamma, beta, conv.bias)
+        if gamma is None:
+            gamma, beta = bn.weight, bn.bias
+    p_weight = conv.weight if weight is None else weight
+    p_bias = conv.bias if bias is _KEEP else bias
+    cfg.params = (p_weight, gamma, beta, p_bias)
     # the kernels read float32 parameters; a model cast with .half() / .to(torch.bfloat16) (TSS
     # scripts/contextnet/benchmark_contextnet.py:62) hands them differentiable f32 views of its 16-bit parameters (boundary
     # plumbing: the gradient flows back through the cast, and the direct-accumulation path below stays off for them)
-    weight, bias = _f32(conv.weight), _f32(conv.bias)
+    weight, bias = _f32(p_weight), _f32(p_bias)
     y = ConvUnitFn.apply(x_raw, weight, _f32(gamma), _f32(beta), bias, cfg)
     return Deferred(y, cfg.out_link, relu)
 
@@ -720,6 +740,32 @@ class _F32Buffers:
             buf.copy_(tmp)
 
 
+def _finalize_forward(link, bn, training, P, Cout, gamma, st):
+    """Statistics slab rows (training) or running statistics (eval) -> mean / invstd / scale of `link`; running statistics updated."""
+    if training:
+        track = bn.track_running_stats and bn.running_mean is not None
+        rbuf = _F32Buffers(bn, track)
+        run_args = (ptr(rbuf.mean), ptr(rbuf.var),
+                    ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None)
+        link.sync = _sync_group(bn)
+        if link.sync is not None:
+            gs = _allreduce_stats(link.stats, P, Cout, link.sync, st)
+            call('tss_bn_finalize_sync', ptr(gs), ptr(gamma), float(bn.eps), float(bn.momentum), *run_args,
+                 ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+        else:
+            call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
+                 float(bn.momentum), *run_args, ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+        rbuf.close()
+    else:
+        pre = _EVAL_AFFINES.get(id(bn)) if _EVAL_AFFINES else None
+        if pre is not None:     # written by the model-wide launch at the top of this forward
+            link.mean, link.invstd, link.scale = pre.unbind(0)
+        else:
+            rbuf = _F32Buffers(bn, True)
+            call('tss_bn_eval_affine', ptr(gamma), ptr(rbuf.mean), ptr(rbuf.var),
+                 float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+
+
 class ConvUnitFn(Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, bias, cfg):
@@ -749,9 +795,13 @@ class ConvUnitFn(Function):
                 raise NotImplementedError('HIP path: depthwise convolution with bias')
             call('tss_dwconv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight),
                  ptr(y), ld(y), stats, B, Hin, Win, Cout, s, d, dt, st)
+        elif cfg.kind == 'ckk' or (cfg.kind == 'dense' and bias is not None):
+            nt = cfg.kh * cfg.kw
+            w_tnc = torch.empty((nt, Cout, cfg.cin), dtype=torch.float32, device=dev)
+            call('tss_permute_wtaps', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, nt, st)
+            call('tss_convkxk_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(bias), ptr(y), ld(y), stats,
+                 B, Hin, Win, cfg.cin, Cout, cfg.kh, cfg.kw, s, d, dt, st)
         elif cfg.kind == 'dense':
-            if bias is not None:
-                raise NotImplementedError('HIP path: dense 3x3 convolution with bias')
             w_tnc = w_tnc16 = None
             if _conv3x3_stream(x.dtype, cfg.cin, Cout, s, cfg.in_link, cfg.in_relu) or _conv3x3_lean(x.dtype, cfg.cin, Cout, s, d):
                 # bf16 tap-major copy: the register-streamed kernel (atrous.hip) / the LDS-halo kernel (conv3x3.hip)
@@ -773,29 +823,7 @@ class ConvUnitFn(Function):
             call('tss_stem3x3_fwd', ptr(x), int(cfg.image_f32), ptr(weight), ptr(y), ld(y), stats,
                  B, cfg.cin, Hin, Win, Cout, s, dt, st)
         if link is not None:
-            bn = cfg.bn
-            if cfg.training:
-                track = bn.track_running_stats and bn.running_mean is not None
-                rbuf = _F32Buffers(bn, track)
-                run_args = (ptr(rbuf.mean), ptr(rbuf.var),
-                            ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None)
-                link.sync = _sync_group(bn)
-                if link.sync is not None:
-                    gs = _allreduce_stats(link.stats, P, Cout, link.sync, st)
-                    call('tss_bn_finalize_sync', ptr(gs), ptr(gamma), float(bn.eps), float(bn.momentum), *run_args,
-                         ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
-                else:
-                    call('tss_bn_finalize', ptr(link.stats), float(P), ptr(gamma), float(bn.eps),
-                         float(bn.momentum), *run_args, ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
-                rbuf.close()
-            else:
-                pre = _EVAL_AFFINES.get(id(bn)) if _EVAL_AFFINES else None
-                if pre is not None:     # written by the model-wide launch at the top of this forward
-                    link.mean, link.invstd, link.scale = pre.unbind(0)
-                else:
-                    rbuf = _F32Buffers(bn, True)
-                    call('tss_bn_eval_affine', ptr(gamma), ptr(rbuf.mean), ptr(rbuf.var),
-                         float(bn.eps), ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+            _finalize_forward(link, cfg.bn, cfg.training, P, Cout, gamma, st)
         cfg.out_link = link
         ctx.cfg = cfg
         ctx.save_for_backward(x, weight, y if link is not None else None)
@@ -901,6 +929,8 @@ class ConvUnitFn(Function):
             elif cfg.kind in ('dense1d_w', 'dense1d_h'):
                 call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout,
                      0 if cfg.kind == 'dense1d_w' else 1, d, dt, wst)
+            elif cfg.kind == 'ckk':
+                call('tss_convkxk_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, cfg.kh, cfg.kw, s, d, dt, wst)
             elif (e.dtype == torch.bfloat16 and s == 1 and y is not None and (Cin * 9) % 8 == 0 and Cout % 8 == 0
                   and not N.fast_paths_disabled()):
                 # unfold once (bf16 [P][Cin*9], column c*9 + tap), then the pointwise MFMA weight-gradient kernel with
@@ -982,9 +1012,14 @@ class ConvUnitFn(Function):
                     call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Cout, Cin, 3, st)
                     call('tss_conv1d3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
                          B, Hin, Win, Cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
+                elif cfg.kind == 'ckk' or s != 1:
+                    # general tap grid / transposed gather of a strided layer (generic implicit-GEMM kernel)
+                    nt = cfg.kh * cfg.kw
+                    w_tcn = torch.empty((nt, Cin, Cout), dtype=torch.float32, device=dev)
+                    call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Cout, Cin, nt, st)
+                    call('tss_convkxk_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
+                         B, Hin, Win, Cin, Cout, cfg.kh, cfg.kw, s, d, dt, st)
                 else:
-                    if s != 1:
-                        raise NotImplementedError('HIP path: input gradient of a strided dense 3x3 convolution')
                     w_tcn = w_tcn16 = None
                     if _conv3x3_lean(e.dtype, Cout, Cin, 1, d):       # contraction over Cout, outputs = Cin
                         w_tcn16 = torch.empty((9, Cin, Cout), dtype=torch.bfloat16, device=dev)
@@ -1000,9 +1035,21 @@ class ConvUnitFn(Function):
         dbias_ret = fused_dbias
         if ctx.has_bias and not (fused_pw and need_dx):
             dbias = _direct_target(p_bias)
-            if dbias is None:
-                dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
-            call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
+            if link is not None and link.training:
+                # BatchNorm with batch statistics removes any per-channel shift: d(loss)/d(bias) is exactly zero
+                if dbias is None:
+                    dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
+            elif link is not None:          # frozen statistics: d(bias) = scale * sum(e)
+                tmp = torch.zeros(Cout, dtype=torch.float32, device=dev)
+                call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(tmp), dt, st)
+                if dbias is None:
+                    dbias_ret = tmp * link.ga
+                else:
+                    dbias.addcmul_(tmp, link.ga)
+            else:
+                if dbias is None:
+                    dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
+                call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
         if side is not None:
             main.wait_stream(side)
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
@@ -1446,6 +1493,207 @@ class GateFn(Function):
 
 fuse_dropout = True    # nn.Dropout after a pending BatchNorm + ReLU rides in the join that materialises it (False: own pass)
 ppm_fused = os.environ.get('TSS_PPM_FUSED', '1') != '0'   # False: every arm through the generic operators (A/B checks)
+
+
+# ----------------------------------------------------------------------------- LEDNet / ESNet glue (csrc/zoo.hip)
+
+class _BNCfg:
+    __slots__ = ('bn', 'training', 'link', 'params')
+
+
+def batch_norm(z, bn, relu=False):
+    """BatchNorm2d (+ReLU) on a MATERIALISED tensor as a deferred unit: the statistics are computed now (one pass over z), the
+    normalisation is applied by the consumer's load like after a convolution.  The nn.BatchNorm2d that follows
+    torch.cat([conv(x), pool(x)]) in DownsamplingBlock (TSS/models/lednet.py:126-144, TSS/models/esnet.py:47-68)."""
+    z = to_nhwc(materialize(z))
+    if not isinstance(bn, _BatchNorm):
+        raise TypeError('expected a BatchNorm module, got %r' % bn)
+    if z.shape[1] % 8 or z.shape[1] != bn.num_features:
+        raise NotImplementedError('HIP path: batch_norm needs %d channels, a multiple of 8; got %d' % (bn.num_features, z.shape[1]))
+    cfg = _BNCfg()
+    cfg.bn = bn
+    cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if cfg.training and bn.momentum is None:
+        raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
+    cfg.params = (bn.weight, bn.bias)
+    y = StandaloneBNFn.apply(z, _f32(bn.weight), _f32(bn.bias), cfg)
+    return Deferred(y, cfg.link, relu)
+
+
+class StandaloneBNFn(Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, cfg):
+        C, P = z.shape[1], npix(z)
+        if cfg.training and P <= 1:
+            raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(z.shape),))
+        st = stream()
+        link = BNLink(C, P, cfg.training, gamma, beta, z.device)
+        if cfg.training:
+            call('tss_tensor_stats', ptr(z), ld(z), P, C, ptr(link.stats), N.dtype_code(z.dtype), st)
+        _finalize_forward(link, cfg.bn, cfg.training, P, C, gamma, st)
+        cfg.link = link
+        ctx.cfg = cfg
+        ctx.has_affine = gamma is not None
+        ctx.save_for_backward(z)
+        return z.view_as(z)
+
+    @staticmethod
+    def backward(ctx, e):
+        cfg = ctx.cfg
+        z, = ctx.saved_tensors
+        link = cfg.link
+        e = to_nhwc(e)
+        C, P = z.shape[1], npix(z)
+        st = stream()
+        dgamma = dbeta = None
+        acc = 0
+        if ctx.has_affine:
+            dgamma, dbeta = _direct_target(cfg.params[0]), _direct_target(cfg.params[1])
+            if dgamma is not None and dbeta is not None:
+                acc = 1
+            else:
+                dgb = torch.empty((2, C), dtype=torch.float32, device=z.device)
+                dgamma, dbeta = dgb[0], dgb[1]
+        if link.sync is not None:
+            raise NotImplementedError('HIP path: cross-replica statistics for a stand-alone BatchNorm')
+        _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st)
+        if acc:
+            dgamma = dbeta = None
+        dz = new_nhwc(*z.shape, e.dtype, z.device)
+        tr = link.training
+        call('tss_bn_bwd_apply', ptr(e), ld(e), ptr(z) if tr else None, ld(z), ptr(link.ga), ptr(link.gb) if tr else None,
+             ptr(link.gce) if tr else None, ptr(link.mean) if tr else None, ptr(dz), ld(dz), P, C, N.dtype_code(e.dtype), st)
+        return dz, dgamma, dbeta, None
+
+
+def pool_concat(y1, bias, x, n1=None):
+    """torch.cat([y1 + bias, F.max_pool2d(x, 2)], dim=1) in one pass (DownsamplingBlock, TSS/models/lednet.py:138-141 /
+    TSS/models/esnet.py:62-65).  y1: the strided convolution's raw output (first n1 channels used; n1 < y1.shape[1] when the layer
+    ran with zero-padded output rows), x: the block input -- an NHWC activation, or the NCHW image."""
+    y1 = to_nhwc(materialize(y1))
+    n1 = y1.shape[1] if n1 is None else n1
+    is_image = x.dim() == 4 and x.shape[1] % 8 != 0
+    if not is_image:
+        x = to_nhwc(materialize(x))
+    else:
+        _check_device(x)
+    B, Cin, Hin, Win = x.shape
+    if Hin % 2 or Win % 2:
+        raise NotImplementedError('HIP path: DownsamplingBlock needs even height and width (torch.cat of the reference fails otherwise)')
+    if tuple(y1.shape) != (B, y1.shape[1], Hin // 2, Win // 2) or n1 > y1.shape[1]:
+        raise RuntimeError('pool_concat: convolution output %s does not match the pooled input %s' % (tuple(y1.shape), tuple(x.shape)))
+    if x.dtype != y1.dtype and x.dtype != torch.float32:
+        raise TypeError('pool_concat: input dtype %s with activations of %s' % (x.dtype, y1.dtype))
+    return PoolConcatFn.apply(y1, _f32(bias), x, n1)
+
+
+class PoolConcatFn(Function):
+    @staticmethod
+    def forward(ctx, y1, bias, x, n1):
+        B, Cin, Hin, Win = x.shape
+        z = new_nhwc(B, n1 + Cin, Hin // 2, Win // 2, y1.dtype, y1.device)
+        x_f32 = int(x.dtype == torch.float32)
+        call('tss_pool_concat_fwd', ptr(y1), ld(y1), ptr(bias), n1, ptr(x), x_f32, *x.stride(), Cin, ptr(z), ld(z), B, Hin, Win,
+             N.dtype_code(z.dtype), stream())
+        ctx.n1, ctx.full1, ctx.has_bias = n1, y1.shape[1], bias is not None
+        ctx.save_for_backward(x)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, = ctx.saved_tensors
+        dz = to_nhwc(dz)
+        B, Cin, Hin, Win = x.shape
+        n1, st, dt = ctx.n1, stream(), N.dtype_code(dz.dtype)
+        dev = dz.device
+        if ctx.full1 == n1:
+            dy1 = dz[:, :n1]
+        elif ctx.full1 == dz.shape[1]:
+            dy1 = dz       # the layer ran with zero-padded output rows: their gradient is discarded by the padding's own backward
+        else:
+            dy1 = new_nhwc(B, ctx.full1, Hin // 2, Win // 2, dz.dtype, dev)
+            dy1.zero_()
+            dy1[:, :n1].copy_(dz[:, :n1])
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:     # column sums through the slab rows: fixed order, no atomics
+            P = npix(dz)
+            slab = torch.empty((N.stat_slabs(), 2 * n1), dtype=torch.float64, device=dev)
+            vec = torch.empty(2 * n1 + 1, dtype=torch.float64, device=dev)
+            call('tss_tensor_stats', ptr(dz), ld(dz), P, n1, ptr(slab), dt, st)
+            call('tss_slab_reduce', ptr(slab), float(P), ptr(vec), n1, st)
+            dbias = vec[:n1].float()
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = new_nhwc(B, Cin, Hin, Win, dz.dtype, dev)
+            call('tss_pool_concat_bwd', ptr(dz), ld(dz), n1, ptr(x), int(x.dtype == torch.float32), *x.stride(), Cin,
+                 ptr(dx), ld(dx), B, Hin, Win, dt, st)
+        return dy1, dbias, dx, None
+
+
+def mul_addrows(u, a, r):
+    """u * a + r with r one row per image ([B, C, 1, 1]): `x * level4(input) + level5(pooled)` of APNModule, TSS/models/lednet.py:86-90."""
+    u, a, r = to_nhwc(materialize(u)), to_nhwc(materialize(a)), to_nhwc(materialize(r))
+    if u.shape != a.shape or u.dtype != a.dtype or r.dtype != u.dtype or tuple(r.shape) != (u.shape[0], u.shape[1], 1, 1) or u.shape[1] % 8:
+        raise RuntimeError('mul_addrows: operands %s, %s, %s' % (tuple(u.shape), tuple(a.shape), tuple(r.shape)))
+    return MulAddRowsFn.apply(u, a, r)
+
+
+class MulAddRowsFn(Function):
+    @staticmethod
+    def forward(ctx, u, a, r):
+        B, C, H, W = u.shape
+        out = new_nhwc(B, C, H, W, u.dtype, u.device)
+        call('tss_mul_addrows_fwd', ptr(u), ld(u), ptr(a), ld(a), ptr(r), ld(r), ptr(out), ld(out), B, H * W, C,
+             N.dtype_code(u.dtype), stream())
+        ctx.save_for_backward(u, a)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        u, a = ctx.saved_tensors
+        g = to_nhwc(g)
+        B, C, H, W = u.shape
+        dev = u.device
+        du, da = new_nhwc(B, C, H, W, g.dtype, dev), new_nhwc(B, C, H, W, g.dtype, dev)
+        dr = new_nhwc(B, C, 1, 1, g.dtype, dev)
+        ws = torch.empty(B * N.lib().tss_rows_slices(B, H * W) * C, dtype=torch.float32, device=dev)
+        call('tss_mul_addrows_bwd', ptr(g), ld(g), ptr(u), ld(u), ptr(a), ld(a), ptr(du), ld(du), ptr(da), ld(da), ptr(dr), ld(dr),
+             ptr(ws), B, H * W, C, N.dtype_code(g.dtype), stream())
+        return du, da, dr
+
+
+def channel_dropout(x, p, training):
+    """nn.Dropout2d (TSS/models/lednet.py:113, TSS/models/esnet.py:117,163): whole channels of an image are zeroed with probability
+    p, the others scaled by 1 / (1 - p).  The mask is drawn with torch's generator (one [B, C] draw), applied by tss_scale_rows."""
+    if not training or p <= 0.0:
+        return x
+    x = to_nhwc(materialize(x))
+    if x.shape[1] % 8:
+        raise NotImplementedError('HIP path: channel dropout needs a multiple of 8 channels')
+    keep = 1.0 - float(p)
+    m = (torch.rand((x.shape[0], x.shape[1]), device=x.device) < keep).to(torch.float32)
+    if keep > 0.0:
+        m = m / keep
+    return ScaleRowsFn.apply(x, m)
+
+
+class ScaleRowsFn(Function):
+    @staticmethod
+    def _run(x, m):
+        B, C, H, W = x.shape
+        out = new_nhwc(B, C, H, W, x.dtype, x.device)
+        call('tss_scale_rows', ptr(x), ld(x), ptr(m), ptr(out), ld(out), B, H * W, C, N.dtype_code(x.dtype), stream())
+        return out
+
+    @staticmethod
+    def forward(ctx, x, m):
+        ctx.save_for_backward(m)
+        return ScaleRowsFn._run(x, m)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, = ctx.saved_tensors
+        return ScaleRowsFn._run(to_nhwc(g), m), None
 
 
 def _hp(tensors):
