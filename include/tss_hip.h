@@ -178,6 +178,12 @@ int tss_convkxk_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            float* dw, int B, int Hin, int Win, int Cin, int N, int kh, int kw, int stride, int dil,
                            int dtype, void* stream);
 
+/* nn.ConvTranspose2d(Cin_t, Cout, k, stride, padding = (k-1)/2, output_padding = stride-1) of UpsamplingBlock TSS/models/esnet.py:71-80:
+ * x [B][Hout/stride][Wout/stride][Cin_t] -> y [B][Hout][Wout][Cout] (+ bias); w_tcn = tss_permute_wtaps(weight as [N = Cin_t][Cin = Cout]
+ * [T = kh*kw]).  Its backward is tss_convkxk_fwd (input gradient) and tss_convkxk_bwd_weight with the roles of x and the gradient swapped. */
+int tss_convkxk_transposed_fwd(const void* x, long ldx, const float* w_tcn, const float* bias, void* y, long ldy,
+                               int B, int Hout, int Wout, int Cout, int Cin_t, int kh, int kw, int stride, int dtype, void* stream);
+
 /* ---- glue of LEDNet / ESNet (csrc/zoo.hip) -------------------------------------------------------------------------------
  * tss_tensor_stats: BatchNorm statistics (slab rows [tss_stat_slabs()][2C], sums and raw second moments) of a materialised tensor:
  *   the nn.BatchNorm2d after torch.cat([conv(x), pool(x)]) of DownsamplingBlock TSS/models/lednet.py:126-144, esnet.py:47-68;

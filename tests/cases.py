@@ -156,7 +156,9 @@ def psp_inputs(name):
 
 # ----------------------------------------------------------------------------- LEDNet + ESNet blocks (tests/golden/zoo.npz)
 ZOO_SHAPES = {'led_down_img': [(2, 3, 16, 24)], 'led_down': [(2, 32, 12, 20)], 'led_apn': [(2, 32, 16, 24)],
-              'es_fcu3': [(2, 16, 12, 20)], 'es_fcu5': [(2, 32, 12, 20)], 'es_fpcu': [(2, 32, 12, 20)], 'es_down': [(2, 16, 12, 20)]}
+              'es_fcu3': [(2, 16, 12, 20)], 'es_fcu5': [(2, 32, 12, 20)], 'es_fpcu': [(2, 32, 12, 20)], 'es_down': [(2, 16, 12, 20)],
+              'es_up': [(2, 64, 6, 10)], 'es_up_cls': [(2, 16, 6, 10)]}
+ESNET_SHAPE = (2, 3, 32, 64)
 LEDNET_SHAPE = (2, 3, 64, 128)
 
 
@@ -165,6 +167,7 @@ def oracle_zoo(name):
     return {'led_down_img': lambda: OZ.Down(3, 32), 'led_down': lambda: OZ.Down(32, 64), 'led_apn': lambda: OZ.AttentionPyramid(32, 19),
             'es_fcu3': lambda: OZ.FactorizedUnit(16, 3), 'es_fcu5': lambda: OZ.FactorizedUnit(32, 5),
             'es_fpcu': lambda: OZ.ParallelFactorizedUnit(32, [2, 5, 9]), 'es_down': lambda: OZ.Down(16, 64, 'activation'),
+            'es_up': lambda: OZ.Up(64, 16), 'es_up_cls': lambda: OZ.Up(16, 19), 'es_net': lambda: OZ.ESNetOracle(3, 19),
             'led_net': lambda: OZ.LedNetOracle(3, 19)}[name]()
 
 
@@ -175,6 +178,7 @@ def product_zoo(name):
     return {'led_down_img': lambda: L.DownsamplingBlock(3, 32), 'led_down': lambda: L.DownsamplingBlock(32, 64),
             'led_apn': lambda: L.APNModule(32, 19), 'es_fcu3': lambda: E.FCUBlock(16, 16, 3), 'es_fcu5': lambda: E.FCUBlock(32, 32, 5),
             'es_fpcu': lambda: E.FPCUBlock(32, 32, [2, 5, 9]), 'es_down': lambda: E.DownsamplingBlock(16, 64),
+            'es_up': lambda: E.UpsamplingBlock(64, 16), 'es_up_cls': lambda: E.UpsamplingBlock(16, 19), 'es_net': lambda: E.ESNet(3, 19),
             'led_net': lambda: L.lednet(3, 19)}[name]()
 
 

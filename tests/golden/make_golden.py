@@ -286,6 +286,8 @@ def zoo_cases():
         'es_fcu5': (lambda: es.FCUBlock(32, 32, 5), [(2, 32, 12, 20)]),
         'es_fpcu': (lambda: es.FPCUBlock(32, 32, [2, 5, 9]), [(2, 32, 12, 20)]),
         'es_down': (lambda: es.DownsamplingBlock(16, 64), [(2, 16, 12, 20)]),
+        'es_up': (lambda: es.UpsamplingBlock(64, 16), [(2, 64, 6, 10)]),
+        'es_up_cls': (lambda: es.UpsamplingBlock(16, 19), [(2, 16, 6, 10)]),
     }
 
 
@@ -298,7 +300,8 @@ def zero_all_dropout(m):
 def gen_zoo():
     """Blocks: forward, dX and every parameter gradient in train and eval mode (formula weights, lattice input, fixed cotangent).
     Whole LedNet (TSS/models/lednet.py:13-55) on a 2 x 3 x 64 x 128 lattice image: eval-mode logits (every 4th pixel, f32) and
-    the full arg-max map; train-mode logits of the same (dropout p = 0: torch's Dropout2d draws cannot be reproduced elsewhere)."""
+    the full arg-max map; train-mode logits of the same (dropout p = 0: torch's Dropout2d draws cannot be reproduced elsewhere).
+    Whole ESNet (TSS/models/esnet.py:8-44) on a 2 x 3 x 32 x 64 lattice image, the same way."""
     blob = {}
     for mode in ('train', 'eval'):
         for name, (make, shapes) in zoo_cases().items():
@@ -326,6 +329,29 @@ def gen_zoo():
     for n, b in m.named_buffers():
         if n.endswith('running_mean') or n.endswith('running_var'):
             blob['train/led_net/buf_norm.' + n] = np.array(b.double().norm().item())
+    es = importlib.import_module('torch_semantic_segmentation.models.esnet')
+    m = es.ESNet(3, 19)
+    m.load_state_dict(formula_state(m), strict=True)
+    zero_all_dropout(m)
+    x = lattice_input(2, 3, 32, 64)
+    m.eval()
+    with torch.no_grad():
+        out = m(x)
+    blob['eval/es_net/out_sub2'] = np32(out[:, :, ::2, ::2])
+    blob['eval/es_net/argmax'] = out.argmax(1).numpy().astype(np.uint8)
+    m.train()
+    out = m(x)
+    blob['train/es_net/out_sub2'] = np32(out[:, :, ::2, ::2].detach())
+    # the train-mode forward of this fixture is ill-conditioned (tiny maps, ReLU / max-pool decisions on near-ties): the reference in
+    # f64 is the anchor and its own f32 distance from it the yardstick (as for the whole-model gradients of G3c)
+    m64 = es.ESNet(3, 19)
+    m64.load_state_dict(formula_state(m64), strict=True)
+    zero_all_dropout(m64)
+    m64.double().train()
+    out64 = m64(x.double()).detach()
+    blob['train/es_net/out64_sub2'] = out64[:, :, ::2, ::2].numpy()
+    blob['train/es_net/err_ref32'] = np.array(((out.detach().double() - out64).abs().max() / out64.abs().max()).item())
+    print('es_net train err_ref32', blob['train/es_net/err_ref32'])
     path = os.path.join(HERE, 'zoo.npz')
     np.savez_compressed(path, **blob)
     print('wrote', path, '%.1f KiB' % (os.path.getsize(path) / 1024), len(blob), 'arrays')

@@ -205,3 +205,21 @@ def test_lednet_whole_model_bit_identical(golden_dir):
     m.train()
     out = m(x)
     assert np.array_equal(out[:, :, ::4, ::4].detach().numpy(), g['train/led_net/out_sub4'])
+
+
+def test_esnet_whole_model_bit_identical(golden_dir):
+    """oracle/zoo.py ESNetOracle == TSS/models/esnet.py ESNet on the golden fixture (eval logits, arg-max, train-mode logits)."""
+    from oracle.recipe import lattice_input
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo.npz'))
+    m = cases.oracle_zoo('es_net')
+    m.load_state_dict(formula_state(m), strict=True)
+    cases.zero_all_dropout(m)
+    x = lattice_input(*cases.ESNET_SHAPE)
+    m.eval()
+    with torch.no_grad():
+        out = m(x)
+    assert np.array_equal(out[:, :, ::2, ::2].numpy(), g['eval/es_net/out_sub2'])
+    assert np.array_equal(out.argmax(1).numpy().astype(np.uint8), g['eval/es_net/argmax'])
+    m.train()
+    out = m(x)
+    assert np.array_equal(out[:, :, ::2, ::2].detach().numpy(), g['train/es_net/out_sub2'])

@@ -756,6 +756,26 @@ int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                 ((double)B * g.Hin * g.Win * N * (yraw ? 2 : 1) + (double)g.P * Cin * (xraw ? 2 : 1)) * esz(dtype));
 }
 
+// nn.ConvTranspose2d(Cin_t, Cout, k, stride, padding = (k - 1) / 2, output_padding = stride - 1) (UpsamplingBlock, TSS/models/esnet.py:71-80):
+// its forward IS the input-gradient gather of the strided convolution with the same weight tensor ([Cin_t][Cout][kh][kw] read as
+// [N][Cin][taps]): x [B][Hout/stride][Wout/stride][Cin_t] -> y [B][Hout][Wout][Cout], w_tcn = [taps][Cout][Cin_t], bias added.
+int tss_convkxk_transposed_fwd(const void* x, long ldx, const float* w_tcn, const float* bias, void* y, long ldy,
+                               int B, int Hout, int Wout, int Cout, int Cin_t, int kh, int kw, int stride, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cout > 0 && Cin_t > 0 && (Cin_t % 8) == 0 && (Cout % 4) == 0 && (ldx % 8) == 0 && ldx >= Cin_t && (ldy % 4) == 0 && ldy >= Cout &&
+              stride >= 1 && (Hout % stride) == 0 && (Wout % stride) == 0 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81 && w_tcn,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  GemmArgs g = {};
+  g.Hin = Hout / stride; g.Win = Wout / stride;
+  g.Hout = Hout; g.Wout = Wout; g.stride = 1; g.tstride = stride; g.dil = 1; g.tap_sign = -1; g.Cin = Cin_t; g.gkh = kh; g.gkw = kw;
+  g.P = (long)B * Hout * Wout; g.KD = Cin_t; g.ND = Cout; g.ntaps = kh * kw; g.mode = A_TAPS;
+  g.a0 = x; g.lda0 = ldx;
+  g.w = w_tcn; g.wrs = Cin_t; g.wcs = 1; g.wts = (long)Cout * Cin_t; g.bias = bias;
+  g.y = y; g.ldy = ldy;
+  return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * g.Hin * g.Win * Cin_t + (double)g.P * Cout) * esz(dtype));
+}
+
 int tss_get_option(int key) { return key == TSS_OPT_DISABLE_FAST_PATHS ? g_tss_disable_fast : -1; }
 
 int tss_set_option(int key, int value) {

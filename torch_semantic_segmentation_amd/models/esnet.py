@@ -1,5 +1,5 @@
-"""ESNet's blocks on the MI355X HIP path: `FCUBlock`, `FPCUBlock` and `DownsamplingBlock` with the
-constructor arguments, module tree and state_dict keys of TSS/models/esnet.py:47-68,83-166.
+"""ESNet on the MI355X HIP path: `ESNet`, `FCUBlock`, `FPCUBlock`, `DownsamplingBlock` and `UpsamplingBlock`
+with the constructor arguments, module tree and state_dict keys of TSS/models/esnet.py:8-166.
 
   * the factorized 1xK / Kx1 convolutions (K = 3: tss_conv1d3_*; K = 5: the kh x kw tap grid of the generic implicit-GEMM kernel,
     tss_convkxk_*) carry their bias in the kernel epilogue; conv -> ReLU -> conv -> BatchNorm [-> ReLU] is two deferred units;
@@ -8,18 +8,74 @@ constructor arguments, module tree and state_dict keys of TSS/models/esnet.py:47
   * FPCUBlock's three dilated branches (rates 2 / 5 / 9) read one materialised tensor; `sum(branches)` is two `join` passes that
     apply the branches' BatchNorms while adding;
   * nn.Dropout2d in training mode: ops.channel_dropout (a [B, C] mask, tss_scale_rows);
-  * DownsamplingBlock: shared with LEDNet (models/lednet.py downsampling_unit).
-
-Not built: `UpsamplingBlock` (nn.ConvTranspose2d) and therefore the whole `ESNet` -- the decoder half of the model; the transposed
-gather it needs exists (tss_convkxk_bwd_data with stride 2 IS that layer's forward), the module around it does not.
+  * DownsamplingBlock: shared with LEDNet (models/lednet.py downsampling_unit);
+  * UpsamplingBlock: nn.ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1) is the transposed gather of the generic
+    kernel (tss_convkxk_transposed_fwd; backward = the strided convolution and its weight gradient with the roles swapped), followed
+    by a stand-alone deferred BatchNorm (ops.batch_norm); the 19-class classifier runs zero-padded to 24 output channels;
+  * `ESNet`: the nn.Sequential of the reference (TSS/models/esnet.py:8-44), returning full-resolution logits.
 """
+from collections import OrderedDict
+
+import torch
 from torch import nn
+from torch.nn import functional as F
 
 from .. import ops
-from ._fused import FusedSequential, run
-from .lednet import downsampling_unit
+from ._fused import FusedSequential, HipModel, run
+from .lednet import downsampling_unit, _PadBN
 
-__all__ = ['FCUBlock', 'FPCUBlock', 'DownsamplingBlock']
+__all__ = ['ESNet', 'FCUBlock', 'FPCUBlock', 'DownsamplingBlock', 'UpsamplingBlock']
+
+
+class ESNet(HipModel):
+    """(TSS/models/esnet.py:8-44): the reference's nn.Sequential, same child names."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.layer1 = FusedSequential(DownsamplingBlock(in_channels, 16), *[FCUBlock(16, 16, 3, dropout_p=0.03) for _ in range(3)])
+        self.layer2 = FusedSequential(DownsamplingBlock(16, 64), *[FCUBlock(64, 64, 5, dropout_p=0.03) for _ in range(2)])
+        self.layer3 = FusedSequential(DownsamplingBlock(64, 128), *[FPCUBlock(128, 128, [2, 5, 9], dropout_p=0.3) for _ in range(3)])
+        self.layer4 = FusedSequential(UpsamplingBlock(128, 64), FCUBlock(64, 64, 5), FCUBlock(64, 64, 5))
+        self.layer5 = FusedSequential(UpsamplingBlock(64, 16), *[FCUBlock(16, 16, 3) for _ in range(3)])
+        self.classifier = FusedSequential(UpsamplingBlock(16, out_channels))
+
+    def forward(self, input):
+        x = self.image_in(input)
+        for stage in (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.classifier):
+            x = stage(x)
+        return self.logits_out(x, input)
+
+
+class UpsamplingBlock(nn.Sequential):
+    """(TSS/models/esnet.py:71-80)"""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(OrderedDict([
+            ('conv', nn.ConvTranspose2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, output_padding=1)),
+            ('bn', nn.BatchNorm2d(out_channels)),
+            ('activation', nn.ReLU(inplace=True)),
+        ]))
+        self.__dict__['_pad'] = _PadBN()
+
+    def forward(self, input):
+        conv, bn = self.conv, self.bn
+        C = conv.out_channels
+        cp = ops.round_up(C, 8)
+        w, b = conv.weight, conv.bias
+        if cp != C:
+            w = F.pad(w, (0, 0, 0, 0, 0, cp - C))
+            b = F.pad(b, (0, cp - C)) if b is not None else None
+        y = ops.conv_transpose(input, w, b, conv.stride[0])
+        if cp == C:
+            return ops.materialize(ops.batch_norm(y, bn, relu=True))
+        # ragged class count: BatchNorm of the padded width through a hidden module that carries the running statistics (pad channels
+        # are 0 before and after: weight rows 0, bias 0, gamma 1, beta 0)
+        pad = self.__dict__['_pad']
+        sh = pad.enter(bn, cp)
+        out = ops.materialize(ops.batch_norm(y, sh, relu=True, gamma=F.pad(bn.weight, (0, cp - C), value=1.0),
+                                             beta=F.pad(bn.bias, (0, cp - C))))
+        pad.leave(bn)
+        return out[:, :C]
 
 
 class DownsamplingBlock(nn.Module):

@@ -740,6 +740,24 @@ class _F32Buffers:
             buf.copy_(tmp)
 
 
+def _colsum(e, C, st):
+    """Per-channel sums of an NHWC tensor over its pixels (f32 [C]) through the statistics slab rows: fixed order, any C."""
+    P = npix(e)
+    slab = torch.empty((N.stat_slabs(), 2 * C), dtype=torch.float64, device=e.device)
+    vec = torch.empty(2 * C + 1, dtype=torch.float64, device=e.device)
+    call('tss_tensor_stats', ptr(e), ld(e), P, C, ptr(slab), N.dtype_code(e.dtype), st)
+    call('tss_slab_reduce', ptr(slab), float(P), ptr(vec), C, st)
+    return vec[:C].float()
+
+
+def _bias_grad_into(e, P, Cout, out, dt, st):
+    """out (f32 [Cout], pre-filled) += column sums of e"""
+    if Cout <= 64:
+        call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(out), dt, st)
+    else:
+        out.add_(_colsum(e, Cout, st))
+
+
 def _finalize_forward(link, bn, training, P, Cout, gamma, st):
     """Statistics slab rows (training) or running statistics (eval) -> mean / invstd / scale of `link`; running statistics updated."""
     if training:
@@ -1041,7 +1059,7 @@ class ConvUnitFn(Function):
                     dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
             elif link is not None:          # frozen statistics: d(bias) = scale * sum(e)
                 tmp = torch.zeros(Cout, dtype=torch.float32, device=dev)
-                call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(tmp), dt, st)
+                _bias_grad_into(e, P, Cout, tmp, dt, st)
                 if dbias is None:
                     dbias_ret = tmp * link.ga
                 else:
@@ -1049,7 +1067,7 @@ class ConvUnitFn(Function):
             else:
                 if dbias is None:
                     dbias = dbias_ret = torch.zeros(Cout, dtype=torch.float32, device=dev)
-                call('tss_bias_grad', ptr(e), ld(e), P, Cout, ptr(dbias), dt, st)
+                _bias_grad_into(e, P, Cout, dbias, dt, st)
         if side is not None:
             main.wait_stream(side)
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
@@ -1501,7 +1519,7 @@ class _BNCfg:
     __slots__ = ('bn', 'training', 'link', 'params')
 
 
-def batch_norm(z, bn, relu=False):
+def batch_norm(z, bn, relu=False, gamma=None, beta=None):
     """BatchNorm2d (+ReLU) on a MATERIALISED tensor as a deferred unit: the statistics are computed now (one pass over z), the
     normalisation is applied by the consumer's load like after a convolution.  The nn.BatchNorm2d that follows
     torch.cat([conv(x), pool(x)]) in DownsamplingBlock (TSS/models/lednet.py:126-144, TSS/models/esnet.py:47-68)."""
@@ -1515,8 +1533,10 @@ def batch_norm(z, bn, relu=False):
     cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
     if cfg.training and bn.momentum is None:
         raise NotImplementedError('HIP path: BatchNorm with momentum=None (cumulative average) is not supported')
-    cfg.params = (bn.weight, bn.bias)
-    y = StandaloneBNFn.apply(z, _f32(bn.weight), _f32(bn.bias), cfg)
+    if gamma is None:
+        gamma, beta = bn.weight, bn.bias
+    cfg.params = (gamma, beta)
+    y = StandaloneBNFn.apply(z, _f32(gamma), _f32(beta), cfg)
     return Deferred(y, cfg.link, relu)
 
 
@@ -1616,18 +1636,64 @@ class PoolConcatFn(Function):
             dy1[:, :n1].copy_(dz[:, :n1])
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[1]:     # column sums through the slab rows: fixed order, no atomics
-            P = npix(dz)
-            slab = torch.empty((N.stat_slabs(), 2 * n1), dtype=torch.float64, device=dev)
-            vec = torch.empty(2 * n1 + 1, dtype=torch.float64, device=dev)
-            call('tss_tensor_stats', ptr(dz), ld(dz), P, n1, ptr(slab), dt, st)
-            call('tss_slab_reduce', ptr(slab), float(P), ptr(vec), n1, st)
-            dbias = vec[:n1].float()
+            dbias = _colsum(dz, n1, st)
         dx = None
         if ctx.needs_input_grad[2]:
             dx = new_nhwc(B, Cin, Hin, Win, dz.dtype, dev)
             call('tss_pool_concat_bwd', ptr(dz), ld(dz), n1, ptr(x), int(x.dtype == torch.float32), *x.stride(), Cin,
                  ptr(dx), ld(dx), B, Hin, Win, dt, st)
         return dy1, dbias, dx, None
+
+
+def conv_transpose(x, weight, bias, stride, cout=None):
+    """nn.ConvTranspose2d(k odd, stride, padding = (k - 1) / 2, output_padding = stride - 1, bias) on a materialised NHWC tensor
+    (UpsamplingBlock, TSS/models/esnet.py:71-80): the transposed gather of the generic implicit-GEMM kernel.  `weight` is the layer's
+    [Cin][Cout][kh][kw] tensor (Cout may be zero-padded by the caller to a multiple of 8)."""
+    x = to_nhwc(materialize(x))
+    if weight.shape[0] != x.shape[1] or x.shape[1] % 8 or weight.shape[1] % 8 or weight.shape[2] % 2 == 0 or weight.shape[3] % 2 == 0:
+        raise NotImplementedError('HIP path: transposed convolution needs channel counts that are multiples of 8 and odd kernel sides; '
+                                  'got weight %s for input %s' % (tuple(weight.shape), tuple(x.shape)))
+    return ConvTransposeFn.apply(x, _f32(weight), _f32(bias), int(stride))
+
+
+class ConvTransposeFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        B, Ci, H, W = x.shape
+        Co, kh, kw = weight.shape[1], weight.shape[2], weight.shape[3]
+        dev, st, dt = x.device, stream(), N.dtype_code(x.dtype)
+        y = new_nhwc(B, Co, H * stride, W * stride, x.dtype, dev)
+        w_tcn = torch.empty((kh * kw, Co, Ci), dtype=torch.float32, device=dev)
+        call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Ci, Co, kh * kw, st)
+        call('tss_convkxk_transposed_fwd', ptr(x), ld(x), ptr(w_tcn), ptr(bias), ptr(y), ld(y), B, H * stride, W * stride, Co, Ci,
+             kh, kw, stride, dt, st)
+        ctx.stride = stride
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = to_nhwc(g)
+        B, Ci, H, W = x.shape
+        Co, kh, kw = weight.shape[1], weight.shape[2], weight.shape[3]
+        s = ctx.stride
+        dev, st, dt = x.device, stream(), N.dtype_code(g.dtype)
+        dx = dw = dbias = None
+        if ctx.needs_input_grad[0]:        # the strided convolution of the gradient with the same weights
+            w_tnc = torch.empty((kh * kw, Ci, Co), dtype=torch.float32, device=dev)
+            call('tss_permute_wtaps', ptr(weight), ptr(w_tnc), None, Ci, Co, kh * kw, st)
+            dx = new_nhwc(B, Ci, H, W, g.dtype, dev)
+            call('tss_convkxk_fwd', ptr(g), ld(g), None, None, None, 0, ptr(w_tnc), None, ptr(dx), ld(dx), None,
+                 B, H * s, W * s, Co, Ci, kh, kw, s, 1, dt, st)
+        if ctx.needs_input_grad[1]:        # that convolution's weight gradient with the roles of activation and gradient swapped
+            dw = torch.zeros_like(weight)
+            call('tss_convkxk_bwd_weight', ptr(x), ld(x), None, 0, None, None, None, None, ptr(g), ld(g), None, None, None, 0,
+                 ptr(dw), B, H * s, W * s, Co, Ci, kh, kw, s, 1, dt, st)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = _colsum(g, Co, st)
+        return dx, dw, dbias, None
 
 
 def mul_addrows(u, a, r):
