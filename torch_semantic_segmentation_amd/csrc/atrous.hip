@@ -38,7 +38,7 @@ struct AtrousArgs {
 
 // NKS_T: k-steps per tap when known at compile time (4: 128 input channels), 0: g.K / 32 at run time.  FULLN: N == 128 (no
 // fragment guards).  The main instance <4, true> is straight-line code per tap: every guard below folds away.
-template <int NKS_T, bool FULLN, bool STATS>
+template <int NKS_T, bool FULLN, bool STATS, int DIST>
 __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs g) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* Ws = reinterpret_cast<T*>(smem);                         // [2][NCH][RS]
@@ -51,8 +51,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
   const int nvec = K >> 3;                                    // vectors per weight row (4, 8, 12 or 16)
   const int wvv = tid % nvec, wr0 = tid / nvec, wrs = NT / nvec;
   const int nwu = (NCH + wrs - 1) / wrs;                      // passes over the 128 rows (<= 8 for K >= 32)
-  uint4 wreg[8];
-  auto w_issue = [&](int tap) {
+  auto w_issue = [&](int tap, uint4 (&wreg)[8]) {
     const T* wt = g.w9 + (long)tap * N * K;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -66,7 +65,7 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
       }
     }
   };
-  auto w_store = [&](int buf) {
+  auto w_store = [&](int buf, const uint4 (&wreg)[8]) {
     T* dst = Ws + buf * NCH * RS;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -147,29 +146,57 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_stream_kernel(const AtrousArgs 
     // wait the compiler puts in front of it is free, and it covers k-steps 1..3 too; only THEN the next tap's requests (weights
     // first, then activations) -- issued before that wait they would be waited for as well (the wait-count pass falls back to
     // vmcnt(0) for a loop-carried prefetch) and every tap would start with an exposed round trip (measured: 510 us per launch)
-    auto do_tap = [&](int tap, uint4 (&cur)[4][4], uint4 (&nxt)[4][4]) {
-      const T* wbuf = Ws + (tap & 1) * NCH * RS + fr * RS + fq * 8;
-      mfma_step(wbuf, 0, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      if (tap + 1 < 9) { w_issue(wtap(tap + 1)); load_tap(tap + 1, nxt); }
-      __builtin_amdgcn_sched_barrier(0);
+    if (DIST == 1) {
+      uint4 wreg[8];
+      auto do_tap = [&](int tap, uint4 (&cur)[4][4], uint4 (&nxt)[4][4]) {
+        const T* wbuf = Ws + (tap & 1) * NCH * RS + fr * RS + fq * 8;
+        mfma_step(wbuf, 0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) { w_issue(wtap(tap + 1), wreg); load_tap(tap + 1, nxt); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k2 = 1; k2 < 4; ++k2)
-        if (k2 < nks) mfma_step(wbuf, k2, cur);
-      if (tap + 1 < 9) w_store((tap + 1) & 1);
-      __syncthreads();               // next tap's buffer complete / this tap's buffer free for tap + 2
-    };
-    uint4 xa[4][4], xb[4][4];
-    load_tap(0, xa);
-    w_issue(wtap(0));
-    w_store(0);
-    __syncthreads();
+        for (int k2 = 1; k2 < 4; ++k2)
+          if (k2 < nks) mfma_step(wbuf, k2, cur);
+        if (tap + 1 < 9) w_store((tap + 1) & 1, wreg);
+        __syncthreads();               // next tap's buffer complete / this tap's buffer free for tap + 2
+      };
+      uint4 xa[4][4], xb[4][4];
+      load_tap(0, xa);
+      w_issue(wtap(0), wreg);
+      w_store(0, wreg);
+      __syncthreads();
 #pragma unroll 1
-    for (int tp = 0; tp < 8; tp += 2) {
-      do_tap(tp, xa, xb);
-      do_tap(tp + 1, xb, xa);
+      for (int tp = 0; tp < 8; tp += 2) {
+        do_tap(tp, xa, xb);
+        do_tap(tp + 1, xb, xa);
+      }
+      do_tap(8, xa, xb);
+    } else {
+      // prefetch distance TWO taps, nine taps written out (register arrays indexed by constants only): the activation fragments of
+      // tap t + 2 and its weights are requested while tap t computes -- a lone wave per SIMD has ~1.7 us of matrix work between a
+      // request and its use instead of ~0.85 us (128 accumulators + 3 x 64 activation + 32 weight registers of the 512 a lone
+      // wave may use; the weights stay one tap ahead: a second register set for them spilled 52 registers)
+      uint4 xs[3][4][4], wr[8];
+      load_tap(0, xs[0]);
+      w_issue(wtap(0), wr);
+      load_tap(1, xs[1]);
+      w_store(0, wr);
+      __syncthreads();
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const T* wbuf = Ws + (tap & 1) * NCH * RS + fr * RS + fq * 8;
+        mfma_step(wbuf, 0, xs[tap % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) w_issue(wtap(tap + 1), wr);
+        if (tap + 2 < 9) load_tap(tap + 2, xs[(tap + 2) % 3]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k2 = 1; k2 < 4; ++k2)
+          if (k2 < nks) mfma_step(wbuf, k2, xs[tap % 3]);
+        if (tap + 1 < 9) w_store((tap + 1) & 1, wr);
+        __syncthreads();
+      }
     }
-    do_tap(8, xa, xb);
     // ---- epilogue: lane = pixel fr, channels i * 16 + fq * 4 .. + 3
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -239,16 +266,16 @@ bool tss_conv3x3_stream_fwd(const void* x, long ldx, const float* in_scale, int 
   constexpr int smem = 2 * NCH * RS * (int)sizeof(T);
   static tss::DevOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<4, true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<4, true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_stream_kernel<0, false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
   }
   const bool full = Cin == 128 && N == 128;
   const int grid = tss::persistent_blocks(g.ntiles, TSS_STAT_SLABS);
-  if (full && !stats) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, false>), dim3(grid), dim3(NT), smem, stream, g);
-  else if (full) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, true>), dim3(grid), dim3(NT), smem, stream, g);
-  else if (!stats) hipLaunchKernelGGL((conv3x3_stream_kernel<0, false, false>), dim3(grid), dim3(NT), smem, stream, g);
-  else hipLaunchKernelGGL((conv3x3_stream_kernel<0, false, true>), dim3(grid), dim3(NT), smem, stream, g);
+  if (full && !stats) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, false, 1>), dim3(grid), dim3(NT), smem, stream, g);
+  else if (full) hipLaunchKernelGGL((conv3x3_stream_kernel<4, true, true, 1>), dim3(grid), dim3(NT), smem, stream, g);
+  else if (!stats) hipLaunchKernelGGL((conv3x3_stream_kernel<0, false, false, 1>), dim3(grid), dim3(NT), smem, stream, g);
+  else hipLaunchKernelGGL((conv3x3_stream_kernel<0, false, true, 1>), dim3(grid), dim3(NT), smem, stream, g);
   return true;
 }

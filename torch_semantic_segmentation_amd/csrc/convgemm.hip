@@ -521,6 +521,8 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw, long red_P, int red_K, int red_N,
                          long P, int K, int N, hipStream_t stream, const void* radd = nullptr, long ldr = 0);  // pwfast.hip
 void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream);  // wgrad.hip
+bool tss_conv3x3_wstat_fwd(const void* x, long ldx, const float* in_scale, int in_relu, const void* w9, void* y, long ldy,
+                           double* stats, int B, int H, int W, int Cin, int N, int stride, int dil, hipStream_t stream);
 bool tss_conv3x3_stream_fwd(const void* x, long ldx, const float* in_scale, int in_relu, const void* w9, void* y, long ldy,
                             double* stats, int B, int H, int W, int Cin, int N, int stride, int dil, hipStream_t stream);  // atrous.hip
 bool tss_stem_direct_fwd(const void* x_nchw, int x_is_f32, const float* w, void* y, long ldy, double* stats,
@@ -624,6 +626,10 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* 
   if (dtype == TSS_BF16 && w_tnc_bf16 && !g_tss_disable_fast && tss::aligned16(w_tnc_bf16)) {
     tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes, 18.0 * (double)g.P * Cin * N);
     // a materialised input (no BatchNorm / ReLU pending): activations streamed into the MFMA operand registers, any dilation
+    // 128 -> 128 without statistics: weights stationary in registers, activation rows walked through an LDS ring (wstat.hip)
+    if (tss_conv3x3_wstat_fwd(x, ldx, in_scale, in_relu, w_tnc_bf16, y, ldy, stats, B, Hin, Win, Cin, N, stride, dil,
+                              (hipStream_t)stream))
+      return tss::check_last("conv3x3_wstat_fwd");
     if (tss_conv3x3_stream_fwd(x, ldx, in_scale, in_relu, w_tnc_bf16, y, ldy, stats, B, Hin, Win, Cin, N, stride, dil,
                                (hipStream_t)stream))
       return tss::check_last("conv3x3_stream_fwd");
