@@ -295,7 +295,7 @@ def mfma_roofline(model, x):
     if not r or not r['launches'] or r['flops'] <= 0:
         return None
     tf = r['flops'] / (r['ms'] * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'conv3x3_stream_kernel|' + r['symbol'], 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TF,
+    return {'bound': 'mfma', 'kernel': r['symbol'], 'achieved': round(tf, 1), 'peak': MFMA_BF16_PEAK_TF,
             'unit': 'TFLOP/s', 'frac': round(tf / MFMA_BF16_PEAK_TF, 4), 'traffic': None, 'launches_per_forward': r['launches'] // 3,
             'avg_launch_us': round(1e3 * r['ms'] / r['launches'], 2), 'alg_flops_per_launch': round(r['flops'] / r['launches'])}
 

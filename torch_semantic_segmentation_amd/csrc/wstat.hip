@@ -160,13 +160,26 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wstat_kernel(const WsArgs g) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) af[(step + 2) % 3][m] = *reinterpret_cast<const bf16x8*>(an + m * 16 * RS);
         }
-        __builtin_amdgcn_sched_barrier(0);               // (the scheduler would sink the reads back to their uses to save registers)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[step >> 2][step & 3][0], af[cur][m], acc[m][0], 0, 0, 0);
           acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[step >> 2][step & 3][1], af[cur][m], acc[m][1], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // issue order of this step, pinned: each MFMA is followed by one of the step's LDS reads and by the register moves / address
+        // arithmetic the compiler needs for the NEXT step (an MFMA holds the vector issue port for 8 of its 16 cycles: one read and one
+        // or two 4-cycle moves fit behind it; issued as a burst in front of the eight MFMAs they cost 48 cycles per step)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // 2 VALU
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // nothing moves between steps: the reads keep their two-step distance
       }
       if (more) __syncthreads();                          // DMA of row j + 2 landed (vmcnt) and visible; every wave is done with row j - 1
       // ---- store (after the barrier: in flight under the next row's MFMAs): lane = pixel m * 16 + fr, channels nbase + fq * 8 .. + 7
