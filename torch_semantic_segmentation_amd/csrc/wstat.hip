@@ -16,8 +16,8 @@
 //   * the four waves of a block split the OUTPUT CHANNELS (32 each) and share the ring: every activation fragment read from LDS
 //     (one ds_read_b128) feeds 2 MFMAs, the weight operand comes from registers: 0.5 LDS reads per MFMA.
 // Launch: 256 blocks; the output rows in walk order are cut into equal contiguous ranges (a block walks one or two segments).
-// Eval-mode forward of a MATERIALISED input only (no pending BatchNorm / ReLU on load, no statistics): everything else stays on
-// atrous.hip / conv3x3.hip / convgemm.hip.
+// Forward of a MATERIALISED input only (no pending BatchNorm / ReLU on load); the statistics of a training-mode BatchNorm behind the
+// layer leave as one slab row per block.  Everything else stays on atrous.hip / conv3x3.hip / convgemm.hip.
 #include "common.h"
 
 namespace {
@@ -31,12 +31,13 @@ constexpr int VPT = (ROWVEC + NT - 1) / NT;              // per thread (7)
 __device__ __attribute__((aligned(16))) unsigned short g_wstat_zero[8];
 
 struct WsArgs {
-  const T* x; long ldx; const T* w9; T* y; long ldy;
+  const T* x; long ldx; const T* w9; T* y; long ldy; double* stats;
   int B, H, W, D;
   int nstrip;
   long nrows;       // output (row, strip) units = B * nstrip * H, in walk order (see below); block i owns units [i, i + 1) * nrows / blocks
 };
 
+template <bool STATS>
 __global__ __launch_bounds__(NT, 1) void conv3x3_wstat_kernel(const WsArgs g) {
   extern __shared__ __align__(16) unsigned char smem[];
   T* ring = reinterpret_cast<T*>(smem);                   // [RING][ROWPX][RS]
@@ -101,6 +102,11 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wstat_kernel(const WsArgs g) {
         wr[tap][k2][nf] = *reinterpret_cast<const bf16x8*>(
             g.w9 + ((long)tap * NC + nbase + ((fr >> 2) << 3) + nf * 4 + (fr & 3)) * KC + k2 * 32 + fq * 8);
 
+  float st1[STATS ? 8 : 1], st2[STATS ? 8 : 1];      // sums / sums of squares of this lane's 8 channels (training-mode BatchNorm behind the layer)
+  if (STATS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { st1[q] = 0.f; st2[q] = 0.f; }
+  }
   bool first = true;
   while (u < hi) {
     if (!first) {
@@ -193,6 +199,26 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wstat_kernel(const WsArgs g) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) { o[q] = (T)acc[m][0][q]; o[4 + q] = (T)acc[m][1][q]; }
           *reinterpret_cast<bf16x8*>(yrow0 + (long)xx * g.ldy) = o;
+          if (STATS) {                                    // from the bits that are stored
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float v = (float)o[q]; st1[STATS ? q : 0] += v; st2[STATS ? q : 0] += v * v; }
+          }
+        }
+      }
+    }
+  }
+  // ---- statistics slab row of this block: a wave owns its 32 channels alone -- sum over the 16 pixel lanes, no LDS
+  if (STATS) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float a = row16_sum(st1[STATS ? q : 0]), c2 = row16_sum(st2[STATS ? q : 0]);
+      if (fr == 0) {
+        const int ch = nbase + fq * 8 + q;
+        g.stats[(long)blockIdx.x * 2 * NC + ch] = (double)a;
+        g.stats[(long)blockIdx.x * 2 * NC + NC + ch] = (double)c2;
+        for (int rr = blockIdx.x + gridDim.x; rr < TSS_STAT_SLABS; rr += gridDim.x) {
+          g.stats[(long)rr * 2 * NC + ch] = 0.0;
+          g.stats[(long)rr * 2 * NC + NC + ch] = 0.0;
         }
       }
     }
@@ -205,19 +231,22 @@ __global__ __launch_bounds__(NT, 1) void conv3x3_wstat_kernel(const WsArgs g) {
 bool tss_conv3x3_wstat_fwd(const void* x, long ldx, const float* in_scale, int in_relu, const void* w9, void* y, long ldy,
                            double* stats, int B, int H, int W, int Cin, int N, int stride, int dil, hipStream_t stream) {
   static const bool off = getenv("TSS_CONV3X3_WSTAT") && atoi(getenv("TSS_CONV3X3_WSTAT")) == 0;      // A/B switch
-  if (off || stats || in_scale || in_relu || stride != 1 || dil < 1 || dil > MAXD || Cin != KC || N != NC || (ldx % 8) != 0 ||
+  if (off || in_scale || in_relu || stride != 1 || dil < 1 || dil > MAXD || Cin != KC || N != NC || (ldx % 8) != 0 ||
       (ldy % 8) != 0 || (long)B * H * W == 0 || H < dil || !tss::aligned16(y))
     return false;
   WsArgs g = {};
-  g.x = (const T*)x; g.ldx = ldx; g.w9 = (const T*)w9; g.y = (T*)y; g.ldy = ldy;
+  g.x = (const T*)x; g.ldx = ldx; g.w9 = (const T*)w9; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
   g.B = B; g.H = H; g.W = W; g.D = dil;
   g.nstrip = (W + TP - 1) / TP;
   g.nrows = (long)B * g.nstrip * H;
   constexpr int smem = RING * ROWPX * RS * (int)sizeof(T);
   static tss::DevOnce attr;
-  if (attr.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wstat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (attr.first()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wstat_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wstat_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  }
   const int grid = g.nrows < 256 ? (int)g.nrows : 256;
-  hipLaunchKernelGGL(conv3x3_wstat_kernel, dim3(grid), dim3(NT), smem, stream, g);
+  if (stats) hipLaunchKernelGGL(conv3x3_wstat_kernel<true>, dim3(grid), dim3(NT), smem, stream, g);
+  else hipLaunchKernelGGL(conv3x3_wstat_kernel<false>, dim3(grid), dim3(NT), smem, stream, g);
   return true;
 }
