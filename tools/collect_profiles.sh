@@ -47,5 +47,7 @@ python3 bench.py --model contextnet14 --no-cpu-baseline --no-extras > $out/${tag
 python3 bench.py --mode eval --model fastscnn_aspp --steps 50 --warmup 5 > $out/${tag}_bench_eval_c5_aspp.json 2> $out/eval3.err
 TSS_SYNCBN_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --syncbn --no-cpu-baseline --no-extras --no-roofline > $out/${tag}_bench_syncbn_1rank.json 2> $out/syncbn.err
 python3 tools/graph_memset_probe.py > $out/${tag}_memset_probe.log 2>&1; cp gpurun_out/memset_probe.txt $out/${tag}_memset_probe.txt
-python3 tools/micro_atrous.py > $out/${tag}_micro_atrous.txt 2>&1
+python3 tools/micro_atrous.py 2>&1 | grep dil > $out/${tag}_micro_atrous.txt
+TSS_CONV3X3_WSTAT=0 python3 tools/micro_atrous.py 2>&1 | grep dil >> $out/${tag}_micro_atrous.txt
+python3 bench.py --model lednet --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_lednet.json 2> $out/lednet.err
 echo "bench done"
