@@ -694,7 +694,11 @@ def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
 
 @pytest.mark.parametrize('cin,cout,dil,shape', [(128, 128, 6, (1, 40, 72)), (128, 128, 18, (2, 37, 53)), (128, 128, 1, (1, 16, 16)),
                                                 (128, 128, 12, (1, 64, 128)), (64, 32, 2, (2, 19, 33)), (96, 48, 5, (1, 30, 41)),
-                                                (32, 128, 3, (3, 9, 70))])
+                                                (32, 128, 3, (3, 9, 70)),
+                                                # the weight-stationary kernel (wstat.hip): odd dilations (conflicted XOR image), a map as
+                                                # high as one dilation, strips narrower than 64 pixels, more images than rows per block
+                                                (128, 128, 5, (1, 23, 100)), (128, 128, 17, (3, 17, 40)), (128, 128, 2, (9, 8, 24)),
+                                                (128, 128, 9, (2, 64, 65))])
 @pytest.mark.parametrize('train', [False, True])
 def test_dense3x3_streamed_mfma_kernel_vs_torch(cin, cout, dil, shape, train):
     """csrc/atrous.hip (dense 3x3, stride 1, any dilation, activations streamed from global memory into the MFMA operand
