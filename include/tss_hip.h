@@ -110,6 +110,13 @@ int tss_pwconv_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                           float* dw, float* ws, int defer_reduce, long P, int K, int N, int dtype, const tss_bn_bwd_job* fin,
                           void* stream);
 long tss_pwconv_bwd_weight_ws(long P, int K, int N, int dtype);
+/* forward of a 1x1 layer over the channel CONCATENATION of nsrc (2..6) bf16 tensors of 128 channels each, every one with its own
+ * pending BatchNorm (means / scales / biases[i], any of them NULL) and a common ReLU flag; the concatenated tensor is never written.
+ * lds[i] == 0: source i is a single row broadcast to all P pixels.  w: [N][nsrc * 128] f32 (w_bf16: its bf16 copy or NULL).
+ * replaces: torch.cat(branches, dim=1) + the 1x1 `project` conv of a DeepLab-style ASPP head (models/aspp.py), eval mode. */
+int tss_pwconv_fwd_multi(const void* const* srcs, const long* lds, const float* const* means, const float* const* scales,
+                         const float* const* biases, int nsrc, int in_relu, const float* w, const void* w_bf16,
+                         const float* bias, void* y, long ldy, long P, int N, int dtype, void* stream);
 /* the slot reduction of a tss_pwconv_bwd_weight(..., defer_reduce = 1) call that no later launch carried */
 int tss_pwconv_wg_reduce(const float* ws, float* dw, long P, int K, int N, void* stream);
 

@@ -478,6 +478,20 @@ def test_graphed_inference_and_benchmark_model_match_eager_eval():
         g(torch.randn(1, 3, 128, 256, device='cuda'))
     r = tssa.benchmark_model(m, x, iterations=3, warmup=1, use_graph=True)
     assert set(r) == {'fps', 'min', 'max', 'mean', 'std'} and r['fps'] > 0 and r['min'] <= r['mean'] <= r['max']
+    # weights read live (default): a parameter update is seen by the next replay.  frozen_weights=True: the preparation (bf16
+    # shadows, eval affines, 3x3 tap copies) ran once before the capture -- same logits, the update is seen after refresh_weights()
+    gf = tssa.GraphedInference(m, frozen_weights=True)
+    assert torch.equal(gf(x2), want2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+        want3 = m(x2).clone()
+    assert not torch.equal(want3, want2)
+    assert torch.equal(g(x2), want3)
+    stale = gf(x2).clone()
+    assert not torch.equal(stale, want3)          # 1x1 weights and BatchNorm affines still those of the capture
+    gf.refresh_weights()
+    assert torch.equal(gf(x2), want3)
 
 
 @pytest.mark.parametrize('use_graph', [False, True])

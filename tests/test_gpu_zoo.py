@@ -16,6 +16,10 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+
 def close(a, b, rel=1e-3, floor=2e-4):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -317,3 +321,33 @@ def test_esnet_whole_model_eval_logits_and_argmax(golden_dir):
     assert close(out_t[:, :, ::2, ::2].detach().float().cpu().numpy(), g['train/es_net/out64_sub2'], rel=bound), bound
     out_t.float().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_aspp_project_layer_reads_its_branches_in_place(B):
+    """Eval-mode ASPP in bf16: the 1x1 project layer walks the five branches source by source (tss_pwconv_fwd_multi: every branch's
+    BatchNorm + ReLU on load, the image-pooling row broadcast, no concat buffer) -- same output as the concat path that the same
+    module takes with gradients enabled; with two images the pooled branch is not one row and the module must fall back by itself."""
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    from torch_semantic_segmentation_amd.models.aspp import ASPP
+    torch.manual_seed(1)
+    m = ASPP(128, 128, atrous_rates=(2, 4, 6)).to(DEV)
+    for mod in m.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3); mod.running_var.uniform_(0.5, 1.5); mod.weight.data.uniform_(0.5, 1.5); mod.bias.data.normal_(0, 0.2)
+    tssa.set_compute_dtype(m, torch.bfloat16)
+    m.eval()
+    x = ops.to_nhwc(torch.randn(B, 128, 40, 72, device=DEV).to(torch.bfloat16))
+    calls = []
+    real = ops.conv_unit_multi
+    ops.conv_unit_multi = lambda *a, **k: calls.append(real(*a, **k)) or calls[-1]
+    try:
+        with torch.no_grad():
+            y1 = m(x).float()
+    finally:
+        ops.conv_unit_multi = real
+    assert len(calls) == 1 and (calls[0] is not None) == (B == 1)
+    y0 = m(x).detach().float()                      # gradients enabled: the concat path
+    assert torch.isfinite(y1).all()
+    assert rel(y1, y0) < 4e-3, rel(y1, y0)

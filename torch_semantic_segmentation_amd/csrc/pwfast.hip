@@ -42,6 +42,11 @@ struct FastArgs {
   int gslots;
   tss_wg::ReduceArgs red;               // bwd: pending weight-gradient slot reduction of the same layer (nred == 0: none)
   int nred8;                            // its block count rounded up to 8 (keeps blockIdx % 8 == XCD for the main blocks)
+  // forward, multi-chunk kernel only: the contraction is the channel CONCATENATION of nsrc tensors of 128 channels each (chunk kc
+  // reads source kc; a pitch of 0 broadcasts one row to every pixel), each with its own pending BatchNorm -- the concat never exists
+  int nsrc;
+  const T* asrc[6]; long ldsrc[6];
+  const float* c0s[6]; const float* c1s[6]; const float* c2s[6];
 };
 
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -504,9 +509,12 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const float relu_lo = g.a_relu ? 0.f : -TSS_INF;
 
   for (int ch = tid; ch < K; ch += NT) {   // folded constants of every contraction channel, once per block
-    const float v0 = (g.c0 ? g.c0 : g.w)[g.c0 ? ch : 0], v1 = (g.c1 ? g.c1 : g.w)[g.c1 ? ch : 0];
-    const float v2 = (g.c2 ? g.c2 : g.w)[g.c2 ? ch : 0], v3 = (g.c3 ? g.c3 : g.w)[g.c3 ? ch : 0];
-    const float c0v = g.c0 ? v0 : 1.f, c1v = g.c1 ? v1 : 0.f, c2v = g.c2 ? v2 : 0.f, c3v = g.c3 ? v3 : 0.f;
+    const float* q0 = g.c0; const float* q1 = g.c1; const float* q2 = g.c2;
+    int cc = ch;
+    if (!BWD && g.nsrc > 0) { const int sI = ch >> 7; cc = ch & 127; q0 = g.c0s[sI]; q1 = g.c1s[sI]; q2 = g.c2s[sI]; }
+    const float v0 = (q0 ? q0 : g.w)[q0 ? cc : 0], v1 = (q1 ? q1 : g.w)[q1 ? cc : 0];
+    const float v2 = (q2 ? q2 : g.w)[q2 ? cc : 0], v3 = (g.c3 ? g.c3 : g.w)[g.c3 ? ch : 0];
+    const float c0v = q0 ? v0 : 1.f, c1v = q1 ? v1 : 0.f, c2v = q2 ? v2 : 0.f, c3v = g.c3 ? v3 : 0.f;
     if (BWD) {       // g = c0*(e - c2) + c1*(y - c3)
       Ck[ch] = c0v; Ck[KTOT + ch] = c1v; Ck[2 * KTOT + ch] = -(c0v * c2v) - c1v * c3v;
     } else {         // a = (x - c1)*c0 + c2
@@ -543,9 +551,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       // A-tile loads first (the HBM round trip), then the weight chunk from L2, then normalise + store
       uint4 ra[NP], rb[NP];
       if (lane_on) {
-        const T* pa = g.a0 + p0 * g.lda0 + kb + (cv_real ? cv * 8 : 0);
+        const bool multi = !BWD && g.nsrc > 0;
+        const int lda = multi ? (int)g.ldsrc[kc] : (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
+        const T* pa = (multi ? g.asrc[kc] + p0 * lda : g.a0 + p0 * g.lda0 + kb) + (cv_real ? cv * 8 : 0);
         const T* pb = BWD ? g.a1 + p0 * g.lda1 + kb + (cv_real ? cv * 8 : 0) : nullptr;
-        const int lda = (int)g.lda0, ldb = BWD ? (int)g.lda1 : 0;
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
           if (ps < npass) {
@@ -780,6 +789,30 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
     if (t128 < thr) launch_fast<false, 64>(g, stream); else launch_fast<false, 128>(g, stream);
   } else launch_fast_mc<false>(g, stream);
   return true;
+}
+
+// forward over the channel concatenation of nsrc 128-channel tensors (see FastArgs::nsrc): the 1x1 `project` layer of an ASPP head
+// reading its five branches in place (models/aspp.py), eval mode.  lds[i] == 0: source i is ONE row (a [1, 128, 1, 1] map)
+// broadcast to every pixel -- the image-pooling branch without its upsampled copy.
+extern "C" int tss_pwconv_fwd_multi(const void* const* srcs, const long* lds, const float* const* means, const float* const* scales,
+                                    const float* const* biases, int nsrc, int in_relu, const float* w, const void* w_bf16,
+                                    const float* bias, void* y, long ldy, long P, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(nsrc >= 2 && nsrc <= 6 && P > 0 && N > 0 && (N % 4) == 0 && (ldy % 4) == 0 && ldy >= N && w && srcs && lds && y,
+              TSS_ERR_SHAPE);
+  FastArgs g = {};
+  g.P = P; g.K = nsrc * KMAX; g.N = N; g.nsrc = nsrc; g.a_relu = in_relu;
+  for (int i = 0; i < nsrc; ++i) {
+    TSS_REQUIRE(srcs[i] && tss::aligned16(srcs[i]) && (lds[i] == 0 || (lds[i] >= KMAX && (lds[i] % 8) == 0)) && lds[i] < (1L << 30), TSS_ERR_SHAPE);
+    g.asrc[i] = (const T*)srcs[i]; g.ldsrc[i] = lds[i];
+    g.c0s[i] = scales ? scales[i] : nullptr; g.c1s[i] = means ? means[i] : nullptr; g.c2s[i] = biases ? biases[i] : nullptr;
+  }
+  g.a0 = g.asrc[0]; g.lda0 = g.ldsrc[0];
+  g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy;
+  if (w_bf16 && tss::aligned16(w_bf16)) { g.wb = (const T*)w_bf16; g.ldwb = g.K; }
+  tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (g.K + N) * 2.0, 2.0 * (double)P * g.K * N);
+  launch_fast_mc<false>(g, (hipStream_t)stream);
+  return tss::check_last("pwconv_fwd_multi");
 }
 
 // backward-data: e_in = relu'(act(x)) * (g W), g = ga*(e-gce) + gb*(yraw-gmu); contraction over N (must be <= 128)

@@ -525,21 +525,32 @@ def create_segmentation_trainer(model, optimizer, loss_fn, device, use_f16=False
 # ----------------------------------------------------------------------------- evaluator
 
 class EvalPrep:
-    """Model-wide preparation of an eval-mode forward as two launches: bf16 shadows of the 1x1 weights
-    (ops.WeightShadows) and the affines of every BatchNorm that runs on its running statistics (ops.EvalAffines).
-    `with prep:` refreshes both from the live parameters / buffers and makes them visible to the layers inside."""
+    """Model-wide preparation of an eval-mode forward: bf16 shadows of the 1x1 weights (ops.WeightShadows, one launch), the affines
+    of every BatchNorm that runs on its running statistics (ops.EvalAffines, one launch) and the bf16 tap-major copies of the dense
+    3x3 weights (ops.Dense3x3Shadows, one small launch per layer).  `with prep:` refreshes them from the live parameters / buffers
+    and makes them visible to the layers inside; with `frozen=True` they are refreshed by refresh() only (weights that do not change
+    between forwards: the preparation leaves the forward, as `model.half()` leaves the timed loop of TSS/utils/benchmark.py)."""
 
-    def __init__(self, model):
-        self.shadows, self.affines = ops.WeightShadows(model), ops.EvalAffines(model)
+    def __init__(self, model, frozen=False):
+        self.shadows, self.affines, self.w3 = ops.WeightShadows(model), ops.EvalAffines(model), ops.Dense3x3Shadows(model)
+        self.frozen, self.fresh = frozen, False
 
-    def __enter__(self):
+    def refresh(self):
         self.shadows.refresh()
         self.affines.refresh()
+        self.w3.refresh()
+        self.fresh = True
+
+    def __enter__(self):
+        if not (self.frozen and self.fresh):
+            self.refresh()
         self.shadows.__enter__()
         self.affines.__enter__()
+        self.w3.__enter__()
         return self
 
     def __exit__(self, *exc):
+        self.w3.__exit__(*exc)
         self.affines.__exit__(*exc)
         self.shadows.__exit__(*exc)
         return False
@@ -635,16 +646,24 @@ class GraphedInference:
     """eval-mode, no-grad forward of `model` captured once in a HIP graph and replayed: the input is copied into a fixed
     device buffer, the returned logits live in a fixed output buffer (overwritten by the next call).  Shapes are fixed
     at the first call.  `lowres=True` returns the 1/8-resolution logits of `model.forward_lowres` (what the fused
-    evaluation head consumes) instead of the x8-upsampled ones."""
+    evaluation head consumes) instead of the x8-upsampled ones.
+    `frozen_weights=False` (default): the model-wide weight / statistics preparation (EvalPrep) is captured with the layers, so every
+    replay follows the live parameters and buffers.  `frozen_weights=True`: it runs once, before the capture, and again only when
+    refresh_weights() is called -- for deployed models whose weights do not change between forwards."""
 
-    def __init__(self, model, lowres=False):
-        self.model, self.lowres = model, lowres
+    def __init__(self, model, lowres=False, frozen_weights=False):
+        self.model, self.lowres, self.frozen = model, lowres, bool(frozen_weights)
         self._graph = self._x = self._out = self._prep = None
+
+    def refresh_weights(self):
+        """Re-run the weight / statistics preparation after the parameters or buffers changed (frozen_weights=True only)."""
+        if self._prep is not None:
+            self._prep.refresh()
 
     def _forward(self, x):
         if self._prep is None:
-            self._prep = EvalPrep(self.model)
-        with self._prep:      # two model-wide launches (captured with the rest): weights and statistics are read live
+            self._prep = EvalPrep(self.model, frozen=self.frozen)
+        with self._prep:      # model-wide preparation launches: captured with the rest (live weights) unless frozen_weights
             return self.model.forward_lowres(x) if self.lowres else self.model(x)
 
     def static_input(self, x):

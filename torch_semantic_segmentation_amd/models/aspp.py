@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from ._fused import Deferred, FusedSequential, HipModel, run
+from ._fused import Deferred, FusedSequential, HipModel, has_hooks, run
 from .fastscnn import FastSCNN
 
 __all__ = ['ASPP', 'ASPPHead', 'FastSCNNASPP', 'fastscnn_aspp']
@@ -41,7 +41,14 @@ class ASPP(nn.Module):
     def forward(self, input):
         x = ops.to_nhwc(ops.materialize(input))
         branches = [run(m, x) for m in list(self.convs)[:-1]]
-        pooled = ops.materialize(run(self.convs[-1], x))                       # (B, out, 1, 1), normalised
+        pooled = run(self.convs[-1], x)                                        # (B, out, 1, 1), BatchNorm + ReLU pending
+        if not self.training and not torch.is_grad_enabled() and not has_hooks(self.project) and not has_hooks(self.convs):
+            # eval forward: the project layer reads the five branches in place, their BatchNorm + ReLU applied on load, the pooled
+            # row broadcast (one image) -- no concat buffer, no upsampled copy of a 1 x 1 map (ops.conv_unit_multi)
+            d = ops.conv_unit_multi(branches + [pooled], self.project[0], self.project[1], relu=True)
+            if d is not None:
+                return ops.materialize(d)              # (eval mode: the project's nn.Dropout is the identity)
+        pooled = ops.materialize(pooled)
         branches.append(Deferred(ops.bilinear(pooled, size=tuple(x.shape[2:]))))   # align_corners is immaterial for a 1x1 source
         return self.project(ops.concat_joined(branches, relu=False))
 

@@ -353,6 +353,41 @@ class WeightShadows:
         return False
 
 
+# bf16 tap-major copies of dense 3x3 weights prepared ahead of a forward (Dense3x3Shadows below): {weight.data_ptr(): [9][N][K] bf16}
+_W3X3 = {}
+
+
+class Dense3x3Shadows:
+    """The bf16 [tap][output][input] copies of every dense 3x3 weight of a model that the matrix-core 3x3 kernels read (wstat.hip,
+    atrous.hip, conv3x3.hip), written ahead of the forward instead of by one tss_permute_w3x3_bf16 launch per layer inside it.  Same
+    contract as WeightShadows: refresh() rewrites them from the live weights; only visible inside `with shadows:`."""
+
+    def __init__(self, module):
+        self.items = []
+        for m in module.modules():
+            if (isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.groups == 1 and m.weight.is_cuda
+                    and m.weight.dtype == torch.float32 and m.in_channels % 8 == 0 and m.out_channels % 8 == 0):
+                w = m.weight
+                self.items.append((w, w.data_ptr(), torch.empty((9, m.out_channels, m.in_channels), dtype=torch.bfloat16, device=w.device)))
+        self.entries = {p: t for _, p, t in self.items}
+
+    def refresh(self):
+        for w, p, t in self.items:
+            if w.data_ptr() != p:
+                raise RuntimeError('Dense3x3Shadows: a parameter was reallocated; rebuild the shadows')
+            call('tss_permute_w3x3_bf16', ptr(w), ptr(t), None, w.shape[0], w.shape[1], stream())
+
+    def __enter__(self):
+        self.prev = dict(_W3X3)
+        _W3X3.update(self.entries)
+        return self
+
+    def __exit__(self, *exc):
+        _W3X3.clear()
+        _W3X3.update(self.prev)
+        return False
+
+
 # eval-mode BatchNorm affines computed for a whole model by one launch (EvalAffines below): {id(bn): [3][C] f32 view},
 # only populated inside a `with affines:` block, for the forward that follows its refresh().
 _EVAL_AFFINES = {}
@@ -710,6 +745,51 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_K
     return Deferred(y, cfg.out_link, relu)
 
 
+def conv_unit_multi(branches, conv, bn=None, relu=False):
+    """conv(torch.cat(branches, dim=1)) -> [BatchNorm] -> [ReLU] for a 1x1 `conv`, with NO concatenated tensor: the kernel walks the
+    contraction source by source and applies every branch's pending BatchNorm (+ the branches' common ReLU) on load
+    (tss_pwconv_fwd_multi).  A branch of shape [1, C, 1, 1] is broadcast over the map (an image-pooling branch needs no upsampled
+    copy).  Eval-mode / no-grad forward only; returns None when the call is outside that envelope (the caller concatenates)."""
+    if torch.is_grad_enabled() or N.fast_paths_disabled() or not (2 <= len(branches) <= 6):
+        return None
+    if conv.kernel_size != (1, 1) or conv.groups != 1 or conv.stride != (1, 1) or conv.padding != (0, 0) or conv.in_channels != 128 * len(branches):
+        return None
+    if bn is not None and (not isinstance(bn, _BatchNorm) or bn.training or bn.running_mean is None):
+        return None
+    ds = [as_deferred(b) for b in branches]
+    full = next((d.raw for d in ds if d.raw.shape[2] * d.raw.shape[3] > 1), None)
+    if full is None or full.dtype != torch.bfloat16 or conv.weight.dtype != torch.float32 or conv.out_channels % 4:
+        return None
+    B, _, H, W = full.shape
+    in_relu = ds[0].relu
+    for d in ds:
+        r = d.raw
+        bcast = tuple(r.shape) == (1, 128, 1, 1) and B == 1
+        if r.dtype != torch.bfloat16 or r.shape[1] != 128 or d.relu != in_relu or not (bcast or tuple(r.shape) == (B, 128, H, W)) or not is_nhwc(r):
+            return None
+    for d in ds:
+        d.take()
+    dev, st = full.device, stream()
+    n = len(ds)
+    srcs = (ctypes.c_void_p * n)(*[d.raw.data_ptr() for d in ds])
+    lds = (ctypes.c_long * n)(*[0 if d.raw.shape[2] * d.raw.shape[3] == 1 else ld(d.raw) for d in ds])
+
+    def vec(getter):
+        return (ctypes.c_void_p * n)(*[(getter(d.link).data_ptr() if d.link is not None and getter(d.link) is not None else None) for d in ds])
+    means, scales, biases = vec(lambda l: l.mean), vec(lambda l: l.scale), vec(lambda l: l.beta)
+    Cout, P = conv.out_channels, B * H * W
+    y = new_nhwc(B, Cout, H, W, torch.bfloat16, dev)
+    weight = conv.weight
+    call('tss_pwconv_fwd_multi', srcs, lds, means, scales, biases, n, int(in_relu), ptr(weight), _shadow(weight, 0), ptr(_f32(conv.bias)),
+         ptr(y), ld(y), P, Cout, N.dtype_code(torch.bfloat16), st)
+    link = None
+    if bn is not None:
+        gamma, beta = _f32(bn.weight), _f32(bn.bias)
+        link = BNLink(Cout, P, False, gamma, beta, dev, slabs=False)
+        _finalize_forward(link, bn, False, P, Cout, gamma, st)
+    return Deferred(y, link, relu)
+
+
 def _f32(p):
     if p is None or p.dtype == torch.float32:
         return p
@@ -822,9 +902,11 @@ class ConvUnitFn(Function):
         elif cfg.kind == 'dense':
             w_tnc = w_tnc16 = None
             if _conv3x3_stream(x.dtype, cfg.cin, Cout, s, cfg.in_link, cfg.in_relu) or _conv3x3_lean(x.dtype, cfg.cin, Cout, s, d):
-                # bf16 tap-major copy: the register-streamed kernel (atrous.hip) / the LDS-halo kernel (conv3x3.hip)
-                w_tnc16 = torch.empty((9, Cout, cfg.cin), dtype=torch.bfloat16, device=dev)
-                call('tss_permute_w3x3_bf16', ptr(weight), ptr(w_tnc16), None, Cout, cfg.cin, st)
+                # bf16 tap-major copy: the weight-stationary / register-streamed kernels (wstat.hip, atrous.hip), the LDS-halo kernel (conv3x3.hip)
+                w_tnc16 = _W3X3.get(weight.data_ptr()) if _W3X3 else None          # prepared ahead of the forward (Dense3x3Shadows)
+                if w_tnc16 is None:
+                    w_tnc16 = torch.empty((9, Cout, cfg.cin), dtype=torch.bfloat16, device=dev)
+                    call('tss_permute_w3x3_bf16', ptr(weight), ptr(w_tnc16), None, Cout, cfg.cin, st)
             else:
                 w_tnc = torch.empty((9, Cout, cfg.cin), dtype=torch.float32, device=dev)
                 call('tss_permute_w3x3', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, st)
