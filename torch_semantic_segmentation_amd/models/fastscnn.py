@@ -62,9 +62,11 @@ class BottleneckBlock(nn.Module):
         c1, c2, c3 = self.conv1[0], self.conv2[0], self.conv3[0]
         residual = tuple(c2.stride) == (1, 1) and c1.in_channels == c3.out_channels and not has_hooks(self.conv1)
         xa, xb, fork = ops.residual_fork(x) if residual else (x, x, None)
-        d = run(self.conv2, run(self.conv1, xa))
-        if fork is not None:
-            ops._pending_forks.pop(id(xa), None)
+        try:
+            d = run(self.conv2, run(self.conv1, xa))
+        finally:                                   # (also when a layer raises: ids are recycled, a stale entry would be picked up later)
+            if fork is not None:
+                ops._pending_forks.pop(id(xa), None)
         d = run(self.conv3, d)
         same = tuple(d.shape) == tuple(x.shape)
         return ops.join(d, xb if same else None, relu=True, fork=fork if same else None)
@@ -98,17 +100,19 @@ class PyramidPoolingModule(nn.Module):
         if plain:
             # x feeds the pools and the concat: the concat's gradient of x is added inside the pools' backward kernel (ops.fork_two)
             xp, xc, fork = ops.fork_two(x)
-            pooled = ops.adaptive_avg_pool_multi(xp, [a[0].output_size for a in arms])
-            x = xc
-            # the arms' 1x1 convolutions + BatchNorm statistics: one launch for all arms (csrc/ppm.hip), else unit by unit
-            ds = ops.ppm_arms([a[1] for a in arms], pooled)
-            if ds is None:
-                ds = [run(a[1], Deferred(p)) for a, p in zip(arms, pooled)]
-            if ops.ppm_arms_fusable(x, ds):
-                cat = ops.concat_upsampled_arms(x, ds)
-            else:
-                cat = ops.concat_upsampled(x, ds)
-            ops.drop_fork(xp, xc)
+            try:
+                pooled = ops.adaptive_avg_pool_multi(xp, [a[0].output_size for a in arms])
+                x = xc
+                # the arms' 1x1 convolutions + BatchNorm statistics: one launch for all arms (csrc/ppm.hip), else unit by unit
+                ds = ops.ppm_arms([a[1] for a in arms], pooled)
+                if ds is None:
+                    ds = [run(a[1], Deferred(p)) for a, p in zip(arms, pooled)]
+                if ops.ppm_arms_fusable(x, ds):
+                    cat = ops.concat_upsampled_arms(x, ds)
+                else:
+                    cat = ops.concat_upsampled(x, ds)
+            finally:
+                ops.drop_fork(xp, xc)
             return self.conv(cat)
         pools = [pool(x) for pool in arms]
         return self.conv(ops.concat_upsampled(x, pools))
@@ -168,13 +172,15 @@ class FastSCNN(HipModel):
         # latter is added in the epilogue of the former's first backward-data kernel, not by an elementwise launch (ops.fork_two)
         hooked = has_hooks(self.features) or has_hooks(self.fusion)
         da, db, fork = (downsample, downsample, None) if hooked else ops.fork_two(downsample)
-        features = self.features(da)
-        # (the fusion module's high-resolution 1x1 layer only needs `downsample` and could run on a side stream under the feature
-        # extractor, as ContextNet's context branch does: measured, 5.58 vs 5.45 ms per step -- it competes with, rather than hides
-        # under, the 1/16-resolution kernels; not done)
-        fusion = self.fusion(features, db)
-        if fork is not None:
-            ops.drop_fork(da, db)
+        try:
+            features = self.features(da)
+            # (the fusion module's high-resolution 1x1 layer only needs `downsample` and could run on a side stream under the feature
+            # extractor, as ContextNet's context branch does: measured, 5.58 vs 5.45 ms per step -- it competes with, rather than hides
+            # under, the 1/16-resolution kernels; not done)
+            fusion = self.fusion(features, db)
+        finally:
+            if fork is not None:
+                ops.drop_fork(da, db)
         return self.classifier(fusion)
 
     def forward(self, input):

@@ -180,10 +180,18 @@ def _reduce_rows_now(ws, dw, ncols, nrows):
     call('tss_dw_reduce_many', 1, a, b, (ctypes.c_int * 1)(ncols), (ctypes.c_int * 1)(nrows), stream())
 
 
-def _defer_dw_reduction(ws, dw, ncols, nrows):
-    """Queue the row reduction of a one-sweep backward for the single launch at the end of the pass (now, if nothing can be deferred)."""
+def _param_observed(p):
+    """A parameter whose gradient somebody may read BEFORE backward() returns (tensor hooks, post-accumulate-grad hooks, e.g. a
+    bucketed all-reduce that overlaps the backward pass): its weight gradient is completed in place, never deferred."""
+    return p is not None and bool(getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None))
+
+
+def _defer_dw_reduction(ws, dw, ncols, nrows, param=None):
+    """Queue the row reduction of a one-sweep backward for the single launch at the end of the pass (now, if nothing can be deferred).
+    Contract of the deferral (and of the postponed 1x1 weight gradients): directly accumulated gradients are complete when backward()
+    returns, not earlier -- except for parameters with hooks, which are finished at once."""
     task = _backward_task()
-    if task == -1:
+    if task == -1 or _param_observed(param):
         _reduce_rows_now(ws, dw, ncols, nrows)
         return
     if _pending_dw and _pending_dw[0][0].device != ws.device:
@@ -1013,7 +1021,7 @@ class ConvUnitFn(Function):
                 defer = 1 if (ws is not None and need_dx and side is None) else 0   # a backward-data launch carries the reduce
                 # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _pending_wg)
                 postponed = bool(defer and postpone_wgrad and dw_ret is None and not getattr(cfg, 'overlapped', False)
-                                 and _backward_task() != -1)
+                                 and _backward_task() != -1 and not _param_observed(p_weight))
                 if not postponed:
                     _flush_wg(st)
                     _flush_red(st)
@@ -1059,9 +1067,9 @@ class ConvUnitFn(Function):
                     call('tss_pwconv_bwd_fused', *gargs, ptr(weight), _shadow(weight, 1), *xargs, int(bool(deferred_in)),
                          ptr(e_in), ld(e_in), bst, ptr(ws), ptr(bws), P, Cin, Cout, dt, st)
                     if dw_ret is None and fused_dbias is None and batch_dw_reductions:
-                        _defer_dw_reduction(ws, dw, Cout * Cin, rows)       # summed with the depthwise rows, at the end of the pass
+                        _defer_dw_reduction(ws, dw, Cout * Cin, rows, p_weight)       # summed with the depthwise rows, at the end of the pass
                         if bws is not None:
-                            _defer_dw_reduction(bws, dbias, Cout, rows)
+                            _defer_dw_reduction(bws, dbias, Cout, rows, p_bias)
                     else:
                         _reduce_rows_now(ws, dw, Cout * Cin, rows)
                         if bws is not None:
@@ -1100,7 +1108,7 @@ class ConvUnitFn(Function):
                     rows = ctypes.c_int(0)
                     call('tss_dwconv3x3_bwd_fused_sweep', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(e_in), ld(e_in),
                          bst, ptr(ws), B, Hin, Win, Cout, s, d, dt, st, ctypes.byref(rows))
-                    _defer_dw_reduction(ws, dw, Cout * 9, rows.value)
+                    _defer_dw_reduction(ws, dw, Cout * 9, rows.value, p_weight)
                 elif cfg.kind == 'dw' and fused_dw:
                     call('tss_dwconv3x3_bwd_fused', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(e_in), ld(e_in),
                          bst, ptr(ws), ptr(dw), B, Hin, Win, Cout, s, d, dt, st)
