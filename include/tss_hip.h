@@ -294,6 +294,22 @@ int tss_dwconv3x3_bwd_weight(const void* e, long lde, const void* yraw, long ldy
 /* defer_reduce = 1: the workspace rows are summed into dw by the tss_dwconv3x3_bwd_data call of the SAME layer that
  * follows (its wg_ws / wg_dw arguments) instead of a kernel of its own. */
 
+/* ---- bilinear upsample (align_corners=True) + depthwise 3x3 (padding = dilation) as one operator (csrc/updw.hip) ------
+ * replaces: nn.UpsamplingBilinear2d(scale_factor) -> DWConv2dBlock(dilation=scale_factor) of FeatureFusionModule.lowres,
+ *           TSS/models/fastscnn.py:74-76; F.interpolate(size=...) -> DWConvBlock(dilation=4), TSS/models/contextnet.py:110-122.
+ * x: materialised bf16 source [B][Hs][Ws][C]; the [B][Ho][Wo][C] upsampled tensor never exists.  bf16 only.
+ * fwd: y raw conv output + its statistics slab rows.  bwd (one sweep over e, yraw): e_up = gradient with respect to the
+ * UPSAMPLED map (bf16 [B][Ho][Wo][C]; tss_bilinear_nhwc_bwd folds it back to the source), ws = [tss_updw_ws_rows(...)][C*9] f32 rows
+ * of per-block weight-gradient sums, *rows_out of them written (host int), summed by tss_dw_reduce_many.
+ * ga..gmu: coefficients of the BatchNorm backward behind the layer (tss_bn_bwd_finalize); yraw NULL: g = ga * e (ga NULL: e). */
+int tss_updw_supported(int B, int Hs, int Ws, int Ho, int Wo, int C, int dil, int dtype);
+int tss_updw_ws_rows(int B, int Hs, int Ws, int Ho, int Wo, int C, int dil, int dtype);   /* rows of `ws` tss_updw_bwd writes */
+int tss_updw_fwd(const void* x, long ldx, int Hs, int Ws, const float* w, void* y, long ldy, double* stats,
+                 int B, int Ho, int Wo, int C, int dil, int dtype, void* stream);
+int tss_updw_bwd(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                 const float* gmu, const float* w, const void* x, long ldx, int Hs, int Ws, void* e_up, long ldeu, float* ws,
+                 int B, int Ho, int Wo, int C, int dil, int dtype, void* stream, int* rows_out);
+
 /* Per-channel statistics buffers (`stats`, `bstats`, `stats_a/b` everywhere in this header) are
  * [tss_stat_slabs()][2*C] f64: every producing kernel writes one partial row per block and zeroes the rest, so
  * the caller allocates them uninitialised; tss_bn_finalize / tss_bn_bwd_finalize sum the rows. */
@@ -351,6 +367,27 @@ int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot,
 int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float p,
                 const unsigned long long* seed_slot, int dtype, void* stream);
 int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtype, void* stream);
+/* nn.Dropout in front of a 1x1 convolution (Classifier: ... -> BN -> ReLU -> Dropout(0.1) -> Conv2d(128, classes, 1),
+ * TSS/models/fastscnn.py:96-97, TSS/models/contextnet.py:85-86) applied ON LOAD by that convolution instead of by a pass of its
+ * own over the 128-channel activation (forward and backward).
+ * tss_dropout_mask: mask = [P][C/8] bytes (buffer rounded up to whole 32-bit words), bit j of byte (p, v) = channel 8 v + j of pixel p
+ *   is kept; Philox4x32-10 keyed by *counter (device), 16 bits per element.  It does NOT advance the counter: the consumer does.
+ * tss_pwconv_fwd_drop: y = (keep / (1 - p) * act(x)) W^T + bias, act = the pending BatchNorm(+ReLU) of x; advances *counter.
+ * tss_pwconv_bwd_fused_drop: tss_pwconv_bwd_fused with the same mask on the weight gradient's activation operand and on e_in;
+ *   ws rows: tss_pwconv_bwd_fused_drop_rows(P).  bf16; K = Cin <= 128 (multiple of 8), N = Cout <= 64 (>= 8, may be ragged). */
+int tss_dropout_mask(const unsigned long long* counter, void* mask, long P, int C, float p, void* stream);
+int tss_pwconv_drop_supported(long P, int K, int N, int dtype);
+int tss_pwconv_fwd_drop(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                        const float* w, const void* w_bf16, const float* bias, void* y, long ldy,
+                        const void* mask, float drop_p, unsigned long long* counter,
+                        long P, int K, int N, int dtype, void* stream);
+int tss_pwconv_bwd_fused_drop_supported(long P, int Cin, int Cout, int dtype);
+int tss_pwconv_bwd_fused_drop_rows(long P);
+int tss_pwconv_bwd_fused_drop(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                              const float* gmu, const float* w, const void* x, long ldx, const float* in_mean,
+                              const float* in_scale, const float* in_bias, int in_relu, int x_pending, const void* mask, float drop_p,
+                              void* e_in, long ldei, double* bstats, float* ws, float* bias_ws, long P, int Cin, int Cout, int dtype,
+                              void* stream);
 /* bf16 shadows of 1x1 weights, all layers in one launch.  table: njobs x 5 int64 on the device:
  * (f32 source [N][K], bf16 copy [N][K], bf16 transpose [K][N], N, K); blocks_per_job x njobs blocks of 256 threads.
  * zero / zero_n (optional): a float buffer cleared by the same launch -- the step's flat gradient buffer (optimizer.zero_grad()

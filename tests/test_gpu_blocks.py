@@ -2,6 +2,7 @@
 statistics), HIP path (through the C ABI) vs golden vectors generated from the reference itself.
 f32 activations; tolerance = the north-star's 1e-3 relative (whole-tensor max norm), with an absolute floor
 for gradients that are analytically zero (e.g. the bias of a BatchNorm that feeds another BatchNorm)."""
+import math
 import os
 
 import numpy as np
@@ -268,13 +269,13 @@ def test_dropout_folded_into_the_join_is_bit_identical_to_its_own_pass(dtype):
         tssa.set_compute_dtype(m, dtype)
         m.train()
         x = torch.randn(2, 32, 8, 24, device=DEV).requires_grad_(True)
-        old = ops.fuse_dropout
-        ops.fuse_dropout = fused
+        old, old_conv = ops.fuse_dropout, ops.fuse_dropout_conv
+        ops.fuse_dropout, ops.fuse_dropout_conv = fused, False      # (the convolution-side fold has its own test below)
         try:
             out = m(x.to(dtype) if dtype != torch.float32 else x)
             out.float().backward(torch.ones_like(out, dtype=torch.float32))
         finally:
-            ops.fuse_dropout = old
+            ops.fuse_dropout, ops.fuse_dropout_conv = old, old_conv
         return out.detach().float(), x.grad.float(), [p.grad.float().clone() for p in m.parameters()]
     o1, dx1, g1 = run(True)
     o0, dx0, g0 = run(False)
@@ -283,6 +284,77 @@ def test_dropout_folded_into_the_join_is_bit_identical_to_its_own_pass(dtype):
         assert cases.rel_err(a.cpu(), b.cpu()) < 1e-5      # weight-gradient sums may differ in order only
     # the mask is real: about 30 % of the (positive) activations feeding the last conv were dropped
     assert (o1 != 0).any()
+
+
+@pytest.mark.parametrize('cin,classes,shape', [(128, 19, (2, 24, 40)), (32, 19, (2, 8, 24)), (64, 21, (3, 17, 9)), (128, 8, (1, 70, 33))])
+@pytest.mark.parametrize('pending', [True, False])
+def test_dropout_applied_on_load_by_the_classifier_conv(cin, classes, shape, pending):
+    """Classifier tail (... -> BN -> ReLU -> Dropout -> Conv2d(., classes, 1), TSS/models/fastscnn.py:96-97) with the dropout applied
+    on load by the convolution (tss_dropout_mask + tss_pwconv_fwd_drop + tss_pwconv_bwd_fused_drop): no pass over the activation.
+    Checked against the same layers with the SAME mask (drawn again through the C ABI from the same counter) applied by torch
+    to the materialised activation: output, input gradient, every parameter gradient; the mask keeps 1 - p of the elements, changes
+    from step to step and repeats from the same seed."""
+    import importlib
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import _native as N, ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    B, H, W = shape
+    p_drop = 0.3
+
+    def build():
+        torch.manual_seed(41)
+        head = [F_.Conv2dBlock(cin, cin, 1)] if pending else []
+        m = F_.FusedSequential(*head, nn.Dropout(p_drop), nn.Conv2d(cin, classes, 1)).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        return m.train()
+
+    def inputs():
+        torch.manual_seed(43)
+        x = torch.randn(B, cin, H, W, device=DEV)
+        if not pending:
+            x = x.relu()
+        return ops.to_nhwc(x.to(torch.bfloat16)).requires_grad_(True), torch.randn(B, classes, H, W, device=DEV)
+
+    def grads(m, x):
+        return [x.grad.float().clone()] + [q.grad.float().clone() for q in m.parameters()]
+
+    # (1) the fold
+    ops._dropout_counters.clear()
+    m = build()
+    x, cot = inputs()
+    seed = int(ops._dropout_counter(x.device).item())
+    out = m(x)
+    assert int(ops._dropout_counter(x.device).item()) == seed + 1          # the consumer advanced the counter
+    out.float().backward(cot)
+    o1, g1 = out.detach().float(), grads(m, x)
+    out2 = m(inputs()[0]).detach().float()
+    assert not torch.equal(out2, o1)                                         # next step, next mask
+    ops._dropout_counters.clear()
+    m_again = build()
+    assert torch.equal(m_again(inputs()[0]).detach().float(), o1)            # same seed, same bits
+
+    # (2) the same mask, applied by torch to the materialised activation
+    P = B * H * W
+    counter = torch.tensor([seed], dtype=torch.int64, device=DEV)
+    mask = torch.empty((P * (cin // 8) + 3) // 4 * 4, dtype=torch.uint8, device=DEV)
+    N.call('tss_dropout_mask', N.ptr(counter), N.ptr(mask), P, cin, p_drop, N.stream())
+    torch.cuda.synchronize()
+    bits = (mask[:P * (cin // 8)].view(P, cin // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8).view(1, 1, 8)) & 1
+    keep = bits.view(B, H, W, cin).permute(0, 3, 1, 2).float()
+    frac = keep.mean().item()
+    assert abs(frac - (1 - p_drop)) < 4 * math.sqrt(p_drop * (1 - p_drop) / keep.numel()) + 1e-4
+    m0 = build()
+    x0, _ = inputs()
+    a = ops.materialize(F_.run(m0[0], x0)) if pending else x0
+    a_drop = ((a.float() * keep) * (1.0 / (1.0 - p_drop))).to(torch.bfloat16)
+    out0 = ops.materialize(ops.conv_unit(ops.to_nhwc(a_drop), m0[-1]))
+    out0.float().backward(cot)
+    o0, g0 = out0.detach().float(), grads(m0, x0)
+    assert cases.rel_err(o1.cpu(), o0.cpu()) < 1e-2
+    for a1, a0 in zip(g1, g0):
+        if a0.norm() > 1e-3:
+            assert cases.rel_err(a1.cpu(), a0.cpu()) < 2e-2
 
 
 @pytest.mark.parametrize('name', ['fast_bneck_res', 'fast_bneck_s2', 'fast_ds_s2', 'fast_dw_d4', 'fast_dw_s1'])

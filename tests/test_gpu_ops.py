@@ -881,3 +881,74 @@ def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
     for k in g0:
         if g0[k].norm() > 1e-3:
             assert rel(g1[k], g0[k]) < 1e-2 and maxrel(g1[k], g0[k]) < 5e-2, k
+
+
+@pytest.mark.parametrize('B,c,hs,ws,size,dil', [(2, 128, 8, 16, (32, 64), 4), (3, 72, 5, 7, (20, 28), 4), (2, 128, 6, 10, (23, 37), 4),
+                                                (1, 64, 9, 9, (18, 18), 2), (2, 8, 4, 6, (16, 24), 4), (8, 128, 4, 8, (16, 32), 4)])
+@pytest.mark.parametrize('train', [True, False])
+def test_upsample_depthwise_in_one_operator_matches_the_two_operators(B, c, hs, ws, size, dil, train):
+    """csrc/updw.hip (bilinear upsample + dilated depthwise 3x3 without the upsampled tensor; FeatureFusionModule.lowres,
+    TSS/models/fastscnn.py:74-76) against upsample and depthwise unit run one after the other (TSS_UPDW=0) on the same bf16
+    operands: ragged strips / channel slices, non-integer scale (ContextNet interpolates to a size), batch and frozen statistics;
+    and its raw convolution output against F.interpolate + F.conv2d in f32."""
+    import importlib
+    import os
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    calls = []
+
+    def run(fused):
+        torch.manual_seed(29)
+        m = F_.FusedSequential(F_.DWConv2dBlock(c, c, kernel_size=3, padding=dil, dilation=dil),
+                               F_.Conv2dBlock(c, c, 1, use_activation=False)).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train(train)
+        if not train:
+            for mod in m.modules():
+                if isinstance(mod, nn.BatchNorm2d):
+                    mod.running_mean.normal_(0, 0.2)
+                    mod.running_var.uniform_(0.5, 1.5)
+        x = ops.to_nhwc(torch.randn(B, c, hs, ws, device=DEV).to(torch.bfloat16)).requires_grad_(True)
+        old = os.environ.get('TSS_UPDW')
+        os.environ['TSS_UPDW'] = '1' if fused else '0'
+        try:
+            d = ops.upsample_dw_unit(x, size, m[0])
+            calls.append(d is not None)
+            if d is None:
+                d = F_.run(m[0], ops.bilinear(x, size=size))
+            out = ops.materialize(F_.run(m[1], d))
+            torch.manual_seed(31)
+            out.float().backward(torch.randn_like(out, dtype=torch.float32))
+            torch.cuda.synchronize()
+        finally:
+            if old is None:
+                del os.environ['TSS_UPDW']
+            else:
+                os.environ['TSS_UPDW'] = old
+        stats = [b.clone() for b in m.buffers()]
+        return out.float(), x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}, stats
+    o1, dx1, g1, s1 = run(True)
+    o0, dx0, g0, s0 = run(False)
+    assert calls == [True, False]
+    assert rel(o1, o0) < 1e-2        # (max |difference| / max |value|: one bf16 ulp of a large element)
+    # the two paths round the gradient of the upsampled map to bf16 after sums taken in different orders; a source pixel of a small
+    # map gathers ~(2 scale)^2 of those roundings: bounded in the L2 norm, and loosely element by element
+    def l2(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(dx1, dx0) < 5e-3 and maxrel(dx1, dx0) < 5e-2
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert l2(g1[k], g0[k]) < 5e-3 and maxrel(g1[k], g0[k]) < 5e-2, k
+    for a, b in zip(s1, s0):
+        assert rel(a, b) < 1e-4
+    # raw convolution output against torch in f32 (bf16 operands, one rounding of the interpolated pixel, one of the output)
+    torch.manual_seed(37)
+    conv = nn.Conv2d(c, c, 3, padding=dil, dilation=dil, groups=c, bias=False).to(DEV)
+    x = torch.randn(B, c, hs, ws, device=DEV).to(torch.bfloat16)
+    d = ops.upsample_dw_unit(ops.to_nhwc(x), size, F_.FusedSequential(conv))
+    assert d is not None and d.link is None
+    up = F.interpolate(x.float(), size=size, mode='bilinear', align_corners=True).to(torch.bfloat16).float()
+    ref = F.conv2d(up, conv.weight, padding=dil, dilation=dil, groups=c)
+    assert rel(d.raw, ref) < 4e-3

@@ -387,6 +387,30 @@ __global__ __launch_bounds__(NT) void dropout_kernel(const T* x, long ldx, T* y,
   }
 }
 
+// The mask alone, for consumers that apply nn.Dropout on load (tss_pwconv_fwd_drop / tss_pwconv_bwd_fused_drop): one BYTE per
+// (pixel, 8-channel vector), bit j = channel 8 v + j is kept.  One Philox call per byte, 16 random bits per element (kept <=>
+// bits >= round(p * 65536): the probability is exact to 2^-16), keyed by the device-side counter -- which this kernel only READS
+// (every block does; the consumer advances it, behind the kernel boundary, so no block can see the next step's value).
+__global__ __launch_bounds__(NT) void dropout_mask_kernel(const unsigned long long* counter, uint32_t* mask4, long nwords, float p) {
+  const unsigned long long seed = *counter;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ 0x5EEDu;
+  const uint32_t thresh = (uint32_t)((double)p * 65536.0 + 0.5);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (long)gridDim.x * blockDim.x) {
+    uint32_t word = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t ctr = (uint64_t)i * 4 + u;
+      uint32_t r[4];
+      philox4x32((uint32_t)ctr, (uint32_t)(ctr >> 32), k0, k1, r);
+      uint32_t byte = 0u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) byte |= (((r[j >> 1] >> (16 * (j & 1))) & 0xffffu) >= thresh ? 1u : 0u) << j;
+      word |= byte << (8 * u);
+    }
+    mask4[i] = word;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ misc
 template <typename T>
 __global__ __launch_bounds__(NT) void colsum_kernel(const T* e, long lde, long P, int N, float* out) {
@@ -638,6 +662,16 @@ int tss_stat_slabs(void) { return TSS_STAT_SLABS; }
 int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot, void* stream) {
   hipLaunchKernelGGL(dropout_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, seed_slot);
   return tss::check_last("dropout_tick");
+}
+
+int tss_dropout_mask(const unsigned long long* counter, void* mask, long P, int C, float p, void* stream) {
+  TSS_REQUIRE(counter && mask && C > 0 && (C % 8) == 0 && p > 0.f && p < 1.f && ((uintptr_t)mask & 3u) == 0, TSS_ERR_SHAPE);
+  if (P == 0) return TSS_OK;
+  const long nwords = (P * (C / 8) + 3) / 4;        // the buffer holds whole 32-bit words (tss_dropout_mask_bytes)
+  long grid = (nwords + NT - 1) / NT;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, counter, (uint32_t*)mask, nwords, p);
+  return tss::check_last("dropout_mask");
 }
 
 int tss_dropout(const void* x, long ldx, void* y, long ldy, long P, int C, float p,

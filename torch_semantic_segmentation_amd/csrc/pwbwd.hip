@@ -27,6 +27,9 @@ struct PbArgs {
   const T* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu, x_pending;
   T* ein; long ldei; double* stats; float* ws; int gslots;
   float* bias_ws;                           // optional [rows][NC]: per-block partial sums of g over the pixels (bias gradient)
+  // DROP instances: nn.Dropout sat between the (pending) activation of x and this layer (tss_pwconv_fwd_drop): one mask byte per
+  // (pixel, 8-channel vector of x), bit j = kept; the weight gradient sees a * keep / (1 - p), the input gradient is scaled alike
+  const unsigned char* dmask; float dinv;
 };
 
 __device__ __forceinline__ float blo(uint32_t u) { return __uint_as_float(u << 16); }
@@ -42,7 +45,7 @@ __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0x
 // TR: no pixel-major image of g at all -- the input-gradient product reads its g operand out of the channel-major image Gt with
 // the transposing LDS read of gfx950 (ds_read_b64_tr_b16: a group of 16 lanes reads a 4-row x 16-column block and lane i receives
 // column i), which frees the 17 KB that keep the 128-channel shape from fitting twice into a CU's LDS
-template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR>
+template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR, bool DROP = false>
 __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const PbArgs g) {
   constexpr int NW = NT / 64;
   constexpr int NCM = 16 * NW * NFW, KCM = 16 * FKM;     // channel capacities
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   const T* xg = g.x + (onA ? cvA * 8 : 0);
   uint4 re[4], ry[4], rx[4];
   uint2 rxn[FKW][MFX];       // raw producer output under this lane's e_in values (ReLU mask + statistics)
+  uint32_t rmk[4], rmx[FKW][MFX];   // DROP: mask bytes of the staged units of x / under this lane's e_in values
   auto issue = [&](long tile) {
     const long p0 = tile * TM;
     if (onG) {
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
         const long p = p0 + pgA * 4 + i;
         const long pc = p < g.P ? p : p0;
         rx[i] = *reinterpret_cast<const uint4*>(xg + pc * g.ldx);
+        if (DROP) rmk[i] = g.dmask[pc * nvA + cvA];
       }
     }
   };
@@ -116,12 +121,13 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 #pragma unroll
         for (int m = 0; m < MFX; ++m) {
           const long p = p0 + wp * PXW + m * 16 + fr;
-          rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
+          if (!DROP || g.x_pending) rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
+          if (DROP) rmx[i][m] = g.dmask[(p < g.P ? p : p0) * nvA + ((n < KC ? n : 0) >> 3)];
         }
       }
     }
   };
-  if (t_begin < t_end) { issue(t_begin); if (g.x_pending) issue_x(t_begin); }
+  if (t_begin < t_end) { issue(t_begin); if (DROP || g.x_pending) issue_x(t_begin); }
 
   // ---- block set-up under the first tile's loads: zero the images once (padding rows / columns stay zero), W^T, constants
   {
@@ -230,6 +236,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
           v[i][2 * h] = fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
           v[i][2 * h + 1] = fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
         }
+        if (DROP) {     // the operand bits of the forward pass: bf16(bf16(a) / (1 - p)), or zero
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = ((rmk[i] >> j) & 1u) ? V8<T>::round(v[i][j]) * g.dinv : 0.f;
+        }
         if (!ok) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -322,6 +332,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
               float v[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q];
+              if (DROP) {
+                const uint32_t mb = rmx[i][m] >> (n & 7);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = ((mb >> q) & 1u) ? v[q] * g.dinv : 0.f;
+              }
               bf16x4 o;
               if (g.x_pending) {
                 const uint2 xr = rxn[i][m];
@@ -344,7 +359,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
         }
       }
     }
-    if (g.x_pending && tile + g.gslots < t_end) issue_x(tile + g.gslots);
+    if ((DROP || g.x_pending) && tile + g.gslots < t_end) issue_x(tile + g.gslots);
   }
 
   // ---- the block's weight-gradient tile -> its workspace row, [NC][KC] like the parameter (blocks without tiles write zeros)
@@ -422,7 +437,7 @@ constexpr size_t smem_bytes() {
   return (size_t)((TR ? 0 : TM) + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float);
 }
 
-template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR>
+template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR, bool DROP = false>
 int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   const long ntiles = (g.P + TM - 1) / TM;
   long gs = (ntiles + 7) / 8;
@@ -433,8 +448,8 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW, TR>();
   static tss::DevOnce attr;
   if (attr.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL((pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL((pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR, DROP>), dim3(8 * (int)gs), dim3(NT), smem, stream, g);
   return 8 * (int)gs;
 }
 
@@ -509,6 +524,45 @@ int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, c
   else if (big_tr()) launch<256, 64, 8, 2, 2, true>(g, (hipStream_t)stream, 2);
   else launch<512, 128, 8, 1, 2, false>(g, (hipStream_t)stream, 1);
   return tss::check_last("pwconv_bwd_fused");
+}
+
+// The same sweep for a layer that applied nn.Dropout to its input on load (tss_pwconv_fwd_drop; mask bytes from tss_dropout_mask):
+// the weight gradient is taken against a * keep / (1 - p), e_in = keep / (1 - p) * relu'(BN(x)) * (g W).  One instance (64-pixel
+// tiles, Cin <= 128, Cout <= 64, ragged Cout allowed): the classifier convs (TSS/models/fastscnn.py:96-97, contextnet.py:85-86).
+int tss_pwconv_bwd_fused_drop_supported(long P, int Cin, int Cout, int dtype) {
+  return (dtype == TSS_BF16 && P > 0 && Cin >= 8 && (Cin % 8) == 0 && Cin <= 128 && Cout >= 8 && Cout <= 64) ? 1 : 0;
+}
+
+int tss_pwconv_bwd_fused_drop_rows(long P) {
+  long gs = ((P + 63) / 64 + 7) / 8;
+  if (gs > 64) gs = 64;
+  if (gs < 1) gs = 1;
+  return (int)(8 * gs);
+}
+
+int tss_pwconv_bwd_fused_drop(const void* e, long lde, const void* yraw, long ldyr, const float* ga, const float* gb, const float* gce,
+                              const float* gmu, const float* w, const void* x, long ldx, const float* in_mean,
+                              const float* in_scale, const float* in_bias, int in_relu, int x_pending, const void* mask, float drop_p,
+                              void* e_in, long ldei, double* bstats, float* ws, float* bias_ws, long P, int Cin, int Cout, int dtype,
+                              void* stream) {
+  const int CoutV = (Cout + 7) / 8 * 8;
+  TSS_REQUIRE(tss_pwconv_bwd_fused_drop_supported(P, Cin, Cout, dtype), TSS_ERR_SHAPE);
+  TSS_REQUIRE(e && x && e_in && ws && w && mask && drop_p > 0.f && drop_p < 1.f, TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= CoutV && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= CoutV && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!bstats || x_pending, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(x) && (!yraw || tss::aligned16(yraw)) && ((uintptr_t)e_in & 7u) == 0, TSS_ERR_ALIGN);
+  PbArgs g = {};
+  g.P = P; g.NC = Cout; g.KC = Cin;
+  g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldy = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.w = w;
+  g.x = (const T*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_pending = x_pending;
+  g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws; g.bias_ws = bias_ws;
+  g.dmask = (const unsigned char*)mask; g.dinv = 1.f / (1.f - drop_p);
+  tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
+                      ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0 + (double)P * (Cin / 8), 4.0 * (double)P * Cin * Cout);
+  launch<256, 64, 8, 1, 1, false, true>(g, (hipStream_t)stream, 2);
+  return tss::check_last("pwconv_bwd_fused_drop");
 }
 
 }  // extern "C"

@@ -47,6 +47,10 @@ struct FastArgs {
   int nsrc;
   const T* asrc[6]; long ldsrc[6];
   const float* c0s[6]; const float* c1s[6]; const float* c2s[6];
+  // forward, DROP instances: nn.Dropout between the pending BatchNorm + ReLU and this layer, applied on load.  dmask: one byte per
+  // (pixel, 8-channel vector) drawn by tss_dropout_mask (bit j = channel 8 v + j kept); dinv = 1 / (1 - p); dcounter: the device-side
+  // Philox counter the mask was keyed by -- advanced here, by the consumer, because every block of the mask kernel reads it
+  const unsigned char* dmask; float dinv; unsigned long long* dcounter;
 };
 
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -129,8 +133,9 @@ __device__ __forceinline__ void stage_weights_bf16(T* Ws, const T* wb, long ldwb
 // TM = pixels per tile.  Forward: 128.  Backward-data: 64 -- it stages two tensors (e, y) and needs the producer's raw
 // output in the epilogue; with 128-pixel tiles those registers leave no room to keep the next tile's loads in flight
 // (an attempt spilled 188 B/lane and lost), with 64-pixel tiles everything is prefetched and nothing spills.
-template <bool BWD, int TM>
+template <bool BWD, int TM, bool DROP = false>
 __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
+  static_assert(!(BWD && DROP), "dropout on load is a forward prologue");
   constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
   constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
   TSS_T(tq0);
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     return;
   }
   const int bidx = BWD ? (int)blockIdx.x - g.nred8 : (int)blockIdx.x;
+  if (DROP && blockIdx.x == 0 && threadIdx.x == 0) *g.dcounter += 1ull;     // the mask of this step is drawn: next step, next mask
 
   const int nchunks = (g.N + NCH - 1) / NCH;
   const int xcd = bidx & 7, slot = bidx >> 3;
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   // trip runs under tile t's MFMA + epilogue instead of being exposed at the top of every tile (counters: 76 % of the
   // wave cycles were waits at 2 waves/SIMD).  ra/rb are dead between the LDS store and the next tile: no extra VGPRs.
   uint4 ra[NP], rb[NP];
+  uint32_t rm[NP];          // DROP: the mask byte of this lane's vector, per staging pass
   // bwd: the producer's raw output under this lane's outputs (ReLU mask + statistics in the epilogue) travels with the same
   // prefetch, one tile ahead: issued at the top of the tile that needs it, it was 0.5 us old when the epilogue wanted it
   // (LDS store + barrier + 32 MFMAs) against a memory latency of 1.5-2 us -- every tile stalled on it.
@@ -222,6 +229,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
           const int rr = ok ? row : 0;
           ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
           if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
+          if (DROP) rm[ps] = g.dmask[(q0 + rr) * nvec + (cv_real ? cv : 0)];
         }
       }
     }
@@ -316,6 +324,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
             if (!BWD) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
+            }
+            if (DROP) {     // the bits the join + dropout pass stores: bf16(bf16(a) / (1 - p)), or zero
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = ((rm[ps] >> j) & 1u) ? V8<T>::round(v[j]) * g.dinv : 0.f;
             }
             if (!ok) {
 #pragma unroll
@@ -737,7 +749,7 @@ void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   else launch_fast_mc_tm<BWD, BM>(g, stream);
 }
 
-template <bool BWD, int TM>
+template <bool BWD, int TM, bool DROP = false>
 void launch_fast(FastArgs& g, hipStream_t stream) {
   constexpr size_t smem = (size_t)(TM + NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
   const int nchunks = (g.N + NCH - 1) / NCH;
@@ -751,9 +763,9 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   const int grid = 8 * nchunks * (int)gs + g.nred8;
   static tss::DevOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  hipLaunchKernelGGL((pwfast_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL((pwfast_kernel<BWD, TM, DROP>), dim3(grid), dim3(NT), smem, stream, g);
 }
 
 }  // namespace
@@ -789,6 +801,32 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
     if (t128 < thr) launch_fast<false, 64>(g, stream); else launch_fast<false, 128>(g, stream);
   } else launch_fast_mc<false>(g, stream);
   return true;
+}
+
+// forward with nn.Dropout applied on load: y = dropout(act(x)) W^T (+bias), mask bytes from tss_dropout_mask (pointwise.hip)
+extern "C" int tss_pwconv_drop_supported(long P, int K, int N, int dtype) {
+  return (!g_tss_disable_fast && dtype == TSS_BF16 && P > 0 && K >= 8 && K <= KMAX && (K % 8) == 0 && N >= 1 && N <= NCH) ? 1 : 0;
+}
+
+extern "C" int tss_pwconv_fwd_drop(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                   const float* w, const void* w_bf16, const float* bias, void* y, long ldy,
+                                   const void* mask, float drop_p, unsigned long long* counter,
+                                   long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(tss_pwconv_drop_supported(P, K, N, dtype) && drop_p > 0.f && drop_p < 1.f && mask && counter && x && w && y, TSS_ERR_SHAPE);
+  TSS_REQUIRE((ldx % 8) == 0 && ldx >= K && (ldy % 4) == 0 && ldy >= (N + 3) / 4 * 4, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && ((uintptr_t)y & 7u) == 0, TSS_ERR_ALIGN);
+  FastArgs g = {};
+  g.P = P; g.K = K; g.N = N;
+  g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
+  g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = nullptr;
+  if (w_bf16 && tss::aligned16(w_bf16)) { g.wb = (const T*)w_bf16; g.ldwb = K; }
+  g.dmask = (const unsigned char*)mask; g.dinv = 1.f / (1.f - drop_p); g.dcounter = counter;
+  tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N) * 2.0 + (double)P * (K / 8), 2.0 * (double)P * K * N);
+  static const long thr = getenv("TSS_PW_FWD_SMALL") ? atol(getenv("TSS_PW_FWD_SMALL")) : 4200;
+  const long t128 = (P + 127) / 128;
+  if (t128 < thr) launch_fast<false, 64, true>(g, (hipStream_t)stream); else launch_fast<false, 128, true>(g, (hipStream_t)stream);
+  return tss::check_last("pwconv_fwd_drop");
 }
 
 // forward over the channel concatenation of nsrc 128-channel tensors (see FastArgs::nsrc): the 1x1 `project` layer of an ASPP head

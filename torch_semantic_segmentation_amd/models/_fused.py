@@ -144,6 +144,15 @@ class FusedSequential(nn.Sequential):
                 i += 1
             elif isinstance(m, nn.Dropout):
                 _leaf_guard(m)
+                nxt = mods[i + 1] if i + 1 < n else None
+                if (m.training and m.p > 0 and isinstance(nxt, nn.Conv2d) and not _fwd_hooked(nxt)
+                        and not (i + 2 < n and isinstance(mods[i + 2], _BatchNorm)) and ops.drop_conv_supported(d, nxt, m.p)):
+                    # Dropout -> 1x1 conv (the Classifier's tail, TSS/models/fastscnn.py:96-97): the convolution applies the mask on
+                    # load, forward and backward; no pass over the activation just for the dropout
+                    _leaf_guard(nxt)
+                    d = ops.conv_unit(d, nxt, None, False, out_dtype=self.act_dtype, drop_p=m.p)
+                    i += 2
+                    continue
                 if m.training and m.p > 0:
                     if isinstance(d, Deferred) and d.relu and 0 < m.p < 1 and ops.fuse_dropout:
                         d = Deferred(ops.join(d, None, True, dropout_p=m.p))   # BN + ReLU + dropout in one pass
@@ -152,8 +161,22 @@ class FusedSequential(nn.Sequential):
                 i += 1
             elif isinstance(m, nn.UpsamplingBilinear2d):
                 _leaf_guard(m)
-                d = Deferred(ops.bilinear(d, size=m.size, scale_factor=m.scale_factor))
-                i += 1
+                # upsample -> depthwise block (FeatureFusionModule.lowres, TSS/models/fastscnn.py:74-76): one operator that
+                # interpolates on the fly (csrc/updw.hip) when the next child is such a block and nobody hooks it
+                nxt = mods[i + 1] if i + 1 < n else None
+                fused = None
+                if isinstance(nxt, FusedSequential) and not has_hooks(nxt):
+                    x = ops.to_nhwc(ops.materialize(d))
+                    d = x
+                    fused = ops.upsample_dw_unit(x, ops._out_size(x, m.size, m.scale_factor), nxt)
+                if fused is not None:
+                    for l in nxt:
+                        _leaf_guard(l)
+                    d = fused
+                    i += 2
+                else:
+                    d = Deferred(ops.bilinear(d, size=m.size, scale_factor=m.scale_factor))
+                    i += 1
             elif isinstance(m, nn.AdaptiveAvgPool2d):
                 _leaf_guard(m)
                 size = m.output_size

@@ -86,8 +86,20 @@ class FeatureFusionModule(nn.Module):
         self.highres = ConvBlock(highres_channels, out_channels, 1, use_relu=False)
 
     def forward(self, lowres, highres):
-        lowres = ops.bilinear(lowres, size=tuple(highres.shape[2:]))
-        return ops.join(run(self.lowres, lowres), run(self.highres, highres), relu=True)
+        size = tuple(highres.shape[2:])
+        first, rest = self.lowres[0], list(self.lowres)[1:]
+        fused = None
+        if not has_hooks(self.lowres):
+            # interpolate -> DWConvBlock(dilation=4) as one operator (csrc/updw.hip): the upsampled context map is never written
+            lowres = ops.to_nhwc(ops.materialize(lowres))
+            fused = ops.upsample_dw_unit(lowres, size, first)
+        if fused is not None:
+            d = fused
+            for m in rest:
+                d = run(m, d)
+        else:
+            d = run(self.lowres, ops.bilinear(lowres, size=size))
+        return ops.join(d, run(self.highres, highres), relu=True)
 
 
 def Classifier(in_channels, out_channels):

@@ -650,7 +650,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped', 'kh', 'kw')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped', 'kh', 'kw', 'drop_p')
 
 
 def _classify(conv, x_is_image):
@@ -699,15 +699,36 @@ def _classify(conv, x_is_image):
 _KEEP = object()
 
 
-def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_KEEP, gamma=None, beta=None, cout=None):
+def drop_conv_supported(x, conv, p):
+    """nn.Dropout(p) -> 1x1 `conv` (no BatchNorm behind it) can run as ONE unit that applies the dropout on load (conv_unit's drop_p)
+    instead of a pass of its own over the activation: the Classifier tails (TSS/models/fastscnn.py:96-97, contextnet.py:85-86)."""
+    if not (fuse_dropout and fuse_dropout_conv) or N.fast_paths_disabled() or not (0.0 < p < 1.0):
+        return False
+    try:
+        kind = _classify(conv, False)[0]
+    except NotImplementedError:
+        return False
+    raw = x.raw if isinstance(x, Deferred) else x
+    if kind != 'pw' or raw.dim() != 4 or raw.dtype != torch.bfloat16 or raw.shape[1] != conv.in_channels:
+        return False
+    P, dt = npix(raw), N.dtype_code(raw.dtype)
+    return bool(N.lib().tss_pwconv_drop_supported(P, conv.in_channels, conv.out_channels, dt)
+                and N.lib().tss_pwconv_bwd_fused_drop_supported(P, conv.in_channels, conv.out_channels, dt))
+
+
+def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_KEEP, gamma=None, beta=None, cout=None, drop_p=0.0):
     """conv -> [BatchNorm] -> [ReLU] as ONE deferred unit.  `x` is a Deferred, an NHWC/NCHW activation tensor
     or (for the stem) the contiguous NCHW image.  Returns a Deferred.
+    drop_p > 0 (after drop_conv_supported): nn.Dropout(drop_p) sits between x's pending activation and the convolution.
     weight / bias / gamma / beta / cout: run the unit with these tensors instead of the modules' own parameters (a weight padded
     with zero output rows so that a ragged channel count fills whole 8-channel vectors, a bias that a later kernel adds)."""
     is_image = (not isinstance(x, Deferred)) and x.dim() == 4 and x.shape[1] % 8 != 0
     kind, stride, dil = _classify(conv, is_image)
     cfg = UnitCfg()
     cfg.kind, cfg.stride, cfg.dil = kind, stride, dil
+    cfg.drop_p = float(drop_p)
+    if cfg.drop_p and (kind != 'pw' or bn is not None):
+        raise RuntimeError('conv_unit: dropout on load needs a 1x1 convolution without BatchNorm (drop_conv_supported)')
     cfg.overlapped = _overlap_depth[0] > 0
     cfg.cin, cfg.cout = conv.in_channels, (cout or conv.out_channels)
     cfg.kh, cfg.kw = conv.kernel_size
@@ -893,7 +914,15 @@ class ConvUnitFn(Function):
         stats = ptr(link.stats) if (link is not None and cfg.training) else None
         aff = _aff(cfg.in_link)
         st = stream()
-        if cfg.kind == 'pw':
+        mask = None
+        if cfg.kind == 'pw' and cfg.drop_p:
+            # the mask is drawn by its own small launch (one byte per 8 channels), applied on load here and in the backward sweep
+            mask = torch.empty(round_up(P * (cfg.cin // 8), 4), dtype=torch.uint8, device=dev)
+            counter = _dropout_counter(dev)
+            call('tss_dropout_mask', ptr(counter), ptr(mask), P, cfg.cin, cfg.drop_p, st)
+            call('tss_pwconv_fwd_drop', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), _shadow(weight, 0), ptr(bias),
+                 ptr(y), ld(y), ptr(mask), cfg.drop_p, ptr(counter), P, cfg.cin, Cout, dt, st)
+        elif cfg.kind == 'pw':
             call('tss_pwconv_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), _shadow(weight, 0), ptr(bias),
                  ptr(y), ld(y), stats, P, cfg.cin, Cout, dt, st)
         elif cfg.kind == 'dw':
@@ -934,7 +963,7 @@ class ConvUnitFn(Function):
             _finalize_forward(link, cfg.bn, cfg.training, P, Cout, gamma, st)
         cfg.out_link = link
         ctx.cfg = cfg
-        ctx.save_for_backward(x, weight, y if link is not None else None)
+        ctx.save_for_backward(x, weight, y if link is not None else None, mask)
         ctx.has_bias = bias is not None
         ctx.has_affine = gamma is not None
         return y
@@ -942,7 +971,7 @@ class ConvUnitFn(Function):
     @staticmethod
     def backward(ctx, e):
         cfg = ctx.cfg
-        x, weight, y = ctx.saved_tensors
+        x, weight, y, drop_mask = ctx.saved_tensors
         dev = x.device
         e = to_nhwc(e)
         dt = N.dtype_code(e.dtype)
@@ -991,7 +1020,7 @@ class ConvUnitFn(Function):
         # (fork after the finalize above, join before this function returns, so every tensor it reads is still alive
         # and a HIP-graph capture sees two parallel branches)
         main = torch.cuda.current_stream(dev)
-        side = _side_stream(dev) if (overlap_wgrad and need_dx and cfg.kind != 'stem'
+        side = _side_stream(dev) if (overlap_wgrad and need_dx and cfg.kind != 'stem' and drop_mask is None
                                     and overlap_min_elems <= P * (Cin + Cout) <= overlap_max_elems) else None
         wst = st
         if side is not None:
@@ -1012,6 +1041,8 @@ class ConvUnitFn(Function):
                 # few channels, many pixels: input gradient and weight gradient in ONE sweep (csrc/pwbwd.hip): e, y, x read once
                 fused_pw = bool(fuse_pw_backward and need_dx and side is None and e.dtype == torch.bfloat16
                                 and not N.fast_paths_disabled() and N.lib().tss_pwconv_bwd_fused_preferred(P, Cin, Cout, dt))
+                if drop_mask is not None:        # dropout on load: the one sweep is the only backward that knows the mask
+                    fused_pw = True
             postponed = False
             if fused_pw:
                 pass
@@ -1051,12 +1082,13 @@ class ConvUnitFn(Function):
                      P, Cin * 9, Cout, dt, None, wst)
             else:
                 call('tss_conv3x3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, s, d, dt, wst)
-            if need_dx:
+            if need_dx or drop_mask is not None:
                 e_in = new_nhwc(B, Cin, Hin, Win, e.dtype, dev)
                 margs = xargs if deferred_in else (None, 0, None, None, None, 0)
                 bst = ptr(il.bstats) if il is not None else None
                 if fused_pw:
-                    rows = N.lib().tss_pwconv_bwd_fused_rows(P, Cin, Cout)
+                    rows = (N.lib().tss_pwconv_bwd_fused_drop_rows(P) if drop_mask is not None
+                            else N.lib().tss_pwconv_bwd_fused_rows(P, Cin, Cout))
                     ws = torch.empty((rows, Cout * Cin), dtype=torch.float32, device=dev)
                     bws = dbias = None
                     if ctx.has_bias:          # the bias gradient leaves the same sweep as per-block rows (no colsum launch, no atomics)
@@ -1064,8 +1096,12 @@ class ConvUnitFn(Function):
                         dbias = _direct_target(p_bias)
                         if dbias is None:
                             dbias = fused_dbias = torch.zeros(Cout, dtype=torch.float32, device=dev)
-                    call('tss_pwconv_bwd_fused', *gargs, ptr(weight), _shadow(weight, 1), *xargs, int(bool(deferred_in)),
-                         ptr(e_in), ld(e_in), bst, ptr(ws), ptr(bws), P, Cin, Cout, dt, st)
+                    if drop_mask is not None:
+                        call('tss_pwconv_bwd_fused_drop', *gargs, ptr(weight), *xargs, int(bool(deferred_in)), ptr(drop_mask),
+                             cfg.drop_p, ptr(e_in), ld(e_in), bst, ptr(ws), ptr(bws), P, Cin, Cout, dt, st)
+                    else:
+                        call('tss_pwconv_bwd_fused', *gargs, ptr(weight), _shadow(weight, 1), *xargs, int(bool(deferred_in)),
+                             ptr(e_in), ld(e_in), bst, ptr(ws), ptr(bws), P, Cin, Cout, dt, st)
                     if dw_ret is None and fused_dbias is None and batch_dw_reductions:
                         _defer_dw_reduction(ws, dw, Cout * Cin, rows, p_weight)       # summed with the depthwise rows, at the end of the pass
                         if bws is not None:
@@ -1141,7 +1177,7 @@ class ConvUnitFn(Function):
         if stash is not None and e_in is not None and not deferred_in:
             stash.g2 = e_in                # the other consumer of this layer's input adds it in its own backward (fork_two)
         dbias_ret = fused_dbias
-        if ctx.has_bias and not (fused_pw and need_dx):
+        if ctx.has_bias and not (fused_pw and (need_dx or drop_mask is not None)):
             dbias = _direct_target(p_bias)
             if link is not None and link.training:
                 # BatchNorm with batch statistics removes any per-channel shift: d(loss)/d(bias) is exactly zero
@@ -1312,6 +1348,123 @@ class BilinearFn(Function):
         call('tss_bilinear_nhwc_bwd', ptr(dy), ld(dy), ptr(dx), ld(dx), ptr(tmp), B, H, W, ho, wo, C,
              N.dtype_code(dy.dtype), stream())
         return dx, None, None
+
+
+class _UpDwCfg:
+    __slots__ = ('size', 'dil', 'bn', 'training', 'out_link', 'params')
+
+
+def upsample_dw_unit(x, size, block):
+    """Bilinear upsample (align_corners=True) to `size` followed by `block` = depthwise 3x3 conv (padding = dilation) -> [BatchNorm]
+    -> [ReLU] as ONE deferred unit (csrc/updw.hip): the upsampled tensor is never written -- the low-resolution branch of the
+    feature-fusion modules (TSS/models/fastscnn.py:74-76, TSS/models/contextnet.py:110-122).  Returns a Deferred, or None when
+    the call is outside the kernel's envelope (the caller then runs the two operators one after the other).  TSS_UPDW=0: never."""
+    mods = list(block) if isinstance(block, torch.nn.Sequential) else None
+    if mods is None or not mods or N.fast_paths_disabled():
+        return None
+    conv = mods[0]
+    bn = mods[1] if len(mods) > 1 and isinstance(mods[1], _BatchNorm) else None
+    relu = isinstance(mods[-1], torch.nn.ReLU) and len(mods) > 1
+    if len(mods) != 1 + int(bn is not None) + int(relu) or not isinstance(conv, torch.nn.Conv2d) or conv.bias is not None:
+        return None
+    try:
+        kind, s, d = _classify(conv, False)
+    except NotImplementedError:
+        return None
+    if kind != 'dw' or s != 1:
+        return None
+    x = to_nhwc(materialize(x))
+    ho, wo = int(size[0]), int(size[1])
+    B, C, Hs, Ws = x.shape
+    if (x.dtype != torch.bfloat16 or C != conv.in_channels
+            or not N.lib().tss_updw_supported(B, Hs, Ws, ho, wo, C, d, N.dtype_code(x.dtype))):
+        return None
+    cfg = _UpDwCfg()
+    cfg.size, cfg.dil, cfg.bn, cfg.training = (ho, wo), d, bn, False
+    gamma = beta = None
+    if bn is not None:
+        cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
+        if (cfg.training and bn.momentum is None) or (cfg.training and _sync_group(bn) is not None):
+            return None
+        gamma, beta = bn.weight, bn.bias
+    cfg.params = (conv.weight, gamma, beta)
+    y = UpDwFn.apply(x, _f32(conv.weight), _f32(gamma), _f32(beta), cfg)
+    return Deferred(y, cfg.out_link, relu)
+
+
+class UpDwFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, cfg):
+        dev, st = x.device, stream()
+        B, C, Hs, Ws = x.shape
+        ho, wo = cfg.size
+        y = new_nhwc(B, C, ho, wo, x.dtype, dev)
+        P = B * ho * wo
+        link = None
+        if cfg.bn is not None:
+            if cfg.training and P <= 1:
+                raise ValueError('Expected more than 1 value per channel when training, got input size %s' % (tuple(y.shape),))
+            link = BNLink(C, P, cfg.training, gamma, beta, dev)
+        stats = ptr(link.stats) if (link is not None and cfg.training) else None
+        call('tss_updw_fwd', ptr(x), ld(x), Hs, Ws, ptr(weight), ptr(y), ld(y), stats, B, ho, wo, C, cfg.dil,
+             N.dtype_code(x.dtype), st)
+        if link is not None:
+            _finalize_forward(link, cfg.bn, cfg.training, P, C, gamma, st)
+        cfg.out_link = link
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, weight, y if link is not None else None)
+        ctx.has_affine = gamma is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, e):
+        cfg = ctx.cfg
+        x, weight, y = ctx.saved_tensors
+        dev, st = x.device, stream()
+        e = to_nhwc(e)
+        dt = N.dtype_code(e.dtype)
+        B, C, Hs, Ws = x.shape
+        ho, wo = cfg.size
+        link = cfg.out_link
+        p_weight, p_gamma, p_beta = cfg.params
+        dgamma = dbeta = None
+        ga = gb = gce = gmu = None
+        if link is not None:
+            acc = 0
+            if ctx.has_affine:
+                dgamma, dbeta = _direct_target(p_gamma), _direct_target(p_beta)
+                if dgamma is not None and dbeta is not None:
+                    acc = 1
+                else:
+                    dgb = torch.empty((2, C), dtype=torch.float32, device=dev)
+                    dgamma, dbeta = dgb[0], dgb[1]
+            _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st)
+            if acc:
+                dgamma = dbeta = None
+            ga, gb, gce, gmu = link.ga, link.gb, link.gce, link.mean
+            if not link.training:
+                y, gb, gce, gmu = None, None, None, None
+        else:
+            y = None
+        dw = _direct_target(p_weight)
+        dw_ret = None
+        if dw is None:
+            dw = dw_ret = torch.zeros_like(weight)
+        ws = torch.empty((N.lib().tss_updw_ws_rows(B, Hs, Ws, ho, wo, C, cfg.dil, dt), C * 9), dtype=torch.float32, device=dev)
+        e_up = new_nhwc(B, C, ho, wo, e.dtype, dev)
+        rows = ctypes.c_int(0)
+        call('tss_updw_bwd', ptr(e), ld(e), ptr(y), ld(y) if y is not None else 0, ptr(ga), ptr(gb), ptr(gce), ptr(gmu),
+             ptr(weight), ptr(x), ld(x), Hs, Ws, ptr(e_up), ld(e_up), ptr(ws), B, ho, wo, C, cfg.dil, dt, st, ctypes.byref(rows))
+        if dw_ret is None and batch_dw_reductions:
+            _defer_dw_reduction(ws, dw, C * 9, rows.value, p_weight)
+        else:
+            _reduce_rows_now(ws, dw, C * 9, rows.value)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = new_nhwc(B, C, Hs, Ws, e.dtype, dev)
+            tmp = torch.empty((B * Hs * wo * C,), dtype=torch.float32, device=dev)
+            call('tss_bilinear_nhwc_bwd', ptr(e_up), ld(e_up), ptr(dx), ld(dx), ptr(tmp), B, Hs, Ws, ho, wo, C, dt, st)
+        return dx, dw_ret, dgamma, dbeta, None
 
 
 def resize_image(x, size=None, scale_factor=None, out_dtype=None):
@@ -1600,6 +1753,8 @@ class GateFn(Function):
 # ----------------------------------------------------------------------------- pyramid pooling, all arms per launch
 
 fuse_dropout = True    # nn.Dropout after a pending BatchNorm + ReLU rides in the join that materialises it (False: own pass)
+# nn.Dropout in front of a 1x1 convolution is applied on load by that convolution (no join at all; TSS_DROP_CONV=0: the join form)
+fuse_dropout_conv = os.environ.get('TSS_DROP_CONV', '1') != '0'
 ppm_fused = os.environ.get('TSS_PPM_FUSED', '1') != '0'   # False: every arm through the generic operators (A/B checks)
 
 
