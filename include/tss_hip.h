@@ -370,8 +370,8 @@ int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtyp
 /* nn.Dropout in front of a 1x1 convolution (Classifier: ... -> BN -> ReLU -> Dropout(0.1) -> Conv2d(128, classes, 1),
  * TSS/models/fastscnn.py:96-97, TSS/models/contextnet.py:85-86) applied ON LOAD by that convolution instead of by a pass of its
  * own over the 128-channel activation (forward and backward).
- * tss_dropout_mask: mask = [P][C/8] bytes (buffer rounded up to whole 32-bit words), bit j of byte (p, v) = channel 8 v + j of pixel p
- *   is kept; Philox4x32-10 keyed by *counter (device), 16 bits per element.  It does NOT advance the counter: the consumer does.
+ * tss_dropout_mask: mask = [P][16] bytes (C <= 128: a pixel's bytes are one aligned 16-byte row), bit j of byte (p, v) = channel
+ *   8 v + j of pixel p is kept; Philox4x32-10 keyed by *counter (device), 16 bits per element.  It does NOT advance the counter: the consumer does.
  * tss_pwconv_fwd_drop: y = (keep / (1 - p) * act(x)) W^T + bias, act = the pending BatchNorm(+ReLU) of x; advances *counter.
  * tss_pwconv_bwd_fused_drop: tss_pwconv_bwd_fused with the same mask on the weight gradient's activation operand and on e_in;
  *   ws rows: tss_pwconv_bwd_fused_drop_rows(P).  bf16; K = Cin <= 128 (multiple of 8), N = Cout <= 64 (>= 8, may be ragged). */

@@ -337,10 +337,10 @@ def test_dropout_applied_on_load_by_the_classifier_conv(cin, classes, shape, pen
     # (2) the same mask, applied by torch to the materialised activation
     P = B * H * W
     counter = torch.tensor([seed], dtype=torch.int64, device=DEV)
-    mask = torch.empty((P * (cin // 8) + 3) // 4 * 4, dtype=torch.uint8, device=DEV)
+    mask = torch.empty((P, 16), dtype=torch.uint8, device=DEV)
     N.call('tss_dropout_mask', N.ptr(counter), N.ptr(mask), P, cin, p_drop, N.stream())
     torch.cuda.synchronize()
-    bits = (mask[:P * (cin // 8)].view(P, cin // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8).view(1, 1, 8)) & 1
+    bits = (mask[:, :cin // 8].reshape(P, cin // 8, 1) >> torch.arange(8, device=DEV, dtype=torch.uint8).view(1, 1, 8)) & 1
     keep = bits.view(B, H, W, cin).permute(0, 3, 1, 2).float()
     frac = keep.mean().item()
     assert abs(frac - (1 - p_drop)) < 4 * math.sqrt(p_drop * (1 - p_drop) / keep.numel()) + 1e-4

@@ -388,7 +388,8 @@ __global__ __launch_bounds__(NT) void dropout_kernel(const T* x, long ldx, T* y,
 }
 
 // The mask alone, for consumers that apply nn.Dropout on load (tss_pwconv_fwd_drop / tss_pwconv_bwd_fused_drop): one BYTE per
-// (pixel, 8-channel vector), bit j = channel 8 v + j is kept.  One Philox call per byte, 16 random bits per element (kept <=>
+// (pixel, 8-channel vector), bit j = channel 8 v + j is kept; a pixel's bytes form one 16-byte row (<= 128 channels), so a lane that
+// needs the mask of every channel of a pixel gets it with ONE aligned load.  One Philox call per byte, 16 random bits per element (kept <=>
 // bits >= round(p * 65536): the probability is exact to 2^-16), keyed by the device-side counter -- which this kernel only READS
 // (every block does; the consumer advances it, behind the kernel boundary, so no block can see the next step's value).
 __global__ __launch_bounds__(NT) void dropout_mask_kernel(const unsigned long long* counter, uint32_t* mask4, long nwords, float p) {
@@ -665,9 +666,10 @@ int tss_dropout_tick(unsigned long long* counter, unsigned long long* seed_slot,
 }
 
 int tss_dropout_mask(const unsigned long long* counter, void* mask, long P, int C, float p, void* stream) {
-  TSS_REQUIRE(counter && mask && C > 0 && (C % 8) == 0 && p > 0.f && p < 1.f && ((uintptr_t)mask & 3u) == 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(counter && mask && C > 0 && (C % 8) == 0 && p > 0.f && p < 1.f && tss::aligned16(mask), TSS_ERR_SHAPE);
   if (P == 0) return TSS_OK;
-  const long nwords = (P * (C / 8) + 3) / 4;        // the buffer holds whole 32-bit words (tss_dropout_mask_bytes)
+  TSS_REQUIRE(C <= 128, TSS_ERR_SHAPE);
+  const long nwords = P * 4;                         // [P][16] bytes
   long grid = (nwords + NT - 1) / NT;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(dropout_mask_kernel, dim3((int)grid), dim3(NT), 0, (hipStream_t)stream, counter, (uint32_t*)mask, nwords, p);

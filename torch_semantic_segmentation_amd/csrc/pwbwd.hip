@@ -39,7 +39,8 @@ __device__ __forceinline__ float bhi(uint32_t u) { return __uint_as_float(u & 0x
 // NFW = 16-channel fragments of Cout whose weight-gradient rows a wave owns (fragments w, w + NW, ...).  Two instances:
 // NSPLIT = 2: the waves pair up over the input-channel fragments of the input gradient (half of FKM each, twice the pixels).
 //   <256, 128, 4, 1, 1>: Cin, Cout <= 64, two blocks per CU;   <256, 64, 4, 2, 1>: Cin <= 64, Cout <= 128, two blocks per CU;
-//   <256, 64, 8, 1, 1>: Cin <= 128, Cout <= 64 (the 19-class classifier conv: Cout need not be a multiple of 8 -- e / y are read
+//   <256, 64, 8, 1, 1>: Cin <= 128, Cout <= 64 (<256, 64, 8, 1, 2> for the DROP form: the waves pair up over the input-channel
+//   fragments, half the statistics registers; without dropout the unpaired form is the faster one, 68 vs 76 us) (the 19-class classifier conv: Cout need not be a multiple of 8 -- e / y are read
 //   through their pitch, channels >= Cout are zeroed here, the weight-gradient row keeps the parameter's [Cout][Cin] shape);
 //   <512, 128, 8, 1, 2>: <= 128 channels, one 8-wave block per CU (opt-in: it loses to the two separate kernels)
 // TR: no pixel-major image of g at all -- the input-gradient product reads its g operand out of the channel-major image Gt with
@@ -61,6 +62,18 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   float* Ec = reinterpret_cast<float*>(At + KCM * ROWT); // [3][KCM]: producer's mean / scale / bias (ReLU mask, statistics)
   float* Cg = Ec + 3 * KCM;                              // [3][NCM]: g = ca*e + cb*y + cc
   float* Ca = Cg + 3 * NCM;                              // [2][KCM]: a = relu?(x*as + ab)
+  // DROP: the 16-byte mask rows of a tile's pixels, two tiles deep.  Wave 0 requests them one tile ahead (one row per lane, the
+  // FIRST request of an iteration, so that every later wait of the wave covers it) and parks them here at the top of the next
+  // iteration; read back byte-wise by the staging threads and by the epilogue.  (LDS-DMA was tried first: a pending
+  // global_load_lds makes the compiler put s_waitcnt vmcnt(0) in front of EVERY barrier -- the prefetch of the next tile, issued just
+  // before the mid-iteration barrier, was then waited for on the spot: 115 us against 68 without dropout.)
+  unsigned char* Ms = reinterpret_cast<unsigned char*>(Ca + 2 * KCM);     // [2][TM][16]
+  static_assert(!DROP || TM == 64, "one mask row per lane of wave 0");
+  uint4 mreg = make_uint4(0u, 0u, 0u, 0u);
+  auto mask_req = [&](long tile) {
+    const long p = tile * TM + (threadIdx.x & 63);
+    mreg = *reinterpret_cast<const uint4*>(g.dmask + (p < g.P ? p : g.P - 1) * 16);
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -87,7 +100,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   const T* xg = g.x + (onA ? cvA * 8 : 0);
   uint4 re[4], ry[4], rx[4];
   uint2 rxn[FKW][MFX];       // raw producer output under this lane's e_in values (ReLU mask + statistics)
-  uint32_t rmk[4], rmx[FKW][MFX];   // DROP: mask bytes of the staged units of x / under this lane's e_in values
   auto issue = [&](long tile) {
     const long p0 = tile * TM;
     if (onG) {
@@ -105,7 +117,6 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
         const long p = p0 + pgA * 4 + i;
         const long pc = p < g.P ? p : p0;
         rx[i] = *reinterpret_cast<const uint4*>(xg + pc * g.ldx);
-        if (DROP) rmk[i] = g.dmask[pc * nvA + cvA];
       }
     }
   };
@@ -121,13 +132,12 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 #pragma unroll
         for (int m = 0; m < MFX; ++m) {
           const long p = p0 + wp * PXW + m * 16 + fr;
-          if (!DROP || g.x_pending) rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
-          if (DROP) rmx[i][m] = g.dmask[(p < g.P ? p : p0) * nvA + ((n < KC ? n : 0) >> 3)];
+          rxn[i][m] = *reinterpret_cast<const uint2*>(px + (p < g.P ? p : p0) * g.ldx);
         }
       }
     }
   };
-  if (t_begin < t_end) { issue(t_begin); if (DROP || g.x_pending) issue_x(t_begin); }
+  if (t_begin < t_end) { issue(t_begin); if (g.x_pending) issue_x(t_begin); if (DROP && wave == 0) mask_req(t_begin); }
 
   // ---- block set-up under the first tile's loads: zero the images once (padding rows / columns stay zero), W^T, constants
   {
@@ -148,9 +158,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
       *reinterpret_cast<uint4*>(Ws + ci * RSX + v * 8) = *reinterpret_cast<const uint4*>(g.wT + (long)ci * g.ldwT + v * 8);
     }
   } else {
+    const float wscale = DROP ? g.dinv : 1.f;         // DROP: e_in = keep / (1 - p) * (g W): the factor rides in the weights
     for (int i = tid; i < NC * KC; i += NT) {        // coalesced reads of w[kc][ci], transposing 2-byte stores
       const int kc = i / KC, ci = i - kc * KC;
-      Ws[ci * RSX + kc] = (T)g.w[i];
+      Ws[ci * RSX + kc] = (T)(g.w[i] * wscale);
     }
   }
   // per-channel constants of the two transforms -> LDS (read back as 16-byte vectors by the staging threads: 40 registers less)
@@ -188,9 +199,14 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
     return tile + row * ROWT + ((((boff >> 4)) ^ ((row >> 3) & 7)) << 4) + (boff & 15);
   };
 
+  int mbuf = 0;
   for (long tile = t_begin; tile < t_end; tile += g.gslots) {
     const long p0 = tile * TM;
+    if (DROP && wave == 0) *reinterpret_cast<uint4*>(Ms + mbuf * TM * 16 + (threadIdx.x & 63) * 16) = mreg;   // (last read two tiles ago)
     __syncthreads();          // the previous tile's matrix products have read the images (first pass: set-up complete)
+    const unsigned char* mrow = Ms + mbuf * TM * 16;
+    if (DROP && wave == 0 && tile + g.gslots < t_end) mask_req(tile + g.gslots);
+    mbuf ^= 1;
     if (onG) {
       float v[4][8], ca[8], cb[8], cc[8];
       V8<float>::load(Cg + cvG * 8, ca); V8<float>::load(Cg + NCM + cvG * 8, cb); V8<float>::load(Cg + 2 * NCM + cvG * 8, cc);
@@ -236,9 +252,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
           v[i][2 * h] = fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
           v[i][2 * h + 1] = fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
         }
-        if (DROP) {     // the operand bits of the forward pass: bf16(bf16(a) / (1 - p)), or zero
+        if (DROP) {     // kept or zero; the factor 1 / (1 - p) of the weight gradient is applied once, to the block's finished tile
+          const uint32_t mk = mrow[(pgA * 4 + i) * 16 + cvA];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] = ((rmk[i] >> j) & 1u) ? V8<T>::round(v[i][j]) * g.dinv : 0.f;
+          for (int j = 0; j < 8; ++j) if (!((mk >> j) & 1u)) v[i][j] = 0.f;
         }
         if (!ok) {
 #pragma unroll
@@ -332,10 +349,10 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
               float v[4];
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q];
-              if (DROP) {
-                const uint32_t mb = rmx[i][m] >> (n & 7);
+              if (DROP) {     // (the factor 1 / (1 - p) is in W^T)
+                const uint32_t mb = (uint32_t)mrow[(wp * PXW + m * 16 + fr) * 16 + (n >> 3)] >> (n & 7);   // bit n % 8 onwards of byte n / 8
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = ((mb >> q) & 1u) ? v[q] * g.dinv : 0.f;
+                for (int q = 0; q < 4; ++q) if (!((mb >> q) & 1u)) v[q] = 0.f;
               }
               bf16x4 o;
               if (g.x_pending) {
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
         }
       }
     }
-    if ((DROP || g.x_pending) && tile + g.gslots < t_end) issue_x(tile + g.gslots);
+    if (g.x_pending && tile + g.gslots < t_end) issue_x(tile + g.gslots);
   }
 
   // ---- the block's weight-gradient tile -> its workspace row, [NC][KC] like the parameter (blocks without tiles write zeros)
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int kc = f * 16 + fq * 4 + r;
-              if (kc < NC && ci < KC) wr[(long)kc * KC + ci] = dw[u][j][r];
+              if (kc < NC && ci < KC) wr[(long)kc * KC + ci] = DROP ? dw[u][j][r] * g.dinv : dw[u][j][r];
             }
           }
         }
@@ -431,10 +448,11 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
   }
 }
 
-template <int NT, int TM, int FKM, int NFW, bool TR>
+template <int NT, int TM, int FKM, int NFW, bool TR, bool DROP = false>
 constexpr size_t smem_bytes() {
   constexpr int NCM = 16 * (NT / 64) * NFW, KCM = 16 * FKM;
-  return (size_t)((TR ? 0 : TM) + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float);
+  return (size_t)((TR ? 0 : TM) + KCM) * (NCM + 8) * 2 + (size_t)(NCM + KCM) * (TM * 2 + 16) + (5 * KCM + 3 * NCM) * sizeof(float)
+         + (DROP ? 2 * TM * 16 : 0);
 }
 
 template <int NT, int TM, int FKM, int NFW, int NSPLIT, bool TR, bool DROP = false>
@@ -445,7 +463,7 @@ int launch(PbArgs& g, hipStream_t stream, int blocks_per_cu) {
   if (gs > cap) gs = cap;
   if (gs < 1) gs = 1;
   g.gslots = (int)gs;
-  constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW, TR>();
+  constexpr size_t smem = smem_bytes<NT, TM, FKM, NFW, TR, DROP>();
   static tss::DevOnce attr;
   if (attr.first())
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwbwd_kernel<NT, TM, FKM, NFW, NSPLIT, TR, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -561,7 +579,7 @@ int tss_pwconv_bwd_fused_drop(const void* e, long lde, const void* yraw, long ld
   g.dmask = (const unsigned char*)mask; g.dinv = 1.f / (1.f - drop_p);
   tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream,
                       ((double)P * Cout * (yraw ? 2 : 1) + (double)P * Cin * 2) * 2.0 + (double)P * (Cin / 8), 4.0 * (double)P * Cin * Cout);
-  launch<256, 64, 8, 1, 1, false, true>(g, (hipStream_t)stream, 2);
+  launch<256, 64, 8, 1, 2, false, true>(g, (hipStream_t)stream, 2);
   return tss::check_last("pwconv_bwd_fused_drop");
 }
 

@@ -47,8 +47,8 @@ struct FastArgs {
   int nsrc;
   const T* asrc[6]; long ldsrc[6];
   const float* c0s[6]; const float* c1s[6]; const float* c2s[6];
-  // forward, DROP instances: nn.Dropout between the pending BatchNorm + ReLU and this layer, applied on load.  dmask: one byte per
-  // (pixel, 8-channel vector) drawn by tss_dropout_mask (bit j = channel 8 v + j kept); dinv = 1 / (1 - p); dcounter: the device-side
+  // forward, DROP instances: nn.Dropout between the pending BatchNorm + ReLU and this layer, applied on load.  dmask: [P][16] bytes, one
+  // per (pixel, 8-channel vector), drawn by tss_dropout_mask (bit j = channel 8 v + j kept); dinv = 1 / (1 - p); dcounter: the device-side
   // Philox counter the mask was keyed by -- advanced here, by the consumer, because every block of the mask kernel reads it
   const unsigned char* dmask; float dinv; unsigned long long* dcounter;
 };
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
           const int rr = ok ? row : 0;
           ra[ps] = *reinterpret_cast<const uint4*>(pa + rr * lda);
           if (BWD) rb[ps] = *reinterpret_cast<const uint4*>(pb + rr * ldb);
-          if (DROP) rm[ps] = g.dmask[(q0 + rr) * nvec + (cv_real ? cv : 0)];
+          if (DROP) rm[ps] = g.dmask[(q0 + rr) * 16 + (cv_real ? cv : 0)];       // mask rows are 16 bytes per pixel
         }
       }
     }
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], relu_lo);
             }
-            if (DROP) {     // the bits the join + dropout pass stores: bf16(bf16(a) / (1 - p)), or zero
+            if (DROP) {     // kept or zero; the factor 1 / (1 - p) is applied to the (few) outputs, in the epilogue
 #pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] = ((rm[ps] >> j) & 1u) ? V8<T>::round(v[j]) * g.dinv : 0.f;
+              for (int j = 0; j < 8; ++j) if (!((rm[ps] >> j) & 1u)) v[j] = 0.f;
             }
             if (!ok) {
 #pragma unroll
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
           if (pin && nin) {
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : acc[m][i][q] + bs[q];
+            for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : (DROP ? acc[m][i][q] * g.dinv + bs[q] : acc[m][i][q] + bs[q]);
             if (BWD && g.xm) {
               const uint2 xr = rxm[i][m];
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};

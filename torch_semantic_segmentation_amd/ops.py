@@ -74,6 +74,7 @@ postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
 # the other stream's kernels already fill the launch gaps, and what postponing leaves for the end of the pass (a weight gradient and
 # its slot reduction per stream, un-overlapped) costs more than the finalize launches it saves (measured: 6.32 vs 6.21 ms per step).
 _overlap_depth = [0]
+postpone_in_overlap = os.environ.get('TSS_POSTPONE_OVERLAPPED', '0') == '1'     # A/B: postpone inside two-stream regions too
 _pending_wg = {}       # stream id -> (launch(fin_job or None), device, stream)
 _pending_red = {}      # stream id -> (ws, dw, P, K, N, device, stream)
 _cb_task = [None]
@@ -299,6 +300,7 @@ def _side_stream(device):
     if key not in _side_streams:
         _side_streams[key] = torch.cuda.Stream(device=device)
     return _side_streams[key]
+
 
 
 # bf16 shadows of the 1x1 convolution weights (WeightShadows below): {weight.data_ptr(): (copy [N][K], transpose [K][N])},
@@ -729,7 +731,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_K
     cfg.drop_p = float(drop_p)
     if cfg.drop_p and (kind != 'pw' or bn is not None):
         raise RuntimeError('conv_unit: dropout on load needs a 1x1 convolution without BatchNorm (drop_conv_supported)')
-    cfg.overlapped = _overlap_depth[0] > 0
+    cfg.overlapped = _overlap_depth[0] > 0 and not postpone_in_overlap
     cfg.cin, cfg.cout = conv.in_channels, (cout or conv.out_channels)
     cfg.kh, cfg.kw = conv.kernel_size
     if kind == 'stem':
@@ -917,7 +919,7 @@ class ConvUnitFn(Function):
         mask = None
         if cfg.kind == 'pw' and cfg.drop_p:
             # the mask is drawn by its own small launch (one byte per 8 channels), applied on load here and in the backward sweep
-            mask = torch.empty(round_up(P * (cfg.cin // 8), 4), dtype=torch.uint8, device=dev)
+            mask = torch.empty((P, 16), dtype=torch.uint8, device=dev)
             counter = _dropout_counter(dev)
             call('tss_dropout_mask', ptr(counter), ptr(mask), P, cfg.cin, cfg.drop_p, st)
             call('tss_pwconv_fwd_drop', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), _shadow(weight, 0), ptr(bias),
