@@ -374,7 +374,7 @@ int tss_bias_grad(const void* e, long lde, long P, int N, float* dbias, int dtyp
  *   8 v + j of pixel p is kept; Philox4x32-10 keyed by *counter (device), 16 bits per element.  It does NOT advance the counter: the consumer does.
  * tss_pwconv_fwd_drop: y = (keep / (1 - p) * act(x)) W^T + bias, act = the pending BatchNorm(+ReLU) of x; advances *counter.
  * tss_pwconv_bwd_fused_drop: tss_pwconv_bwd_fused with the same mask on the weight gradient's activation operand and on e_in;
- *   ws rows: tss_pwconv_bwd_fused_drop_rows(P).  bf16; K = Cin <= 128 (multiple of 8), N = Cout <= 64 (>= 8, may be ragged). */
+ *   ws rows: tss_pwconv_bwd_fused_drop_rows(P); yraw must be NULL (no BatchNorm behind the convolution).  bf16; K = Cin <= 128 (multiple of 8), N = Cout <= 64 (>= 8, may be ragged). */
 int tss_dropout_mask(const unsigned long long* counter, void* mask, long P, int C, float p, void* stream);
 int tss_pwconv_drop_supported(long P, int K, int N, int dtype);
 int tss_pwconv_fwd_drop(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

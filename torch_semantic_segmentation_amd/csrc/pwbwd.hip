@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
         const long p = p0 + pgG * 4 + i;
         const long pc = p < g.P ? p : p0;          // clamp to the tile's first pixel (always valid) and zero afterwards
         re[i] = *reinterpret_cast<const uint4*>(eg + pc * g.lde);
-        ry[i] = *reinterpret_cast<const uint4*>(yg + pc * ldyy);
+        if (!DROP) ry[i] = *reinterpret_cast<const uint4*>(yg + pc * ldyy);     // (DROP: no BatchNorm behind the layer, host-checked: g = ca * e)
       }
     }
     if (onA) {
@@ -214,11 +214,16 @@ __global__ __launch_bounds__(NT, (NT == 256 ? 2 : 1)) void pwbwd_kernel(const Pb
       for (int i = 0; i < 4; ++i) {
         const bool ok = p0 + pgG * 4 + i < g.P;
         const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[i]);
-        const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[i]);
+        const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[DROP ? 0 : i]);
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-          v[i][2 * h] = ca[2 * h] * blo(ue[h]) + (cb[2 * h] * blo(uy[h]) + cc[2 * h]);
-          v[i][2 * h + 1] = ca[2 * h + 1] * bhi(ue[h]) + (cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]);
+          if (DROP) {
+            v[i][2 * h] = ca[2 * h] * blo(ue[h]);
+            v[i][2 * h + 1] = ca[2 * h + 1] * bhi(ue[h]);
+          } else {
+            v[i][2 * h] = ca[2 * h] * blo(ue[h]) + (cb[2 * h] * blo(uy[h]) + cc[2 * h]);
+            v[i][2 * h + 1] = ca[2 * h + 1] * bhi(ue[h]) + (cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]);
+          }
         }
         if (!ok) {
 #pragma unroll
@@ -567,12 +572,12 @@ int tss_pwconv_bwd_fused_drop(const void* e, long lde, const void* yraw, long ld
   TSS_REQUIRE(tss_pwconv_bwd_fused_drop_supported(P, Cin, Cout, dtype), TSS_ERR_SHAPE);
   TSS_REQUIRE(e && x && e_in && ws && w && mask && drop_p > 0.f && drop_p < 1.f, TSS_ERR_SHAPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= CoutV && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= CoutV && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw, TSS_ERR_SHAPE);           // a convolution behind nn.Dropout with a training-mode BatchNorm behind IT: not this entry
   TSS_REQUIRE(!bstats || x_pending, TSS_ERR_SHAPE);
-  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(x) && (!yraw || tss::aligned16(yraw)) && ((uintptr_t)e_in & 7u) == 0, TSS_ERR_ALIGN);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(x) && ((uintptr_t)e_in & 7u) == 0, TSS_ERR_ALIGN);
   PbArgs g = {};
   g.P = P; g.NC = Cout; g.KC = Cin;
-  g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldy = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.e = (const T*)e; g.lde = lde; g.y = nullptr; g.ldy = 0; g.ga = ga; g.gb = nullptr; g.gce = nullptr; g.gmu = nullptr;
   g.w = w;
   g.x = (const T*)x; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu; g.x_pending = x_pending;
   g.ein = (T*)e_in; g.ldei = ldei; g.stats = bstats; g.ws = ws; g.bias_ws = bias_ws;
