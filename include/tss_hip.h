@@ -87,6 +87,16 @@ const char* tss_prof_symbol(int kernel_id);  /* device kernel the operator launc
 int tss_pwconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w, const void* w_bf16, const float* bias, void* y, long ldy, double* stats,
                    long P, int K, int N, int dtype, void* stream);
+/* Eval mode (frozen statistics, no gradient): the BatchNorm BEHIND the layer, the skip of a residual block and the ReLU after the sum
+ * are applied in the epilogue, so a block output is written by its last 1x1 layer and no join pass exists:
+ *   y = relu?((x_act W^T + bias - out_mean) * out_scale + out_beta + residual)      out_scale = gamma / sqrt(running_var + eps)
+ * replaces: conv3 -> BatchNorm2d -> (+ input) -> ReLU of BottleneckBlock.forward, TSS/models/fastscnn.py:152-161,
+ *           TSS/models/contextnet.py:139-147 under model.eval().  bf16; K <= 768 (multiple of 8), N a multiple of 4. */
+int tss_pwconv_fwd_joined(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                          const float* w, const void* w_bf16, const float* bias,
+                          const float* out_mean, const float* out_scale, const float* out_beta,
+                          const void* residual, long ldr, int out_relu, void* y, long ldy,
+                          long P, int K, int N, int dtype, void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
  * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
  * wT_bf16 (optional, bf16 path): a current bf16 TRANSPOSE [K][N] of w written by tss_cast_weights.

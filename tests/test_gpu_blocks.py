@@ -524,3 +524,63 @@ def test_residual_fan_in_folded_into_the_first_layers_backward_matches_autograds
     for k in g0:
         if g0[k].norm() > 1e-3:
             assert l2(g1[k], g0[k]) < 2e-2, k
+
+
+@pytest.mark.parametrize('family,cin,cout,stride,shape', [('fastscnn', 64, 64, 1, (2, 24, 40)), ('fastscnn', 64, 96, 2, (2, 24, 40)),
+                                                         ('fastscnn', 128, 128, 1, (1, 32, 64)), ('contextnet', 32, 32, 1, (3, 17, 9)),
+                                                         ('contextnet', 48, 64, 2, (2, 16, 24))])
+def test_eval_block_output_written_by_conv3_epilogue(family, cin, cout, stride, shape):
+    """model.eval(), no gradient, bf16: BottleneckBlock's frozen BatchNorm, skip and ReLU run in the epilogue of conv3
+    (tss_pwconv_fwd_joined) instead of a join pass.  Against the join form of the same block (TSS_EVAL_EPILOGUE=0 path) and against the
+    block evaluated by torch in f32 on the same bf16 input (TSS/models/fastscnn.py:152-161, TSS/models/contextnet.py:139-147)."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    M = importlib.import_module('torch_semantic_segmentation_amd.models.' + family)
+    torch.manual_seed(53)
+    m = M.BottleneckBlock(cin, cout, stride=stride, expansion=6).to(DEV)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(0, 0.3)
+            mod.running_var.uniform_(0.5, 1.5)
+            mod.weight.data.uniform_(0.5, 1.5)
+            mod.bias.data.normal_(0, 0.2)
+    tssa.set_compute_dtype(m, torch.bfloat16)
+    m.eval()
+    B, H, W = shape
+    x = torch.randn(B, cin, H, W, device=DEV).to(torch.bfloat16)
+    calls = []
+    orig = ops.conv_unit_joined
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        calls.append(r is not None)
+        return r
+    ops.conv_unit_joined = spy
+    try:
+        with torch.no_grad():
+            y1 = m(x).float()
+            old = ops.eval_epilogue
+            ops.eval_epilogue = False
+            try:
+                y0 = m(x).float()
+            finally:
+                ops.eval_epilogue = old
+    finally:
+        ops.conv_unit_joined = orig
+    assert calls == [True, False]
+    # torch, f32, the reference's formula
+    with torch.no_grad():
+        c1, b1 = m.conv1[0], m.conv1[1]
+        c2, b2 = m.conv2[0], m.conv2[1]
+        c3, b3 = m.conv3[0], m.conv3[1]
+        import torch.nn.functional as F
+        t = F.relu(F.batch_norm(F.conv2d(x.float(), c1.weight), b1.running_mean, b1.running_var, b1.weight, b1.bias, False, 0.0, b1.eps))
+        t = F.relu(F.batch_norm(F.conv2d(t, c2.weight, stride=stride, padding=1, groups=c2.groups), b2.running_mean, b2.running_var,
+                                b2.weight, b2.bias, False, 0.0, b2.eps))
+        t = F.batch_norm(F.conv2d(t, c3.weight), b3.running_mean, b3.running_var, b3.weight, b3.bias, False, 0.0, b3.eps)
+        ref = F.relu(t + x.float()) if tuple(t.shape) == tuple(x.shape) else F.relu(t)
+    assert cases.rel_err(y1.cpu(), y0.cpu()) < 2e-2
+    e1 = ((y1 - ref).norm() / ref.norm()).item()
+    e0 = ((y0 - ref).norm() / ref.norm()).item()
+    assert e1 < 1e-2 and e1 < 1.2 * e0 + 1e-3, (e1, e0)       # (the epilogue form skips one bf16 rounding of the conv output)

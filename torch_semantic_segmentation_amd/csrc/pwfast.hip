@@ -51,6 +51,10 @@ struct FastArgs {
   // per (pixel, 8-channel vector), drawn by tss_dropout_mask (bit j = channel 8 v + j kept); dinv = 1 / (1 - p); dcounter: the device-side
   // Philox counter the mask was keyed by -- advanced here, by the consumer, because every block of the mask kernel reads it
   const unsigned char* dmask; float dinv; unsigned long long* dcounter;
+  // forward, eval mode (frozen statistics): the BatchNorm BEHIND the layer, the skip of a residual block and the ReLU after the sum are
+  // applied in the epilogue -- y = relu?((acc + bias - emean) * escale + ebeta + radd) -- so the block output is written by the layer
+  // itself and no join pass exists (escale == NULL: plain output).  radd / ldr as in backward.
+  const float* emean; const float* escale; const float* ebeta; int erelu;
 };
 
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -182,6 +186,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     Ec[tid] = (in && hm) ? e0 : 0.f;
     Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
     Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
+    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
+      const float sc = g.escale[nn], mu = g.emean ? g.emean[nn] : 0.f, be = g.ebeta ? g.ebeta[nn] : 0.f;
+      Ec[tid] = in ? be + ((hm ? e0 : 0.f) - mu) * sc : 0.f;
+      Ec[NCH + tid] = in ? sc : 0.f;
+    }
   }
   const int K = g.K;
   const int kwp = (K + 31) & ~31;          // MFMA k-steps cover kwp columns; columns >= K are zero in both tiles
@@ -389,6 +398,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : (DROP ? acc[m][i][q] * g.dinv + bs[q] : acc[m][i][q] + bs[q]);
+            if (!BWD && g.escale) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q] * cms[q] + bs[q];
+            }
             if (BWD && g.xm) {
               const uint2 xr = rxm[i][m];
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
@@ -403,10 +416,14 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
               for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             } else {
-              if (BWD && g.radd) {     // fan-in of a residual block: the other gradient of this tensor is added here, not by a launch of its own
+              if (g.radd) {     // bwd: fan-in of a residual block (the other gradient of this tensor); fwd, eval epilogue: the block's skip
                 const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
                 const uint2 rr = *reinterpret_cast<const uint2*>(g.radd + pr * g.ldr + nlane + i * 16);
                 v[0] += bits_lo(rr.x); v[1] += bits_hi(rr.x); v[2] += bits_lo(rr.y); v[3] += bits_hi(rr.y);
+              }
+              if (!BWD && g.erelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
               }
               bf16x4 o;
 #pragma unroll
@@ -515,6 +532,11 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     Ec[tid] = (in && hm) ? e0 : 0.f;
     Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
     Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
+    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
+      const float sc = g.escale[nn], mu = g.emean ? g.emean[nn] : 0.f, be = g.ebeta ? g.ebeta[nn] : 0.f;
+      Ec[tid] = in ? be + ((hm ? e0 : 0.f) - mu) * sc : 0.f;
+      Ec[NCH + tid] = in ? sc : 0.f;
+    }
   }
   const int K = g.K;
   const int nkc = (K + KMAX - 1) / KMAX;
@@ -660,6 +682,10 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
             float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = BWD ? acc[m][i][q] : acc[m][i][q] + bs[q];
+            if (!BWD && g.escale) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q] * cms[q] + bs[q];
+            }
             if (BWD && g.xm) {
               const uint2 xr = *reinterpret_cast<const uint2*>(xrow_m + (long)m * 16 * g.ldxm + i * 16);
               const float xc[4] = {bits_lo(xr.x) - cmm[0], bits_hi(xr.x) - cmm[1], bits_lo(xr.y) - cmm[2], bits_hi(xr.y) - cmm[3]};
@@ -674,10 +700,14 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
               for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * xc[q]; }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             } else {
-              if (BWD && g.radd) {     // fan-in of a residual block: the other gradient of this tensor is added here, not by a launch of its own
+              if (g.radd) {     // bwd: fan-in of a residual block (the other gradient of this tensor); fwd, eval epilogue: the block's skip
                 const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
                 const uint2 rr = *reinterpret_cast<const uint2*>(g.radd + pr * g.ldr + nlane + i * 16);
                 v[0] += bits_lo(rr.x); v[1] += bits_hi(rr.x); v[2] += bits_lo(rr.y); v[3] += bits_hi(rr.y);
+              }
+              if (!BWD && g.erelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
               }
               bf16x4 o;
 #pragma unroll
@@ -801,6 +831,33 @@ bool tss_pwfast_fwd(const void* x, long ldx, const float* in_mean, const float* 
     if (t128 < thr) launch_fast<false, 64>(g, stream); else launch_fast<false, 128>(g, stream);
   } else launch_fast_mc<false>(g, stream);
   return true;
+}
+
+// forward with the eval-mode BatchNorm behind the layer, the skip and the ReLU after the sum in the epilogue (see FastArgs::escale)
+extern "C" int tss_pwconv_fwd_joined(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                     const float* w, const void* w_bf16, const float* bias,
+                                     const float* out_mean, const float* out_scale, const float* out_beta,
+                                     const void* residual, long ldr, int out_relu, void* y, long ldy,
+                                     long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(!g_tss_disable_fast && P > 0 && K >= 8 && K <= KTOT && (K % 8) == 0 && N >= 4 && (N % 4) == 0 && x && w && y && out_scale,
+              TSS_ERR_SHAPE);
+  TSS_REQUIRE((ldx % 8) == 0 && ldx >= K && (ldy % 4) == 0 && ldy >= N && (!residual || ((ldr % 4) == 0 && ldr >= N)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(x) && ((uintptr_t)y & 7u) == 0 && (!residual || ((uintptr_t)residual & 7u) == 0), TSS_ERR_ALIGN);
+  FastArgs g = {};
+  g.P = P; g.K = K; g.N = N;
+  g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
+  g.w = w; g.w_trans = 0; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = nullptr;
+  if (w_bf16 && tss::aligned16(w_bf16)) { g.wb = (const T*)w_bf16; g.ldwb = K; }
+  g.emean = out_mean; g.escale = out_scale; g.ebeta = out_beta; g.erelu = out_relu;
+  g.radd = (const T*)residual; g.ldr = ldr;
+  tss::ProfScope prof(TSS_K_PWCONV_FWD, (hipStream_t)stream, (double)P * (K + N * (residual ? 2 : 1)) * 2.0, 2.0 * (double)P * K * N);
+  if (K <= KMAX) {
+    static const long thr = getenv("TSS_PW_FWD_SMALL") ? atol(getenv("TSS_PW_FWD_SMALL")) : 4200;
+    const long t128 = (P + 127) / 128 * ((N + NCH - 1) / NCH);
+    if (t128 < thr) launch_fast<false, 64>(g, (hipStream_t)stream); else launch_fast<false, 128>(g, (hipStream_t)stream);
+  } else launch_fast_mc<false>(g, (hipStream_t)stream);
+  return tss::check_last("pwconv_fwd_joined");
 }
 
 // forward with nn.Dropout applied on load: y = dropout(act(x)) W^T (+bias), mask bytes from tss_dropout_mask (pointwise.hip)

@@ -67,6 +67,12 @@ class BottleneckBlock(nn.Module):
         finally:                                   # (also when a layer raises: ids are recycled, a stale entry would be picked up later)
             if fork is not None:
                 ops._pending_forks.pop(id(xa), None)
+        if fork is None and not has_hooks(self.conv3):
+            # model.eval(), no gradient: the frozen BatchNorm, the skip and the ReLU ride in conv3's epilogue -- no join pass
+            same_shape = (d.shape[0], c3.out_channels) + tuple(d.shape[2:]) == tuple(x.shape)
+            out = ops.conv_unit_joined(d, self.conv3, xb if same_shape else None, relu=True)
+            if out is not None:
+                return out
         d = run(self.conv3, d)
         same = tuple(d.shape) == tuple(x.shape)
         return ops.join(d, xb if same else None, relu=True, fork=fork if same else None)

@@ -821,6 +821,48 @@ def conv_unit_multi(branches, conv, bn=None, relu=False):
     return Deferred(y, link, relu)
 
 
+eval_epilogue = os.environ.get('TSS_EVAL_EPILOGUE', '1') != '0'   # A/B: 0 = eval-mode block outputs through the join pass, as in training
+
+
+def conv_unit_joined(x, block, residual=None, relu=True):
+    """Eval-mode, no-grad form of `join(block(x), residual, relu)` for block = FusedSequential(1x1 Conv2d, BatchNorm2d): the frozen
+    BatchNorm, the skip and the ReLU run in the epilogue of the convolution (tss_pwconv_fwd_joined), so the block output is written
+    once and no join pass exists (BottleneckBlock.forward of both models under model.eval()).  Returns the materialised tensor, or None
+    when the call is outside that envelope (training statistics, gradients, f32, hooks: the caller takes the ordinary path)."""
+    if not eval_epilogue or torch.is_grad_enabled() or N.fast_paths_disabled():
+        return None
+    mods = list(block) if isinstance(block, torch.nn.Sequential) else None
+    if mods is None or len(mods) != 2 or not isinstance(mods[0], torch.nn.Conv2d) or not isinstance(mods[1], _BatchNorm):
+        return None
+    conv, bn = mods
+    if bn.training or bn.running_mean is None or bn.running_var is None:
+        return None
+    try:
+        kind = _classify(conv, False)[0]
+    except NotImplementedError:
+        return None
+    raw = x.raw if isinstance(x, Deferred) else x
+    if (kind != 'pw' or raw.dim() != 4 or raw.dtype != torch.bfloat16 or raw.shape[1] != conv.in_channels
+            or conv.in_channels % 8 or conv.in_channels > 768 or conv.out_channels % 8 or conv.weight.dtype != torch.float32):
+        return None
+    B, _, H, W = raw.shape
+    Cout, P = conv.out_channels, B * H * W
+    if residual is not None:
+        residual = to_nhwc(materialize(residual))
+        if tuple(residual.shape) != (B, Cout, H, W) or residual.dtype != raw.dtype:
+            return None
+    d = as_deferred(x).take()
+    dev, st = raw.device, stream()
+    gamma, beta = _f32(bn.weight), _f32(bn.bias)
+    link = BNLink(Cout, P, False, gamma, beta, dev, slabs=False)
+    _finalize_forward(link, bn, False, P, Cout, gamma, st)
+    y = new_nhwc(B, Cout, H, W, raw.dtype, dev)
+    call('tss_pwconv_fwd_joined', ptr(d.raw), ld(d.raw), *_aff(d.link), int(d.relu), ptr(conv.weight), _shadow(conv.weight, 0),
+         ptr(_f32(conv.bias)), ptr(link.mean), ptr(link.scale), ptr(beta), ptr(residual), ld(residual) if residual is not None else 0,
+         int(bool(relu)), ptr(y), ld(y), P, conv.in_channels, Cout, N.dtype_code(raw.dtype), st)
+    return y
+
+
 def _f32(p):
     if p is None or p.dtype == torch.float32:
         return p
