@@ -252,6 +252,15 @@ int tss_dwconv3x3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
  * gradient of that tensor, radd (bf16 [P][K], pitch ldr), is added in the epilogue instead of by an elementwise launch:
  * e_in = g W + radd.  Lean bf16 path only (tss_pwconv_bwd_data_radd_supported); no producer mask / statistics (input materialised). */
 int tss_pwconv_bwd_data_radd_supported(long P, int K, int N, int dtype);
+/* ... and for a layer whose materialised input is the OUTPUT of a relu join (a block output, relu(BN(join_y) + skip), TSS/models/
+ * fastscnn.py:158-161): that join's backward runs in this launch's epilogue -- e_in = (g W + radd) where join_out > 0, else 0, and
+ * join_bstats = slab rows of sum(e_in), sum(e_in * (join_y - join_mean)).  radd optional.  Only valid when e_in is the COMPLETE
+ * gradient of the join's output; tss_join_bwd on the summed gradient stays the exact fallback. */
+int tss_pwconv_bwd_data_joined(const void* e, long lde, const void* yraw, long ldyr,
+                               const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
+                               void* e_in, long ldei, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
+                               const void* radd, long ldr, const void* join_out, long ldjo, const void* join_y, long ldjy,
+                               const float* join_mean, double* join_bstats, long P, int K, int N, int dtype, void* stream);
 int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldyr,
                              const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
                              void* e_in, long ldei, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,

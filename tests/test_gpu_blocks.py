@@ -584,3 +584,58 @@ def test_eval_block_output_written_by_conv3_epilogue(family, cin, cout, stride, 
     e1 = ((y1 - ref).norm() / ref.norm()).item()
     e0 = ((y0 - ref).norm() / ref.norm()).item()
     assert e1 < 1e-2 and e1 < 1.2 * e0 + 1e-3, (e1, e0)       # (the epilogue form skips one bf16 rounding of the conv output)
+
+
+@pytest.mark.parametrize('family', ['fastscnn', 'contextnet'])
+@pytest.mark.parametrize('extra_consumer', [False, True])
+def test_join_backward_rides_in_the_next_layers_backward_data_launch(family, extra_consumer):
+    """Three bottleneck blocks in a row (bf16, training): the backward of a block output's join -- ReLU mask + BatchNorm-backward sums --
+    runs in the epilogue of the next block's first backward-data launch (tss_pwconv_bwd_data_joined) instead of tss_join_bwd.  Same
+    gradients as with the fusion switched off; and when the block output has ANOTHER consumer (deep supervision: a hook feeds it to an
+    auxiliary head), autograd hands the join a summed gradient and its own kernel runs on it -- the fallback is exact."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    M = importlib.import_module('torch_semantic_segmentation_amd.models.' + family)
+    counts = {}
+
+    def run(fused):
+        torch.manual_seed(61)
+        blocks = [M.BottleneckBlock(32, 48, stride=2, expansion=6), M.BottleneckBlock(48, 48, expansion=6),
+                  M.BottleneckBlock(48, 48, expansion=6)]
+        m = torch.nn.Sequential(*blocks).to(DEV)
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        m.train()
+        x = ops.to_nhwc(torch.randn(3, 32, 40, 56, device=DEV).to(torch.bfloat16)).requires_grad_(True)
+        old, orig = ops.fuse_join_backward, ops.call
+        names = []
+
+        def spy(name, *a):
+            names.append(name)
+            return orig(name, *a)
+        ops.fuse_join_backward, ops.call = fused, spy
+        try:
+            h = x
+            aux = 0.0
+            for i, blk in enumerate(m):
+                h = blk(h)
+                if extra_consumer and i == 0:
+                    aux = h.float().mean() * 3.0           # a second consumer of the first block's output
+            torch.manual_seed(67)
+            ((h.float() * torch.randn_like(h, dtype=torch.float32)).sum() + aux).backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.fuse_join_backward, ops.call = old, orig
+        counts[fused] = (names.count('tss_join_bwd'), names.count('tss_pwconv_bwd_data_joined'))
+        return x.grad.float(), {k: p.grad.float() for k, p in m.named_parameters()}
+    dx1, g1 = run(True)
+    dx0, g0 = run(False)
+    assert counts[False] == (3, 0)
+    # blocks 0 and 1 feed an expand convolution; the last block's output feeds the loss
+    assert counts[True] == ((2, 2) if extra_consumer else (1, 2)), counts
+    def l2(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert l2(dx1, dx0) < 5e-3
+    for k in g0:
+        if g0[k].norm() > 1e-3:
+            assert l2(g1[k], g0[k]) < 5e-3, k

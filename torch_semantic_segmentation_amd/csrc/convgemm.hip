@@ -519,7 +519,9 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw, long red_P, int red_K, int red_N,
-                         long P, int K, int N, hipStream_t stream, const void* radd = nullptr, long ldr = 0);  // pwfast.hip
+                         long P, int K, int N, hipStream_t stream, const void* radd = nullptr, long ldr = 0,
+                         const void* jout = nullptr, long ldjo = 0, const void* jy = nullptr, long ldjy = 0,
+                         const float* jmean = nullptr, double* jstats = nullptr);  // pwfast.hip
 void tss_wg_reduce_standalone(const float* ws, float* dw, long P, int K, int N, hipStream_t stream);  // wgrad.hip
 bool tss_conv3x3_wstat_fwd(const void* x, long ldx, const float* in_scale, int in_relu, const void* w9, void* y, long ldy,
                            double* stats, int B, int H, int W, int Cin, int N, int stride, int dil, hipStream_t stream);
@@ -606,6 +608,31 @@ int tss_pwconv_bwd_data_radd(const void* e, long lde, const void* yraw, long ldy
                            e_in, ldei, nullptr, wg_ws, wg_dw, wg_P, wg_K, wg_N, P, K, N, (hipStream_t)stream, radd, ldr))
     return TSS_ERR_SHAPE;
   return tss::check_last("pwfast_bwd_data_radd");
+}
+
+// tss_pwconv_bwd_data_radd (radd optional here) for a layer whose materialised input is the output of a relu join (a block output):
+// the backward of THAT join runs in this launch's epilogue -- e_in = (g W + radd) masked by join_out > 0, and join_bstats receives the
+// slab rows of sum(e_in), sum(e_in * (join_y - join_mean)) for the BatchNorm behind join_y.  Valid only when e_in is the complete
+// gradient of that join's output (the caller checks; the join's own backward kernel remains the fallback).
+int tss_pwconv_bwd_data_joined(const void* e, long lde, const void* yraw, long ldyr,
+                               const float* ga, const float* gb, const float* gce, const float* gmu, const float* w, const void* wT_bf16,
+                               void* e_in, long ldei, const float* wg_ws, float* wg_dw, long wg_P, int wg_K, int wg_N,
+                               const void* radd, long ldr, const void* join_out, long ldjo, const void* join_y, long ldjy,
+                               const float* join_mean, double* join_bstats, long P, int K, int N, int dtype, void* stream) {
+  TSS_REQUIRE(tss_pwconv_bwd_data_radd_supported(P, K, N, dtype) && yraw && join_out && join_y && join_bstats, TSS_ERR_SHAPE);
+  if (wg_P <= 0) { wg_P = P; wg_K = K; wg_N = N; }
+  TSS_REQUIRE(!(wg_ws && wg_dw) || (wg_K > 0 && wg_N > 0 && (wg_K % 8) == 0 && (wg_N % 8) == 0), TSS_ERR_SHAPE);
+  TSS_REQUIRE((lde % 8) == 0 && lde >= N && (ldyr % 8) == 0 && ldyr >= N && (ldei % 4) == 0 && ldei >= K
+              && (!radd || ((ldr % 4) == 0 && ldr >= K)) && (ldjo % 4) == 0 && ldjo >= K && (ldjy % 4) == 0 && ldjy >= K, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(e_in) && tss::aligned16(w) && (!radd || ((uintptr_t)radd & 7u) == 0)
+              && ((uintptr_t)join_out & 7u) == 0 && ((uintptr_t)join_y & 7u) == 0, TSS_ERR_ALIGN);
+  const double bytes = (double)P * (N * 2 + K * (radd ? 4 : 3)) * 2.0;
+  tss::ProfScope prof(TSS_K_PWCONV_BWD_DATA, (hipStream_t)stream, bytes, 2.0 * (double)P * K * N);
+  if (!tss_pwfast_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, wT_bf16, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                           e_in, ldei, nullptr, wg_ws, wg_dw, wg_P, wg_K, wg_N, P, K, N, (hipStream_t)stream, radd, ldr,
+                           join_out, ldjo, join_y, ldjy, join_mean, join_bstats))
+    return TSS_ERR_SHAPE;
+  return tss::check_last("pwfast_bwd_data_joined");
 }
 
 int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

@@ -55,6 +55,10 @@ struct FastArgs {
   // applied in the epilogue -- y = relu?((acc + bias - emean) * escale + ebeta + radd) -- so the block output is written by the layer
   // itself and no join pass exists (escale == NULL: plain output).  radd / ldr as in backward.
   const float* emean; const float* escale; const float* ebeta; int erelu;
+  // backward, materialised input that is the OUTPUT of a relu join (the previous block's relu(BN(y3) + skip)): that join's backward --
+  // ReLU mask from its output jout, the BatchNorm-backward sums of e and e * (jy - jmean) as slab rows in `stats` -- runs in this
+  // epilogue, on the complete gradient (acc + radd), instead of in a pass of its own (ops.JoinFn.backward then only forwards e_in)
+  const T* jout; long ldjo; const T* jy; long ldjy; const float* jmean;
 };
 
 __device__ __forceinline__ float bits_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
@@ -137,8 +141,9 @@ __device__ __forceinline__ void stage_weights_bf16(T* Ws, const T* wb, long ldwb
 // TM = pixels per tile.  Forward: 128.  Backward-data: 64 -- it stages two tensors (e, y) and needs the producer's raw
 // output in the epilogue; with 128-pixel tiles those registers leave no room to keep the next tile's loads in flight
 // (an attempt spilled 188 B/lane and lost), with 64-pixel tiles everything is prefetched and nothing spills.
-template <bool BWD, int TM, bool DROP = false>
+template <bool BWD, int TM, bool DROP = false, bool JB = false>
 __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
+  static_assert(!JB || BWD, "the join-backward epilogue belongs to backward-data");
   static_assert(!(BWD && DROP), "dropout on load is a forward prologue");
   constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
   constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
@@ -179,8 +184,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     const int n = n0 + tid;
     const bool in = n < g.N;
     const int nn = in ? n : 0;
-    const bool hm = BWD ? (g.xm && g.mm) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
-    const float e0 = (hm ? (BWD ? g.mm : g.bias) : g.w)[hm ? nn : 0];
+    const bool hj = JB && !g.xm && g.jout && g.jmean;
+    const bool hm = BWD ? ((g.xm && g.mm) || hj) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
+    const float e0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
     const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
     const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
     Ec[tid] = (in && hm) ? e0 : 0.f;
@@ -426,10 +432,22 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
               }
               bf16x4 o;
+              if (JB && g.jout) {     // the backward of the join that produced this layer's input
+                const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
+                const uint2 ov = *reinterpret_cast<const uint2*>(g.jout + pr * g.ldjo + nlane + i * 16);
+                const uint2 yv = *reinterpret_cast<const uint2*>(g.jy + pr * g.ldjy + nlane + i * 16);
+                const float oo[4] = {bits_lo(ov.x), bits_hi(ov.x), bits_lo(ov.y), bits_hi(ov.y)};
+                const float yc[4] = {bits_lo(yv.x) - cmm[0], bits_hi(yv.x) - cmm[1], bits_lo(yv.y) - cmm[2], bits_hi(yv.y) - cmm[3]};
 #pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+                for (int q = 0; q < 4; ++q) o[q] = (T)(oo[q] > 0.f ? v[q] : 0.f);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+                for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * yc[q]; }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+              }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             }
           }
@@ -486,8 +504,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 constexpr int KTOT = 768;
 // TM = pixels per tile: 128, or 64 when a layer has fewer than 256 tiles of 128 (the 1/32-resolution project / expand
 // layers: 128 blocks of 128 pixels left half the CUs idle behind a five-chunk serial chain).
-template <bool BWD, int TM>
+template <bool BWD, int TM, bool JB = false>
 __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
+  static_assert(!JB || BWD, "the join-backward epilogue belongs to backward-data");
   constexpr int MF = TM / 32;    // 16-pixel MFMA fragments per wave (two waves split the tile's pixels)
   constexpr int NP = TM / 16;    // staging passes (>= 16 rows per pass)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -525,8 +544,9 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
     const int n = n0 + tid;
     const bool in = n < g.N;
     const int nn = in ? n : 0;
-    const bool hm = BWD ? (g.xm && g.mm) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
-    const float e0 = (hm ? (BWD ? g.mm : g.bias) : g.w)[hm ? nn : 0];
+    const bool hj = JB && !g.xm && g.jout && g.jmean;
+    const bool hm = BWD ? ((g.xm && g.mm) || hj) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
+    const float e0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
     const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
     const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
     Ec[tid] = (in && hm) ? e0 : 0.f;
@@ -710,10 +730,22 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
               }
               bf16x4 o;
+              if (JB && g.jout) {     // the backward of the join that produced this layer's input
+                const long pr = p0 + wm * (TM / 2) + m * 16 + fr;
+                const uint2 ov = *reinterpret_cast<const uint2*>(g.jout + pr * g.ldjo + nlane + i * 16);
+                const uint2 yv = *reinterpret_cast<const uint2*>(g.jy + pr * g.ldjy + nlane + i * 16);
+                const float oo[4] = {bits_lo(ov.x), bits_hi(ov.x), bits_lo(ov.y), bits_hi(ov.y)};
+                const float yc[4] = {bits_lo(yv.x) - cmm[0], bits_hi(yv.x) - cmm[1], bits_lo(yv.y) - cmm[2], bits_hi(yv.y) - cmm[3]};
 #pragma unroll
-              for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+                for (int q = 0; q < 4; ++q) o[q] = (T)(oo[q] > 0.f ? v[q] : 0.f);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+                for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * yc[q]; }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (T)v[q];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float rq = (float)o[q]; st1[i][q] += rq; st2[i][q] += rq * rq; }
+              }
               *reinterpret_cast<bf16x4*>(yrow + (long)m * 16 * g.ldy + i * 16) = o;
             }
           }
@@ -750,7 +782,7 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   }
 }
 
-template <bool BWD, int TM>
+template <bool BWD, int TM, bool JB = false>
 void launch_fast_mc_tm(FastArgs& g, hipStream_t stream) {
   constexpr size_t smem = (size_t)(TM + NCH) * RS * sizeof(T) + 3 * KTOT * sizeof(float) + 3 * NCH * sizeof(float);
   const int nchunks = (g.N + NCH - 1) / NCH;
@@ -763,23 +795,23 @@ void launch_fast_mc_tm(FastArgs& g, hipStream_t stream) {
   const int grid = 8 * nchunks * (int)gs + g.nred8;
   static tss::DevOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_mc_kernel<BWD, TM, JB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  hipLaunchKernelGGL((pwfast_mc_kernel<BWD, TM>), dim3(grid), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL((pwfast_mc_kernel<BWD, TM, JB>), dim3(grid), dim3(NT), smem, stream, g);
 }
 
-template <bool BWD>
+template <bool BWD, bool JB = false>
 void launch_fast_mc(FastArgs& g, hipStream_t stream) {
   const int nchunks = (g.N + NCH - 1) / NCH;
   // fewer than 256 block-tiles of 128 pixels: halve the tile so that every CU gets a block
   const long t128 = (g.P + BM - 1) / BM * nchunks;
   static const long thr32 = getenv("TSS_PW_MC_SMALL") ? atol(getenv("TSS_PW_MC_SMALL")) : 192;
-  if (t128 < thr32) launch_fast_mc_tm<BWD, 32>(g, stream);
-  else if (t128 < 256) launch_fast_mc_tm<BWD, 64>(g, stream);
-  else launch_fast_mc_tm<BWD, BM>(g, stream);
+  if (t128 < thr32) launch_fast_mc_tm<BWD, 32, JB>(g, stream);
+  else if (t128 < 256) launch_fast_mc_tm<BWD, 64, JB>(g, stream);
+  else launch_fast_mc_tm<BWD, BM, JB>(g, stream);
 }
 
-template <bool BWD, int TM, bool DROP = false>
+template <bool BWD, int TM, bool DROP = false, bool JB = false>
 void launch_fast(FastArgs& g, hipStream_t stream) {
   constexpr size_t smem = (size_t)(TM + NCH) * RS * sizeof(T) + 3 * NCH * sizeof(float);
   const int nchunks = (g.N + NCH - 1) / NCH;
@@ -793,9 +825,9 @@ void launch_fast(FastArgs& g, hipStream_t stream) {
   const int grid = 8 * nchunks * (int)gs + g.nred8;
   static tss::DevOnce attr;
   if (attr.first()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pwfast_kernel<BWD, TM, DROP, JB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   }
-  hipLaunchKernelGGL((pwfast_kernel<BWD, TM, DROP>), dim3(grid), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL((pwfast_kernel<BWD, TM, DROP, JB>), dim3(grid), dim3(NT), smem, stream, g);
 }
 
 }  // namespace
@@ -915,9 +947,11 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gce, const float* gmu, const float* w, const void* wT_bf16, const void* xraw, long ldx,
                          const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                          void* e_in, long ldei, double* bstats, const float* red_ws, float* red_dw, long red_P, int red_K, int red_N,
-                         long P, int K, int N, hipStream_t stream, const void* radd, long ldr) {
+                         long P, int K, int N, hipStream_t stream, const void* radd, long ldr,
+                         const void* jout, long ldjo, const void* jy, long ldjy, const float* jmean, double* jstats) {
   if (g_tss_disable_fast || !yraw || N > KTOT || (N % 8) != 0 || (K % 4) != 0 || P <= 0) return false;
   if (radd && (xraw || (ldr % 4) != 0 || ldr < K)) return false;     // the add is only folded into the unmasked epilogue
+  if (jout && (xraw || !jy || !jstats || (ldjo % 4) != 0 || ldjo < K || (ldjy % 4) != 0 || ldjy < K)) return false;
   FastArgs g = {};
   if (red_ws && red_dw) {   // weight-gradient slots (of this layer or of one further up the backward pass) are summed by the first blocks of this launch
     g.red = tss_wg::reduce_args(red_ws, red_dw, red_P, red_K, red_N);
@@ -929,10 +963,13 @@ bool tss_pwfast_bwd_data(const void* e, long lde, const void* yraw, long ldyr, c
   if (wT_bf16 && tss::aligned16(wT_bf16)) { g.wb = (const T*)wT_bf16; g.ldwb = N; }   // transpose [conv K][conv N]: rows of N contraction channels
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   g.radd = (const T*)radd; g.ldr = ldr;
+  if (jout) { g.jout = (const T*)jout; g.ldjo = ldjo; g.jy = (const T*)jy; g.ldjy = ldjy; g.jmean = jmean; g.stats = jstats; }
   if (N <= KMAX) {
     static const long thr = getenv("TSS_PW_BWD_SMALL") ? atol(getenv("TSS_PW_BWD_SMALL")) : 4200;   // 32-pixel tiles, as above
     const long t64 = (P + 63) / 64 * ((K + NCH - 1) / NCH);
-    if (t64 < thr) launch_fast<true, 32>(g, stream); else launch_fast<true, 64>(g, stream);
-  } else launch_fast_mc<true>(g, stream);
+    if (jout) { if (t64 < thr) launch_fast<true, 32, false, true>(g, stream); else launch_fast<true, 64, false, true>(g, stream); }
+    else if (t64 < thr) launch_fast<true, 32>(g, stream); else launch_fast<true, 64>(g, stream);
+  } else if (jout) launch_fast_mc<true, true>(g, stream);
+  else launch_fast_mc<true>(g, stream);
   return true;
 }

@@ -208,10 +208,10 @@ _pending_forks = {}
 
 
 class _Fork:
-    __slots__ = ('g2', 'consumed')
+    __slots__ = ('g2', 'consumed', 'prev_join')
 
     def __init__(self):
-        self.g2, self.consumed = None, False
+        self.g2, self.consumed, self.prev_join = None, False, None
 
 
 class ForkFn(Function):
@@ -241,9 +241,29 @@ def residual_fork(x):
             and x.dtype == torch.bfloat16 and not N.fast_paths_disabled()):
         return x, x, None
     fork = _Fork()
+    fork.prev_join = _take_join(x)         # x is a block output: its join's backward can ride in the first layer's backward-data launch
     xa, xb = ForkFn.apply(x, fork)
     _pending_forks[id(xa)] = fork          # picked up by the first conv unit that consumes xa (conv_unit)
     return xa, xb, fork
+
+
+# A relu join whose output feeds a 1x1 layer (block output -> the next block's expand conv): the join's backward (ReLU mask of its
+# output + the BatchNorm-backward sums) can run in the epilogue of that layer's backward-data launch (tss_pwconv_bwd_data_joined).
+# join() registers its configuration here, keyed by the output tensor; the consuming conv unit picks it up.
+fuse_join_backward = os.environ.get('TSS_FUSE_JOIN_BWD', '1') != '0'
+# ... for block outputs up to this many elements: the two extra loads of the epilogue drain the next tile's prefetch, which costs a long
+# layer more than the join launch it saves (262 k pixels x 64 channels: +48 us against a 28 us join; 65 k x 64: +10 against 14;
+# 16 k x 96-128: +2 against 9)
+fuse_join_backward_max = int(os.environ.get('TSS_FUSE_JOIN_BWD_MAX', '4000000'))
+_join_ctx = {}
+
+
+def _take_join(x):
+    if not _join_ctx or not torch.is_tensor(x):
+        return None
+    ref = _join_ctx.pop(id(x), None)
+    cfg = ref() if ref is not None else None
+    return cfg if (cfg is not None and cfg.j_ptr == x.data_ptr()) else None
 
 
 _pending_stash = {}
@@ -652,7 +672,7 @@ def materialize(d, relu_override=None):
 
 class UnitCfg:
     __slots__ = ('kind', 'stride', 'dil', 'in_link', 'in_relu', 'bn', 'training', 'out_dtype', 'out_link',
-                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped', 'kh', 'kw', 'drop_p')
+                 'image_f32', 'cin', 'cout', 'params', 'res_fork', 'stash_fork', 'overlapped', 'kh', 'kw', 'drop_p', 'prev_join')
 
 
 def _classify(conv, x_is_image):
@@ -742,7 +762,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_K
         cfg.in_link, cfg.in_relu = None, False
         cfg.image_f32 = x_raw.dtype == torch.float32
         cfg.out_dtype = out_dtype or x_raw.dtype
-        cfg.res_fork = cfg.stash_fork = None
+        cfg.res_fork = cfg.stash_fork = cfg.prev_join = None
     else:
         d = as_deferred(x).take()
         x_raw = d.raw
@@ -751,6 +771,7 @@ def conv_unit(x, conv, bn=None, relu=False, out_dtype=None, weight=None, bias=_K
         cfg.out_dtype = x_raw.dtype
         cfg.res_fork = _pending_forks.pop(id(x_raw), None) if _pending_forks else None
         cfg.stash_fork = _pending_stash.pop(id(x_raw), None) if _pending_stash else None
+        cfg.prev_join = cfg.res_fork.prev_join if cfg.res_fork is not None else (_take_join(x_raw) if d.link is None and not d.relu else None)
     if x_raw.shape[1] != conv.in_channels:
         raise RuntimeError('expected %d input channels, got %d' % (conv.in_channels, x_raw.shape[1]))
     cfg.bn = bn
@@ -1161,8 +1182,22 @@ class ConvUnitFn(Function):
                         red, hold = _take_red(dev)
                     else:
                         red, hold = ((ptr(ws), ptr(dw), 0, 0, 0) if defer else (None, None, 0, 0, 0)), None
-                    if (radd is not None and not deferred_in and y is not None and e.dtype == torch.bfloat16 and radd.dtype == e.dtype
-                            and tuple(radd.shape) == tuple(e_in.shape) and N.lib().tss_pwconv_bwd_data_radd_supported(P, Cin, Cout, dt)):
+                    radd_ok = (radd is not None and not deferred_in and y is not None and e.dtype == torch.bfloat16 and radd.dtype == e.dtype
+                               and tuple(radd.shape) == tuple(e_in.shape) and N.lib().tss_pwconv_bwd_data_radd_supported(P, Cin, Cout, dt))
+                    pj = getattr(cfg, 'prev_join', None)
+                    if (pj is not None and (radd is None or radd_ok) and not deferred_in and y is not None and e.dtype == torch.bfloat16
+                            and P * Cin <= fuse_join_backward_max
+                            and pj.j_a is not None and pj.j_ptr == x.data_ptr() and tuple(pj.j_a.shape) == tuple(x.shape)
+                            and is_nhwc(pj.j_a) and N.lib().tss_pwconv_bwd_data_radd_supported(P, Cin, Cout, dt)):
+                        # this layer's input is a block output: that join's backward (ReLU mask + BatchNorm-backward sums) in the epilogue
+                        jl = pj.a_link
+                        call('tss_pwconv_bwd_data_joined', *gargs, ptr(weight), _shadow(weight, 1), ptr(e_in), ld(e_in), *red,
+                             ptr(radd), ld(radd) if radd is not None else 0, ptr(x), ld(x), ptr(pj.j_a), ld(pj.j_a), ptr(jl.mean),
+                             ptr(jl.bstats), P, Cin, Cout, dt, st)
+                        pj.fused_e = e_in
+                        if radd is not None:
+                            fork.consumed = True
+                    elif radd_ok:
                         call('tss_pwconv_bwd_data_radd', *gargs, ptr(weight), _shadow(weight, 1), ptr(e_in), ld(e_in),
                              *red, ptr(radd), ld(radd), P, Cin, Cout, dt, st)
                         fork.consumed = True
@@ -1246,7 +1281,7 @@ class ConvUnitFn(Function):
 # ----------------------------------------------------------------------------- join (materialise / add / relu)
 
 class JoinCfg:
-    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus', 'drop_p', 'res_fork')
+    __slots__ = ('a_link', 'b_link', 'relu', 'links', 'relus', 'drop_p', 'res_fork', 'j_a', 'j_ptr', 'fused_e', '__weakref__')
 
 
 def join(a, b=None, relu=False, dropout_p=0.0, fork=None):
@@ -1271,7 +1306,16 @@ def join(a, b=None, relu=False, dropout_p=0.0, fork=None):
             raise RuntimeError('join: operands differ in shape/dtype: %s vs %s' % (a.raw.shape, b.raw.shape))
         braw, cfg.b_link = b.raw, b.link
     cfg.res_fork = fork if b is not None else None
-    return JoinFn.apply(a.raw, braw, cfg)
+    cfg.j_a = cfg.j_ptr = cfg.fused_e = None
+    out = JoinFn.apply(a.raw, braw, cfg)
+    if (fuse_join_backward and cfg.relu and not cfg.drop_p and cfg.a_link is not None and cfg.b_link is None and out.requires_grad
+            and out.dtype == torch.bfloat16 and not N.fast_paths_disabled()):
+        import weakref
+        cfg.j_a, cfg.j_ptr = a.raw, out.data_ptr()
+        if len(_join_ctx) > 256:          # outputs nobody picked up (consumed by something other than a conv unit)
+            _join_ctx.clear()
+        _join_ctx[id(out)] = weakref.ref(cfg)
+    return out
 
 
 class JoinFn(Function):
@@ -1295,6 +1339,17 @@ class JoinFn(Function):
     def backward(ctx, dout):
         cfg = ctx.cfg
         a, b, out = ctx.saved_tensors
+        fe = getattr(cfg, 'fused_e', None)
+        cfg.fused_e = None
+        if (fe is not None and dout.data_ptr() == fe.data_ptr() and dout.shape == fe.shape and dout.dtype == fe.dtype
+                and dout.stride() == fe.stride()):
+            # the consumer's backward-data launch already did this join's backward on the complete gradient (mask + slab rows written):
+            # dout IS e.  (Any other gradient of `out` would have made autograd hand us a different, summed tensor.)
+            fork = getattr(cfg, 'res_fork', None)
+            if fork is not None and ctx.has_b:
+                fork.g2 = dout
+            return dout, (dout if ctx.has_b else None), None
+        del fe
         dout = to_nhwc(dout)
         al, bl = cfg.a_link, cfg.b_link
         e = new_nhwc(*dout.shape, dout.dtype, dout.device) if cfg.relu else None
