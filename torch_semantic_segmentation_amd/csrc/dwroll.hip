@@ -273,7 +273,9 @@ __global__ __launch_bounds__(NT, 2) void dw_fwd_roll_kernel(const RollArgs g) {
         s1[j] += acc[j];
         s2[j] += acc[j] * acc[j];
       }
-      V8<bf16_t>::store(g.y + (((long)c.b * g.Hout + orow) * g.Wout + c.x0 + p) * g.ldy + c0, acc);
+      // (row base: wave-uniform 64-bit arithmetic on the scalar unit; the lane adds a 32-bit offset -- the whole address as one 64-bit
+      //  vector expression was ~10 vector instructions per emitted row)
+      V8<bf16_t>::store(g.y + ((long)c.b * g.Hout + orow) * g.Wout * g.ldy + ((c.x0 + p) * (int)g.ldy + c0), acc);
     }
   };
   auto compute = [&](const Cursor& c, int slot) {
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[j] = accA[j];
           }
-          V4<bf16_t>::store(g.ein + (((long)cc.b * g.H + q) * g.W + cc.x0 + p) * g.ldei + c0, out);
+          V4<bf16_t>::store(g.ein + ((long)cc.b * g.H + q) * g.W * g.ldei + ((cc.x0 + p) * (int)g.ldei + c0), out);
         }
         // weight gradient over the rows this unit owns (idx = 1 .. RS for row r, 2 .. RS + 1 for row r - 1)
         const bool own_cur = idx >= 1 && idx <= g.RS;
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s2_kernel(const RollBwdArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[j] = acc[j];
       }
-      V4<bf16_t>::store(g.ein + (((long)c.b * g.H + q) * g.W + px) * g.ldei + c0, out);
+      V4<bf16_t>::store(g.ein + ((long)c.b * g.H + q) * g.W * g.ldei + (px * (int)g.ldei + c0), out);
     }
   };
 

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NT, 2) void updw_fwd_kernel(const UpDwArgs g) {
         const float rq = (float)o[j];
         s1[j] += rq; s2[j] += rq * rq;
       }
-      *reinterpret_cast<bf16x8*>(g.y + (((long)b * g.Ho + r) * g.Wo + col) * g.ldy + c0) = o;
+      *reinterpret_cast<bf16x8*>(g.y + ((long)b * g.Ho + r) * g.Wo * g.ldy + (col * (int)g.ldy + c0)) = o;
     }
   };
 
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NT, 2) void updw_bwd_kernel(const UpDwArgs g) {
   }
   if (wk.je > wk.js) { lerp(wk.js - 1, X[0]); lerp(wk.js, X[1]); }
   auto emit = [&](int r, const float (&acc)[4]) {
-    if (col_on) V4<bf16_t>::store(g.eup + (((long)b * g.Ho + r) * g.Wo + col) * g.ldeu + c0, acc);
+    if (col_on) V4<bf16_t>::store(g.eup + ((long)b * g.Ho + r) * g.Wo * g.ldeu + (col * (int)g.ldeu + c0), acc);
   };
 
   for (int jb = wk.js; jb < wk.je; jb += UR) {
