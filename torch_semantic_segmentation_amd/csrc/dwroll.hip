@@ -672,14 +672,15 @@ __global__ __launch_bounds__(NT, 2) void dw_bwd_roll_s1_kernel(const RollBwdArgs
         const bool own_cur = idx >= 1 && idx <= g.RS;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float gc = own_cur ? G[1][j] : 0.f, gp = prev_owned ? gprev[j] : 0.f;
+          // (gprev is stored already zeroed outside the owned rows: "previous row owned" now == "current row owned" one step ago)
+          const float gc = own_cur ? G[1][j] : 0.f, gp = gprev[j];
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) {
             dwa[6 + kx][j] += gp * A[kx][j];          // o = r - 1, tap row 2: a[o + 1]
             dwa[3 + kx][j] += gc * A[kx][j];          // o = r,     tap row 1
             dwa[0 + kx][j] += gc * aprev[kx][j];      // o = r,     tap row 0: a[o - 1]
           }
-          gprev[j] = G[1][j];
+          gprev[j] = gc;
 #pragma unroll
           for (int kx = 0; kx < 3; ++kx) aprev[kx][j] = A[kx][j];
           accA[j] = accB[j]; accB[j] = accC[j];
