@@ -434,7 +434,9 @@ __global__ __launch_bounds__(NT, 2) void updw_bwd_kernel(const UpDwArgs g) {
   }
 }
 
-constexpr int FWD_TILE_BYTES = 56 * 1024, BWD_TILE_BYTES = 36 * 1024;
+// forward: 40 KB (two row segments per class at the benchmark's size, three blocks per CU: 55 us) is preferred over 56 KB (one segment, two
+// blocks per CU: 57 us), which remains the fallback when the segments would exceed the 512 statistics slab rows (larger batches)
+constexpr int FWD_TILE_BYTES = 40 * 1024, FWD_TILE_MAX = 56 * 1024, BWD_TILE_BYTES = 36 * 1024;
 constexpr int BWD_MAX_UNITS = 8192;        // workspace rows of the weight gradient (the forward's units are slab rows: <= 512)
 constexpr int FWD_FIXED_BYTES = 2 * (FPX + 2 * MAXD) * 64 * 2, BWD_FIXED_BYTES = 2 * (BPX + 2 * MAXD) * 16 * 16;
 
@@ -467,7 +469,8 @@ bool shape_ok(int B, int Hs, int Ws, int Ho, int Wo, int C, int D, int dtype) {
   UpDwArgs g = {};
   g.Hs = Hs; g.Ws = Ws; g.B = B; g.Ho = Ho; g.Wo = Wo; g.C = C; g.D = D;
   UpDwArgs h = g;
-  return geometry(g, FPX, D, FWD_TILE_BYTES, TSS_STAT_SLABS) && geometry(h, BPX, 0, BWD_TILE_BYTES, BWD_MAX_UNITS);
+  return (geometry(g, FPX, D, FWD_TILE_BYTES, TSS_STAT_SLABS) || geometry(g, FPX, D, FWD_TILE_MAX, TSS_STAT_SLABS))
+         && geometry(h, BPX, 0, BWD_TILE_BYTES, BWD_MAX_UNITS);
 }
 
 }  // namespace
@@ -496,12 +499,15 @@ int tss_updw_fwd(const void* x, long ldx, int Hs, int Ws, const float* w, void* 
   UpDwArgs g = {};
   g.x = (const bf16_t*)x; g.ldx = ldx; g.Hs = Hs; g.Ws = Ws; g.w = w; g.y = (bf16_t*)y; g.ldy = ldy; g.stats = stats;
   g.B = B; g.Ho = Ho; g.Wo = Wo; g.C = C; g.D = dil;
-  TSS_REQUIRE(geometry(g, FPX, dil, FWD_TILE_BYTES, TSS_STAT_SLABS), TSS_ERR_SHAPE);
+  // A/B: TSS_UPDW_FWD_TILE=<bytes> -- a smaller source tile means more row segments (more, shorter blocks) and a third block per CU
+  static const int tile_budget = getenv("TSS_UPDW_FWD_TILE") ? atoi(getenv("TSS_UPDW_FWD_TILE")) : FWD_TILE_BYTES;
+  TSS_REQUIRE(geometry(g, FPX, dil, tile_budget < FWD_TILE_MAX ? tile_budget : FWD_TILE_MAX, TSS_STAT_SLABS)
+              || geometry(g, FPX, dil, FWD_TILE_MAX, TSS_STAT_SLABS), TSS_ERR_SHAPE);
   size_t smem = (size_t)g.tile_vecs * 16 + FWD_FIXED_BYTES;
   if (smem < (size_t)FPX * 2 * 64 * 4) smem = (size_t)FPX * 2 * 64 * 4;          // the statistics reduction aliases it
   static tss::DevOnce attr;
   if (attr.first())
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(updw_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_TILE_BYTES + FWD_FIXED_BYTES + 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(updw_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FWD_TILE_MAX + FWD_FIXED_BYTES + 1024);
   tss::ProfScope prof(TSS_K_DWCONV_FWD, (hipStream_t)stream, ((double)B * Hs * Ws + (double)B * Ho * Wo) * C * 2.0, 0);
   hipLaunchKernelGGL(updw_fwd_kernel, dim3(g.nsl * g.nunits), dim3(NT), smem, (hipStream_t)stream, g);
   return tss::check_last("updw_fwd");
