@@ -58,6 +58,7 @@ overlap_min_elems = int(os.environ.get('TSS_OVERLAP_MIN', '0'))
 # (only for gradients written straight into their final buffer: a gradient RETURNED to autograd must be complete on return)
 batch_dw_reductions = os.environ.get('TSS_BATCH_DW_REDUCE', '1') == '1'
 fuse_pw_backward = os.environ.get('TSS_PW_BWD_FUSED', '1') != '0'     # csrc/pwbwd.hip, for the layers it prefers
+sweep_pw_backward = os.environ.get('TSS_PW_SWEEP', '1') != '0'        # csrc/pwsweep.hip: the large 1x1 layers, one sweep (round 4)
 _pending_dw = []
 
 # Backward-pass scheduling ("launch count"): every dependent launch costs >= 4.7 us in the replayed step, so
@@ -1109,7 +1110,18 @@ class ConvUnitFn(Function):
                 if drop_mask is not None:        # dropout on load: the one sweep is the only backward that knows the mask
                     fused_pw = True
             postponed = False
-            if fused_pw:
+            sweep_pw = False
+            if cfg.kind == 'pw' and not fused_pw:
+                # the large layers (128 -> 128, 64 -> 384, 384 -> 64 with enough pixels): one sweep with the whole weight-gradient tile in
+                # the registers of one 512-thread block per CU (csrc/pwsweep.hip)
+                fork = getattr(cfg, 'res_fork', None)
+                radd_s = fork.g2 if fork is not None else None
+                sweep_pw = bool(sweep_pw_backward and need_dx and side is None and e.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                                and not N.fast_paths_disabled()
+                                and N.lib().tss_pwconv_bwd_sweep_preferred(P, Cin, Cout, int(bool(deferred_in)), dt)
+                                and (radd_s is None or (not deferred_in and radd_s.dtype == e.dtype and tuple(radd_s.shape) == tuple(x.shape)
+                                                        and is_nhwc(radd_s))))
+            if fused_pw or sweep_pw:
                 pass
             elif cfg.kind == 'pw':
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
@@ -1175,6 +1187,23 @@ class ConvUnitFn(Function):
                         _reduce_rows_now(ws, dw, Cout * Cin, rows)
                         if bws is not None:
                             _reduce_rows_now(bws, dbias, Cout, rows)
+                elif sweep_pw:
+                    rows = N.lib().tss_pwconv_bwd_sweep_rows(P, Cin, Cout)
+                    ws = torch.empty((rows, Cout * Cin), dtype=torch.float32, device=dev)
+                    wT = _shadow(weight, 1)
+                    hold_wT = None
+                    if wT is None:          # no current shadow (plain autograd outside a Trainer): a transpose of this call's own
+                        hold_wT = weight.detach().t().contiguous().to(torch.bfloat16)
+                        wT = ptr(hold_wT)
+                    call('tss_pwconv_bwd_sweep', *gargs, wT, *xargs, int(bool(deferred_in)), ptr(radd_s),
+                         ld(radd_s) if radd_s is not None else 0, ptr(e_in), ld(e_in), bst, ptr(ws), P, Cin, Cout, dt, st)
+                    del hold_wT
+                    if radd_s is not None:
+                        fork.consumed = True
+                    if dw_ret is None and batch_dw_reductions:
+                        _defer_dw_reduction(ws, dw, Cout * Cin, rows, p_weight)       # summed with the depthwise rows, at the end of the pass
+                    else:
+                        _reduce_rows_now(ws, dw, Cout * Cin, rows)
                 elif cfg.kind == 'pw':
                     fork = getattr(cfg, 'res_fork', None)
                     radd = fork.g2 if fork is not None else None
