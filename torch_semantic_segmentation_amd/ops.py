@@ -1193,7 +1193,7 @@ class ConvUnitFn(Function):
                     wT = _shadow(weight, 1)
                     hold_wT = None
                     if wT is None:          # no current shadow (plain autograd outside a Trainer): a transpose of this call's own
-                        hold_wT = weight.detach().t().contiguous().to(torch.bfloat16)
+                        hold_wT = weight.detach().reshape(Cout, Cin).t().contiguous().to(torch.bfloat16)
                         wT = ptr(hold_wT)
                     call('tss_pwconv_bwd_sweep', *gargs, wT, *xargs, int(bool(deferred_in)), ptr(radd_s),
                          ld(radd_s) if radd_s is not None else 0, ptr(e_in), ld(e_in), bst, ptr(ws), P, Cin, Cout, dt, st)
