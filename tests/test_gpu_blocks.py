@@ -639,3 +639,147 @@ def test_join_backward_rides_in_the_next_layers_backward_data_launch(family, ext
     for k in g0:
         if g0[k].norm() > 1e-3:
             assert l2(g1[k], g0[k]) < 5e-3, k
+
+
+
+# ----------------------------------------------------------------------------- re-entrant backward passes (round 4)
+
+def _fast_features(seed=41):
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    F_ = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    torch.manual_seed(seed)
+    m = torch.nn.Sequential(F_.Conv2dBlock(32, 32, 1), F_.BottleneckBlock(32, 32), F_.BottleneckBlock(32, 32),
+                            F_.DSConv2dBlock(32, 48, kernel_size=3, padding=1)).to(DEV)
+    m.train()
+    return m
+
+
+def _grads(m):
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+
+
+def _same(a, b):
+    """equal to 1e-6 of the tensor's norm (the f32 parity path sums some weight gradients with f32 atomics: order noise ~1e-7);
+    analytically-zero gradients (a BatchNorm bias in front of a linear conv + BatchNorm) are rounding noise on both sides"""
+    a, b = a.double(), b.double()
+    return bool((a - b).norm() <= 1e-6 * max(float(b.norm()), 1.0))
+
+
+def _run_plain(m, x, cot, direct=True):
+    from torch_semantic_segmentation_amd import ops
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p) if direct else None
+    xx = x.clone().requires_grad_(True)
+    with ops.direct_grads(direct):
+        out = ops.materialize(m(xx))
+        out.backward(cot)
+    torch.cuda.synchronize()
+    return out.detach().clone(), xx.grad.detach().clone(), _grads(m)
+
+
+def test_checkpointed_block_keeps_the_outer_passes_postponed_work():
+    """One BottleneckBlock under torch.utils.checkpoint(use_reentrant=True): its recomputation runs a NESTED backward pass inside the
+    outer one.  The postponed weight gradients / row reductions of the outer pass used to be deleted when the graph-task id changed
+    (ops._backward_task); now every pass owns its state.  All gradients equal the plain run (f32 path: to 1e-6)."""
+    from torch.utils.checkpoint import checkpoint
+    from torch_semantic_segmentation_amd import ops
+    m = _fast_features()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 24, 40, generator=g).to(DEV)
+    cot = torch.randn(2, 48, 24, 40, generator=g).to(DEV)
+    out0, dx0, g0 = _run_plain(m, x, cot)
+
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    xx = x.clone().requires_grad_(True)
+    with ops.direct_grads(True):
+        h = ops.materialize(m[0](xx))
+        h = checkpoint(lambda t: ops.materialize(m[1](t)), h, use_reentrant=True)
+        out = ops.materialize(m[3](m[2](h)))
+        out.backward(cot)
+    torch.cuda.synchronize()
+    assert not ops._passes
+    g1 = _grads(m)
+    assert _same(out, out0)
+    assert _same(xx.grad, dx0)
+    for k in g0:
+        assert _same(g1[k], g0[k]), k
+
+
+def test_autograd_grad_inside_a_backward_hook_does_not_touch_the_outer_pass():
+    """A tensor hook that runs torch.autograd.grad on an unrelated sub-graph of HIP operators while the outer backward pass is in
+    flight: the inner pass completes its own gradients, the outer pass's gradients equal the plain run."""
+    from torch_semantic_segmentation_amd import ops
+    m = _fast_features()
+    side = _fast_features(seed=43)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 32, 24, 40, generator=g).to(DEV)
+    cot = torch.randn(2, 48, 24, 40, generator=g).to(DEV)
+    out0, dx0, g0 = _run_plain(m, x, cot)
+    _, _, gs0 = _run_plain(side, x, cot, direct=False)
+
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    inner = {}
+
+    def hook(grad):
+        # an inner pass over ANOTHER model, gradients returned (not accumulated directly): it must neither flush nor drop what the
+        # outer pass postponed
+        with torch.enable_grad(), ops.direct_grads(False):
+            so = ops.materialize(side(x.clone().requires_grad_(True)))
+            params = list(side.parameters())
+            gs = torch.autograd.grad(so, params, cot)
+        inner.update({k: v.detach().clone() for (k, _), v in zip(side.named_parameters(), gs)})
+        return grad
+    xx = x.clone().requires_grad_(True)
+    with ops.direct_grads(True):
+        h = ops.materialize(m[1](ops.materialize(m[0](xx))))
+        h.register_hook(hook)
+        out = ops.materialize(m[3](m[2](h)))
+        out.backward(cot)
+    torch.cuda.synchronize()
+    assert not ops._passes
+    g1 = _grads(m)
+    assert _same(xx.grad, dx0)
+    for k in g0:
+        assert _same(g1[k], g0[k]), k
+    assert set(inner) == set(gs0)
+    for k in gs0:
+        assert _same(inner[k], gs0[k]), k
+
+
+def test_two_trainers_in_two_threads_do_not_share_scheduling_state():
+    """Two models stepping concurrently from two host threads (each with its own stream): the forward-pass registries are per thread
+    and the backward-pass state per graph task, so both produce the gradients of their single-threaded runs."""
+    import threading
+    from torch_semantic_segmentation_amd import ops
+    g = torch.Generator().manual_seed(7)
+    models = [_fast_features(seed=51), _fast_features(seed=52)]
+    xs = [torch.randn(2, 32, 24, 40, generator=g).to(DEV) for _ in range(2)]
+    cots = [torch.randn(2, 48, 24, 40, generator=g).to(DEV) for _ in range(2)]
+    want = [_run_plain(m, x, c) for m, x, c in zip(models, xs, cots)]
+    got, errs = [None, None], []
+    barrier = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+                barrier.wait()
+                for _ in range(5):
+                    got[i] = _run_plain(models[i], xs[i], cots[i])
+        except Exception as exc:       # noqa: BLE001
+            errs.append(exc)
+    torch.cuda.synchronize()
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert not ops._passes
+    for i in range(2):
+        assert _same(got[i][1], want[i][1])
+        for k in want[i][2]:
+            assert _same(got[i][2][k], want[i][2][k]), (i, k)

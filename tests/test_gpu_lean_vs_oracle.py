@@ -78,6 +78,10 @@ def product_chain(spec):
         act = kw.get('act', True)
         if kind == 'pw':
             blocks.append(F.Conv2dBlock(cin, cout, kernel_size=1, use_activation=act))
+        elif kind == 'up':      # FusedSequential runs it together with the depthwise block behind it (csrc/updw.hip)
+            blocks.append(nn.UpsamplingBilinear2d(size=kw.get('size'), scale_factor=kw.get('scale')))
+        elif kind == 'bneck':
+            blocks.append(F.BottleneckBlock(cin, cout, stride=kw.get('stride', 1), expansion=kw.get('expansion', 6)))
         elif kind == 'dw':
             d = kw.get('dilation', 1)
             blocks.append(F.DWConv2dBlock(cin, cout, kernel_size=3, padding=d, stride=kw.get('stride', 1), dilation=d,
@@ -94,6 +98,10 @@ def oracle_chain(spec):
         act = kw.get('act', True)
         if kind == 'pw':
             blocks.append(O.unit(cin, cout, 1, act=act))
+        elif kind == 'up':
+            blocks.append(nn.UpsamplingBilinear2d(size=kw.get('size'), scale_factor=kw.get('scale')))
+        elif kind == 'bneck':
+            blocks.append(O._FastResidual(cin, cout, stride=kw.get('stride', 1), expansion=kw.get('expansion', 6)))
         elif kind == 'dw':
             blocks.append(O.unit(cin, cout, 3, stride=kw.get('stride', 1), dilation=kw.get('dilation', 1), depthwise=True, act=act))
         else:
@@ -101,8 +109,9 @@ def oracle_chain(spec):
     return nn.Sequential(*blocks)
 
 
-def run_case(spec, shape, seed=0):
-    """-> (oracle f64 results, lean results, general results), each a dict name -> numpy array."""
+def run_case(spec, shape, seed=0, train=True):
+    """-> (oracle f64 results, lean results, general results), each a dict name -> numpy array.
+    train=False: frozen (non-trivial) running statistics on both sides, gradients still taken."""
     import torch_semantic_segmentation_amd as tssa
     from torch_semantic_segmentation_amd import _native as N
     torch.manual_seed(seed)
@@ -114,10 +123,13 @@ def run_case(spec, shape, seed=0):
             if isinstance(m, nn.BatchNorm2d):     # non-trivial affine, f32 on both sides
                 m.weight.uniform_(0.6, 1.4)
                 m.bias.uniform_(-0.3, 0.3)
+                if not train:
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 1.5)
     state = {k: v.clone() for k, v in ref.state_dict().items()}
     g = torch.Generator().manual_seed(seed + 1)
     x = bf16_round_(torch.randn(*shape, generator=g))
-    ref.double().train()
+    ref.double().train(train)
     emulate_bf16_storage(ref)
     xr = x.double().requires_grad_(shape[1] % 8 == 0)
     out_r = ref(xr)
@@ -127,7 +139,7 @@ def run_case(spec, shape, seed=0):
     def noisy(noise_seed):      # the same oracle with the storage format's noise model (oracle/bf16_storage.py, dithered rounding)
         r2 = oracle_chain(spec)
         r2.load_state_dict(state, strict=True)
-        r2.double().train()
+        r2.double().train(train)
         emulate_bf16_storage(r2, dither=torch.Generator().manual_seed(noise_seed))
         x2 = x.double().requires_grad_(shape[1] % 8 == 0)
         o2 = r2(x2)
@@ -152,7 +164,7 @@ def run_case(spec, shape, seed=0):
     def hip(disable_fast):
         m = product_chain(spec)
         m.load_state_dict(state, strict=True)
-        m.to(DEV).train()
+        m.to(DEV).train(train)
         tssa.set_compute_dtype(m, torch.bfloat16)
         is_act = shape[1] % 8 == 0
         xh = x.to(DEV).to(torch.bfloat16 if is_act else torch.float32).requires_grad_(is_act)
@@ -251,6 +263,13 @@ BASELINE_LAYERS = [
     ('baseline_stem_ds', [('stem', 3, 32, {'stride': 2}), ('dw', 32, 32, {'stride': 2, 'act': False}), ('pw', 32, 48, {})], (2, 3, 1024, 2048)),
     # the decoder's 128-channel layers at 1/8 resolution: dilation-4 depthwise + the two biggest 1x1 layers of the step
     ('baseline_decoder', [('pw', 64, 128, {}), ('dw', 128, 128, {'dilation': 4}), ('pw', 128, 128, {})], (8, 64, 128, 256)),
+    # round 4: the low-resolution branch of the fusion module AS THE BENCHMARK RUNS IT -- x4 upsample + dilation-4
+    # depthwise 3x3 in one operator (csrc/updw.hip, its 40 KB / 56 KB source-tile variants at 8 x 128 x 32 x 64 -> 128 x 256) and the
+    # 128 -> 128 layer behind it, whose backward is the one-sweep kernel of csrc/pwsweep.hip with a pending BatchNorm + ReLU on x
+    ('baseline_fusion_lowres', [('up', 128, 128, {'scale': 4}), ('dw', 128, 128, {'dilation': 4}), ('pw', 128, 128, {'act': False})],
+     (8, 128, 32, 64)),
+    # the classifier's separable pair at 1/8 resolution: depthwise (no ReLU) -> 128 -> 128: pwsweep.hip with a pending BatchNorm only
+    ('baseline_classifier_ds', [('dw', 128, 128, {'act': False}), ('pw', 128, 128, {})], (8, 128, 128, 256)),
 ]
 
 
@@ -260,6 +279,134 @@ def test_baseline_sized_layers_vs_f64_oracle(case):
     compared tensor by tensor: tests/test_gpu_fullsize.py explains why), against the f64 bf16-storage oracle."""
     name, spec, shape = case
     bad = check(name, *run_case(spec, shape))
+    assert not bad, bad
+
+
+# round 4 (VERDICT r03 next 2b): features.1 of FastSCNN at its real size -- three inverted residuals at 1/16 -> 1/32 resolution.  The
+# second and third block's expand convolutions carry the previous block's join backward in their backward-data epilogue
+# (tss_pwconv_bwd_data_joined, 16 k pixels x 96 channels) and the skip gradient (radd); the first block's expand layer at 65 k pixels
+# runs the one-sweep backward of csrc/pwsweep.hip (64 -> 384 with a materialised input).
+BNECK_CHAINS = [
+    ('baseline_features_1', [('bneck', 64, 96, {'stride': 2}), ('bneck', 96, 96, {}), ('bneck', 96, 96, {})], (8, 64, 64, 128)),
+    # features.0.1 / .2 at their real size: 64 -> 384 -> 64 with the skip: pwsweep.hip expand (radd) and project instances
+    ('baseline_features_0_12', [('bneck', 64, 64, {}), ('bneck', 64, 64, {})], (8, 64, 64, 128)),
+]
+
+
+@pytest.mark.parametrize('case', BNECK_CHAINS, ids=[c[0] for c in BNECK_CHAINS])
+def test_bottleneck_chains_at_benchmark_size_vs_f64_oracle(case):
+    name, spec, shape = case
+    bad = check(name, *run_case(spec, shape), cap=CAP_BLOCK, direct=DIRECT_BLOCK)
+    assert not bad, bad
+
+
+# round 4 (VERDICT r03 weak 1 / next 2): the fused upsample + dilated depthwise operator against the f64 oracle, bound from the noise
+# model -- the shapes tests/test_gpu_ops.py used to compare with the unfused pair of the same library under hand-fitted bounds:
+# ragged strips / channel slices, non-integer scale (ContextNet interpolates to a size), dilation 2, batch and frozen statistics
+UPDW_CASES = [
+    ('updw_128_x4', 2, 128, 8, 16, (32, 64), 4), ('updw_72_ragged', 3, 72, 5, 7, (20, 28), 4), ('updw_128_size', 2, 128, 6, 10, (23, 37), 4),
+    ('updw_64_d2', 1, 64, 9, 9, (18, 18), 2), ('updw_8', 2, 8, 4, 6, (16, 24), 4), ('updw_128_b8', 8, 128, 4, 8, (16, 32), 4),
+]
+
+
+@pytest.mark.parametrize('train', [True, False], ids=['train', 'frozen'])
+@pytest.mark.parametrize('case', UPDW_CASES, ids=[c[0] for c in UPDW_CASES])
+def test_upsample_depthwise_operator_vs_f64_oracle(case, train):
+    name, B, c, hs, ws, size, dil = case
+    spec = [('up', c, c, {'size': size}), ('dw', c, c, {'dilation': dil}), ('pw', c, c, {'act': False})]
+    bad = check('%s_%s' % (name, 'train' if train else 'frozen'), *run_case(spec, (B, c, hs, ws), train=train))
+    assert not bad, bad
+
+
+class _FixedMask(nn.Module):
+    """nn.Dropout with a GIVEN keep mask: x * keep / (1 - p)"""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.keep, self.p = keep, p
+
+    def forward(self, x):
+        return x * self.keep.to(x.dtype) / (1.0 - self.p)
+
+
+@pytest.mark.parametrize('shape', [(8, 128, 128, 256), (2, 128, 40, 72)], ids=['benchmark_size', 'small'])
+def test_dropout_on_load_convolution_vs_f64_oracle_with_the_same_mask(shape):
+    """round 4: the Classifier's tail -- DSConv2dBlock -> nn.Dropout(0.1) -> nn.Conv2d(128, 19, 1)
+    (TSS/models/fastscnn.py:94-97) -- with the dropout ACTIVE: the product applies it on load (tss_pwconv_fwd_drop, tss_pwconv_bwd_fused_drop);
+    the mask it drew is read back (tss_dropout_mask's bytes) and injected into the f64 bf16-storage oracle as a fixed multiplier.
+    Forward, dX, every dW, the bias gradient; bound = 3 x the oracle-vs-oracle noise distance + floor, as everywhere in this file."""
+    import importlib
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    F = importlib.import_module('torch_semantic_segmentation_amd.models.fastscnn')
+    p = 0.1
+    B, C, H, W = shape
+    torch.manual_seed(11)
+    convs = lambda: (O.separable(C, C), nn.Conv2d(C, 19, kernel_size=1))
+    sep, last = convs()
+    with torch.no_grad():
+        for m in list(sep.modules()) + [last]:
+            if isinstance(m, nn.Conv2d):
+                bf16_round_(m.weight)
+                if m.bias is not None:
+                    bf16_round_(m.bias)
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(12)
+    x = bf16_round_(torch.randn(*shape, generator=g))
+    cot = bf16_round_(torch.randn(B, 19, H, W, generator=g) * 0.5 + 0.1)
+
+    # ---- product first: it draws the mask
+    prod = F.FusedSequential(F.DSConv2dBlock(C, C, kernel_size=3, padding=1), nn.Dropout(p), nn.Conv2d(C, 19, kernel_size=1))
+    state = {}
+    for k, v in sep.state_dict().items():
+        state['0.' + k] = v.clone()
+    for k, v in last.state_dict().items():
+        state['2.' + k] = v.clone()
+    prod.load_state_dict(state, strict=True)
+    prod.to(DEV).train()
+    tssa.set_compute_dtype(prod, torch.bfloat16)
+    xh = x.to(DEV).to(torch.bfloat16).requires_grad_(True)
+    ops._drop_mask_probe = []
+    try:
+        out = prod(xh)
+        out.backward(cot.to(DEV).to(out.dtype))
+        torch.cuda.synchronize()
+        masks = list(ops._drop_mask_probe)
+    finally:
+        ops._drop_mask_probe = None
+    assert len(masks) == 1, 'the dropout did not run on load (tss_pwconv_fwd_drop)'
+    mb = masks[0].cpu().numpy()                                     # [P][16] bytes, bit j of byte v = channel 8 v + j kept
+    keep = np.unpackbits(mb[:, :C // 8, None], axis=2, bitorder='little').reshape(B, H, W, C).transpose(0, 3, 1, 2)
+    keep_t = torch.from_numpy(np.ascontiguousarray(keep)).double()
+    frac = float(keep_t.mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+
+    def collect(mods, o, xg):
+        res = {'out': o.detach().double().cpu().numpy(), 'dx': xg.grad.detach().double().cpu().numpy()}
+        for i, mod in mods:
+            for n, q in mod.named_parameters():
+                kind = 'dw' if q.dim() == 4 else ('dbeta' if n.endswith('bias') else 'dgamma')
+                res['%s:%d.%s' % (kind, i, n)] = q.grad.detach().double().cpu().numpy()
+        return res
+
+    def oracle(dither):
+        s2, l2_ = convs()
+        s2.load_state_dict(sep.state_dict())
+        l2_.load_state_dict(last.state_dict())
+        net = nn.Sequential(s2, _FixedMask(keep_t, p), l2_).double().train()
+        emulate_bf16_storage(net, dither=dither)
+        xo = x.double().requires_grad_(True)
+        o = net(xo)
+        o.backward(cot.double())
+        return collect([(0, s2), (2, l2_)], o, xo)
+    want = oracle(None)
+    na, nb = oracle(torch.Generator().manual_seed(1007)), oracle(torch.Generator().manual_seed(2011))
+    lean = collect([(0, prod[0]), (2, prod[2])], out, xh)
+    _NOISE[0] = (na, nb)
+    # (no "general" run: with the fast paths off the dropout is a pass of its own with another mask; the yardstick column repeats lean)
+    bad = check('drop_conv_%dx%d' % (H, W), want, lean, lean, cap=CAP_BLOCK, direct=DIRECT_BLOCK)
     assert not bad, bad
 
 

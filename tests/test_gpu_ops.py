@@ -682,7 +682,7 @@ def test_batched_depthwise_row_reductions_match_the_immediate_ones(stride):
                 out.float().backward(torch.randn_like(out, dtype=torch.float32))
         finally:
             ops.batch_dw_reductions = old
-        assert not ops._pending_dw
+        assert not ops._passes          # every pass flushed and dropped its own state
         return {k: p.grad.clone() for k, p in m.named_parameters()}
     g1, g0 = run(True), run(False)
     for k in g0:
@@ -883,6 +883,77 @@ def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
             assert rel(g1[k], g0[k]) < 1e-2 and maxrel(g1[k], g0[k]) < 5e-2, k
 
 
+@pytest.mark.parametrize('cin,cout,pending,relu,radd,frozen', [
+    (128, 128, 1, 0, 0, 0), (128, 128, 1, 1, 0, 0), (128, 128, 0, 0, 1, 0), (128, 128, 0, 0, 0, 1),
+    (64, 384, 0, 0, 0, 0), (64, 384, 0, 0, 1, 0), (384, 64, 1, 1, 0, 0), (384, 64, 1, 0, 0, 1)])
+def test_large_pointwise_one_sweep_backward_matches_two_launches(cin, cout, pending, relu, radd, frozen):
+    """csrc/pwsweep.hip (round 4: input gradient + weight gradient of the 128 -> 128, 64 -> 384 and 384 -> 64 layers from one pass over
+    e, y, x; one 512-thread block per CU, inline-assembly tile requests with hand-placed waits) against tss_pwconv_bwd_weight +
+    tss_pwconv_bwd_data (+ _radd) through the C ABI on the same operands: pitches wider than the channel count, several tiles per
+    block and blocks without tiles, producer BatchNorm pending (mask + statistics) or not, skip gradient, frozen statistics (no yraw)."""
+    from torch_semantic_segmentation_amd import _native as N, ops
+    B, H, W = 2, 160, 128             # 40960 pixels: 640 / 1280 tiles over 256 blocks (uneven), a multiple of both tile sizes
+    P = B * H * W
+    torch.manual_seed(5)
+    assert N.lib().tss_pwconv_bwd_sweep_preferred(P, cin, cout, pending, N.TSS_BF16) == 1
+    assert N.lib().tss_pwconv_bwd_sweep_preferred(P + 8, cin, cout, pending, N.TSS_BF16) == 0      # ragged pixel count: the two-kernel path
+    lde, ldx = cout + 8, cin + 16
+    buf = lambda ld_: torch.randn(P, ld_, device=DEV).to(torch.bfloat16)
+    e, y, x, rd = buf(lde), buf(lde), buf(ldx), buf(ldx)
+    v = lambda c, s_=0.1: torch.randn(c, device=DEV) * s_
+    ga, gb, gce, gmu = torch.rand(cout, device=DEV) + 0.5, v(cout, 0.05), v(cout, 0.01), v(cout)
+    mean, sc, bias = (v(cin), torch.rand(cin, device=DEV) + 0.5, v(cin)) if pending else (None, None, None)
+    w = (torch.randn(cout, cin, device=DEV) * 0.2).to(torch.bfloat16).float()
+    wT = w.t().contiguous().to(torch.bfloat16)
+    S = N.stat_slabs()
+    st = N.stream()
+    yy = None if frozen else y
+    gargs = (N.ptr(e), lde, N.ptr(yy), lde if yy is not None else 0, N.ptr(ga), N.ptr(gb if yy is not None else None),
+             N.ptr(gce if yy is not None else None), N.ptr(gmu if yy is not None else None))
+    xargs = (N.ptr(x), ldx, N.ptr(mean), N.ptr(sc), N.ptr(bias), relu)
+
+    def pair():
+        dw = torch.zeros(cout, cin, device=DEV)
+        ei = torch.full((P, ldx), 7.0, device=DEV).to(torch.bfloat16)
+        bst = torch.empty(S, 2 * cin, dtype=torch.float64, device=DEV) if pending else None
+        nws = N.lib().tss_pwconv_bwd_weight_ws(P, cin, cout, N.TSS_BF16) if yy is not None else 0
+        ws = torch.empty(max(nws, 1), device=DEV)
+        N.call('tss_pwconv_bwd_weight', *gargs, *xargs, N.ptr(dw), N.ptr(ws) if nws else None, 0, P, cin, cout, N.TSS_BF16, None, st)
+        red = (None, None, 0, 0, 0)
+        if radd:
+            N.call('tss_pwconv_bwd_data_radd', *gargs, N.ptr(w), N.ptr(wT), N.ptr(ei), ldx, *red, N.ptr(rd), ldx, P, cin, cout, N.TSS_BF16, st)
+        else:
+            margs = xargs if pending else (None, 0, None, None, None, 0)
+            N.call('tss_pwconv_bwd_data', *gargs, N.ptr(w), N.ptr(wT), *margs, N.ptr(ei), ldx, N.ptr(bst), *red, P, cin, cout, N.TSS_BF16, st)
+        torch.cuda.synchronize()
+        return ei[:, :cin].float(), dw, (bst.sum(0) if pending else None), ei[:, cin:].float()
+
+    def sweep():
+        dw = torch.zeros(cout, cin, device=DEV)
+        ei = torch.full((P, ldx), 7.0, device=DEV).to(torch.bfloat16)
+        bst = torch.empty(S, 2 * cin, dtype=torch.float64, device=DEV) if pending else None
+        rows = N.lib().tss_pwconv_bwd_sweep_rows(P, cin, cout)
+        assert rows == 256
+        ws = torch.full((rows, cout * cin), float('nan'), device=DEV)
+        N.call('tss_pwconv_bwd_sweep', *gargs, N.ptr(wT), *xargs, pending, N.ptr(rd) if radd else None, ldx if radd else 0,
+               N.ptr(ei), ldx, N.ptr(bst), N.ptr(ws), P, cin, cout, N.TSS_BF16, st)
+        ops._reduce_rows_now(ws, dw, cout * cin, rows)
+        torch.cuda.synchronize()
+        return ei[:, :cin].float(), dw, (bst.sum(0) if pending else None), ei[:, cin:].float()
+    e0, dw0, s0, pad0 = pair()
+    e1, dw1, s1, pad1 = sweep()
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+    assert torch.equal(pad1, pad0)                       # nothing written into the pitch padding
+    assert l2(e1, e0) < 2e-4, l2(e1, e0)                  # (the two paths fold the BatchNorm-backward constants in a different order: rare 1-ulp flips)
+    assert (e1 - e0).abs().max() <= 2.0 ** -6 * e0.abs().max()
+    assert l2(dw1, dw0) < 1e-4, l2(dw1, dw0)
+    if pending:
+        assert l2(s1, s0) < 1e-4, l2(s1, s0)
+    # bit-reproducible: no atomics anywhere
+    e2, dw2, s2, _ = sweep()
+    assert torch.equal(e2, e1) and torch.equal(dw2, dw1) and (not pending or torch.equal(s2, s1))
+
+
 @pytest.mark.parametrize('B,c,hs,ws,size,dil', [(2, 128, 8, 16, (32, 64), 4), (3, 72, 5, 7, (20, 28), 4), (2, 128, 6, 10, (23, 37), 4),
                                                 (1, 64, 9, 9, (18, 18), 2), (2, 8, 4, 6, (16, 24), 4), (8, 128, 4, 8, (16, 32), 4)])
 @pytest.mark.parametrize('train', [True, False])
@@ -932,15 +1003,11 @@ def test_upsample_depthwise_in_one_operator_matches_the_two_operators(B, c, hs, 
     o1, dx1, g1, s1 = run(True)
     o0, dx0, g0, s0 = run(False)
     assert calls == [True, False]
-    assert rel(o1, o0) < 1e-2        # (max |difference| / max |value|: one bf16 ulp of a large element)
-    # the two paths round the gradient of the upsampled map to bf16 after sums taken in different orders; a source pixel of a small
-    # map gathers ~(2 scale)^2 of those roundings: bounded in the L2 norm, and loosely element by element
-    def l2(a, b):
-        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
-    assert l2(dx1, dx0) < 5e-3 and maxrel(dx1, dx0) < 5e-2
-    for k in g0:
-        if g0[k].norm() > 1e-3:
-            assert l2(g1[k], g0[k]) < 5e-3 and maxrel(g1[k], g0[k]) < 5e-2, k
+    # (how close the fused operator is to the reference's arithmetic -- forward, dX, every dW, batch and frozen statistics, these very
+    # shapes -- is asserted against the f64 oracle under a noise-derived bound in tests/test_gpu_lean_vs_oracle.py::
+    # test_upsample_depthwise_operator_vs_f64_oracle; the hand-fitted fused-vs-unfused bounds that stood here in round 3 are gone.  What
+    # stays: both paths ran, neither produced garbage, and the running statistics -- f32 sums of the same bf16 numbers -- agree)
+    assert torch.isfinite(o1).all() and torch.isfinite(dx1).all() and rel(o1, o0) < 0.1 and rel(dx1, dx0) < 0.5
     for a, b in zip(s1, s0):
         assert rel(a, b) < 1e-4
     # raw convolution output against torch in f32 (bf16 operands, one rounding of the interpolated pixel, one of the output)

@@ -50,4 +50,19 @@ python3 tools/graph_memset_probe.py > $out/${tag}_memset_probe.log 2>&1; cp gpur
 python3 tools/micro_atrous.py 2>&1 | grep dil > $out/${tag}_micro_atrous.txt
 TSS_CONV3X3_WSTAT=0 python3 tools/micro_atrous.py 2>&1 | grep dil >> $out/${tag}_micro_atrous.txt
 python3 bench.py --model lednet --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_lednet.json 2> $out/lednet.err
+# "what you get without this project" (SURVEY 8d): the oracle's modules on the stock PyTorch-ROCm / MIOpen path, same batch, beside the headline
+python3 bench.py --stock --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_stock.json 2> $out/stock.err
+python3 tools/micro_sweep.py > $out/${tag}_micro_sweep.txt 2>&1
 echo "bench done"
+# 5. the parity table of the benchmarked kernels against the f64 oracle, written by the test itself: the tracked copy can not lag the code
+python3 -m pytest tests/test_gpu_lean_vs_oracle.py -q -x > $out/lean_parity_pytest.log 2>&1 || true
+cp gpurun_out/lean_parity.txt $out/${tag}_lean_parity.txt
+tail -3 $out/lean_parity_pytest.log
+echo "parity done"
+# 6. where the waves of each kernel spend their cycles (one counter-only pass, 8 SQ counters)
+cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT -d $out/wave --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --graph off --no-cpu-baseline --no-roofline --no-extras > /dev/null 2> $out/wave.err
+python3 $root/tools/pmc_wavestate.py $out/wave > $out/${tag}_pmc_wavestate.txt
+rm -rf $out/wave
+cd $root
+echo "wavestate done"

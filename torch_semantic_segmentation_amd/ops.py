@@ -14,6 +14,7 @@ There is no torch/ATen fallback here: every operator calls the C ABI and raises 
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -59,26 +60,37 @@ overlap_min_elems = int(os.environ.get('TSS_OVERLAP_MIN', '0'))
 batch_dw_reductions = os.environ.get('TSS_BATCH_DW_REDUCE', '1') == '1'
 fuse_pw_backward = os.environ.get('TSS_PW_BWD_FUSED', '1') != '0'     # csrc/pwbwd.hip, for the layers it prefers
 sweep_pw_backward = os.environ.get('TSS_PW_SWEEP', '1') != '0'        # csrc/pwsweep.hip: the large 1x1 layers, one sweep (round 4)
-_pending_dw = []
-
 # Backward-pass scheduling ("launch count"): every dependent launch costs >= 4.7 us in the replayed step, so
 #   * the weight gradient of a 1x1 layer -- which nothing downstream in the backward pass depends on -- is POSTPONED until the
 #     next BatchNorm-backward finalize is due, and that finalize rides in front of its grid (tss_pwconv_bwd_weight's `fin`);
 #   * the slot reduction of a launched weight gradient rides in front of the next backward-data grid of ANY 1x1 layer.
-# State of the running backward pass; everything left over is flushed by the end-of-pass callback, so gradients are complete
-# when backward() returns (and not before: see direct_grads).
+# Everything left over is flushed by the end-of-pass callback, so gradients are complete when backward() returns (and not before:
+# see direct_grads).
 postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
-# Both are keyed by the stream the postponed work belongs to: a model whose branches run on two streams (ContextNet) has two
-# independent backward chains, and a launch postponed on one stream must neither ride on nor carry work of the other (its
-# operands are ordered on its own stream only).
 # Layers that run inside a two-stream region of the forward pass (ContextNet's branches, `overlap_region`) are not postponed: there
 # the other stream's kernels already fill the launch gaps, and what postponing leaves for the end of the pass (a weight gradient and
 # its slot reduction per stream, un-overlapped) costs more than the finalize launches it saves (measured: 6.32 vs 6.21 ms per step).
 _overlap_depth = [0]
 postpone_in_overlap = os.environ.get('TSS_POSTPONE_OVERLAPPED', '0') == '1'     # A/B: postpone inside two-stream regions too
-_pending_wg = {}       # stream id -> (launch(fin_job or None), device, stream)
-_pending_red = {}      # stream id -> (ws, dw, P, K, N, device, stream)
-_cb_task = [None]
+
+
+class _Pass:
+    """Scheduling state of ONE running backward pass (one autograd graph task).  Round 4: the state used to be module-global and
+    was cleared whenever the graph-task id changed, so a nested pass (torch.utils.checkpoint(use_reentrant=True), a hook calling
+    torch.autograd.grad) silently deleted the OUTER pass's postponed weight gradients and row reductions.  Now every graph task has
+    its own: a nested pass postpones, flushes and completes its own work, the outer one keeps its own.
+    `wg` / `red` are keyed by the stream the postponed work belongs to: a model whose branches run on two streams (ContextNet) has
+    two independent backward chains, and a launch postponed on one stream must neither ride on nor carry work of the other."""
+    __slots__ = ('dw', 'wg', 'red')
+
+    def __init__(self):
+        self.dw = []        # (ws, dw, ncols, nrows): row reductions for the one launch at the end of the pass
+        self.wg = {}        # stream id -> (launch(fin_job or None), device, stream)
+        self.red = {}       # stream id -> (ws, dw, P, K, N, device, stream)
+
+
+_passes = {}                # graph-task id -> _Pass
+_lock = threading.RLock()   # two trainers in two threads (each with its own autograd device thread) share this module
 
 
 class BnBwdJob(ctypes.Structure):
@@ -89,37 +101,54 @@ class BnBwdJob(ctypes.Structure):
 
 
 def _backward_task():
-    """Id of the running autograd graph task (-1: none).  The first call of a pass queues the end-of-pass flush; state left over
-    from a pass that raised before its callback ran is void and dropped."""
+    """Id of the running autograd graph task (-1: none, or nothing can be deferred).  The first call of a pass creates its state and
+    queues its end-of-pass flush on THAT graph task."""
     try:
         task = torch._C._current_graph_task_id()
     except AttributeError:          # private API gone: nothing is deferred
         return -1
-    if task != -1 and _cb_task[0] != task:
-        del _pending_dw[:]
-        _pending_wg.clear()
-        _pending_red.clear()
-        try:
-            torch.autograd.variable.Variable._execution_engine.queue_callback(_end_of_backward)
-        except Exception:           # noqa: BLE001 -- no callback, no deferral
-            return -1
-        _cb_task[0] = task
+    if task == -1:
+        return -1
+    with _lock:
+        if task not in _passes:
+            try:
+                torch.autograd.variable.Variable._execution_engine.queue_callback(lambda _t=task: _end_of_backward(_t))
+            except Exception:           # noqa: BLE001 -- no callback, no deferral
+                return -1
+            # state of passes that raised before their callback ran is void; graph-task ids only grow, and a running outer pass of a
+            # nested one is never more than a few ids behind: keep the newest 16
+            for old in sorted(_passes)[:-15]:
+                del _passes[old]
+            _passes[task] = _Pass()
     return task
 
 
-def _flush_wg(sid=None):
+def _cur_pass():
+    task = _backward_task()
+    return _passes.get(task) if task != -1 else None
+
+
+def _flush_wg(sid=None, ps=None):
     """Launch postponed weight gradients now, without a rider, each on the stream it belongs to (sid: only that stream's)."""
-    for k in ([sid] if sid is not None else list(_pending_wg)):
-        ent = _pending_wg.pop(k, None)
+    ps = ps if ps is not None else _cur_pass()
+    if ps is None:
+        return
+    for k in ([sid] if sid is not None else list(ps.wg)):
+        with _lock:
+            ent = ps.wg.pop(k, None)
         if ent is not None:
             launch, dev, st_ = ent
             with torch.cuda.device(dev), torch.cuda.stream(st_):
                 launch(None)
 
 
-def _flush_red(sid=None):
-    for k in ([sid] if sid is not None else list(_pending_red)):
-        ent = _pending_red.pop(k, None)
+def _flush_red(sid=None, ps=None):
+    ps = ps if ps is not None else _cur_pass()
+    if ps is None:
+        return
+    for k in ([sid] if sid is not None else list(ps.red)):
+        with _lock:
+            ent = ps.red.pop(k, None)
         if ent is not None:
             ws, dw, P, K, Nn, dev, st_ = ent
             with torch.cuda.device(dev), torch.cuda.stream(st_):
@@ -128,33 +157,48 @@ def _flush_red(sid=None):
 
 def _take_red(dev):
     """(ws ptr, dw ptr, P, K, N) of a slot reduction waiting for a carrier on THIS stream (else NULLs) + its tensors (kept alive by the caller)."""
-    ent = _pending_red.pop(stream(), None)
+    ps = _cur_pass()
+    ent = None
+    if ps is not None:
+        with _lock:
+            ent = ps.red.pop(stream(), None)
     if ent is not None:
         ws, dw, P, K, Nn = ent[:5]
         return (ptr(ws), ptr(dw), P, K, Nn), (ws, dw)
     return (None, None, 0, 0, 0), None
 
 
-def _end_of_backward():
-    _cb_task[0] = None
-    _flush_wg()
-    _flush_red()
+def _end_of_backward(task):
+    with _lock:
+        ps = _passes.pop(task, None)
+    if ps is None:
+        return
+    _flush_wg(ps=ps)
+    _flush_red(ps=ps)
     # the row reductions below run on the current stream: order it behind the side streams whose kernels wrote some of the rows
     # (the autograd engine joins its leaf streams only AFTER the final callbacks)
-    if _pending_dw and _side_streams:
+    if ps.dw and _side_streams:
         cur = torch.cuda.current_stream()
         for s_ in _side_streams.values():
             if s_.device == cur.device:
                 cur.wait_stream(s_)
-    _flush_dw_reductions()
+    _flush_dw_reductions(ps)
 
 
 def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
     """BatchNorm-backward coefficients + d(gamma), d(beta) of `link`: in front of a postponed weight-gradient grid of the same
-    stream when there is one (no launch of its own), else tss_bn_bwd_finalize."""
+    stream (and the same pass) when there is one (no launch of its own), else tss_bn_bwd_finalize."""
     training = int(link.training if training is None else training)
-    ent = _pending_wg.get(st)
-    if ent is not None and ent[1] == link.bstats.device and _backward_task() != -1 and _pending_wg.pop(st, None) is not None:
+    ps = _cur_pass()
+    ent = None
+    if ps is not None:
+        with _lock:
+            ent = ps.wg.get(st)
+            if ent is not None and ent[1] == link.bstats.device:
+                ps.wg.pop(st, None)
+            else:
+                ent = None
+    if ent is not None:
         job = BnBwdJob(ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
                        ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), int(C))
         ent[0](job)
@@ -163,9 +207,10 @@ def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
          ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
 
 
-def _flush_dw_reductions():
-    jobs = list(_pending_dw)
-    del _pending_dw[:]
+def _flush_dw_reductions(ps):
+    with _lock:
+        jobs = list(ps.dw)
+        del ps.dw[:]
     if not jobs:
         return
     n = len(jobs)
@@ -192,20 +237,57 @@ def _defer_dw_reduction(ws, dw, ncols, nrows, param=None):
     """Queue the row reduction of a one-sweep backward for the single launch at the end of the pass (now, if nothing can be deferred).
     Contract of the deferral (and of the postponed 1x1 weight gradients): directly accumulated gradients are complete when backward()
     returns, not earlier -- except for parameters with hooks, which are finished at once."""
-    task = _backward_task()
-    if task == -1 or _param_observed(param):
+    ps = _cur_pass()
+    if ps is None or _param_observed(param):
         _reduce_rows_now(ws, dw, ncols, nrows)
         return
-    if _pending_dw and _pending_dw[0][0].device != ws.device:
-        _flush_dw_reductions()
-    _pending_dw.append((ws, dw, ncols, nrows, task))
+    if ps.dw and ps.dw[0][0].device != ws.device:
+        _flush_dw_reductions(ps)
+    with _lock:
+        ps.dw.append((ws, dw, ncols, nrows))
+
+
+class _PerThread:
+    """A dict private to the calling thread.  The forward-pass registries below (keyed by id() of a tensor between the operator that
+    registers an entry and the operator that picks it up, both in the same forward call) are per thread, so two models running their
+    forward passes in two threads never see -- or steal -- each other's entries."""
+
+    def __init__(self):
+        self._tl = threading.local()
+
+    def _d(self):
+        d = getattr(self._tl, 'd', None)
+        if d is None:
+            d = self._tl.d = {}
+        return d
+
+    def __bool__(self):
+        return bool(self._d())
+
+    def __len__(self):
+        return len(self._d())
+
+    def __setitem__(self, k, v):
+        self._d()[k] = v
+
+    def __contains__(self, k):
+        return k in self._d()
+
+    def pop(self, k, default=None):
+        return self._d().pop(k, default)
+
+    def get(self, k, default=None):
+        return self._d().get(k, default)
+
+    def clear(self):
+        self._d().clear()
 
 
 # Residual blocks: the block input has two consumers (the first 1x1 layer and the skip), so its gradient is a sum of two tensors.
 # Autograd would add them with an elementwise launch of its own; instead the skip's gradient (produced first, by the join's
 # backward) is handed to the first layer's backward-data kernel, which adds it in its epilogue (tss_pwconv_bwd_data_radd).
 fold_residual_adds = os.environ.get('TSS_FOLD_RESIDUAL', '1') != '0'
-_pending_forks = {}
+_pending_forks = _PerThread()
 
 
 class _Fork:
@@ -256,7 +338,7 @@ fuse_join_backward = os.environ.get('TSS_FUSE_JOIN_BWD', '1') != '0'
 # layer more than the join launch it saves (262 k pixels x 64 channels: +48 us against a 28 us join; 65 k x 64: +10 against 14;
 # 16 k x 96-128: +2 against 9)
 fuse_join_backward_max = int(os.environ.get('TSS_FUSE_JOIN_BWD_MAX', '4000000'))
-_join_ctx = {}
+_join_ctx = _PerThread()
 
 
 def _take_join(x):
@@ -267,7 +349,7 @@ def _take_join(x):
     return cfg if (cfg is not None and cfg.j_ptr == x.data_ptr()) else None
 
 
-_pending_stash = {}
+_pending_stash = _PerThread()
 
 
 def fork_two(x):
@@ -720,6 +802,7 @@ def _classify(conv, x_is_image):
 
 
 _KEEP = object()
+_drop_mask_probe = None       # a list while a test collects the masks drawn by dropout-on-load convolutions
 
 
 def drop_conv_supported(x, conv, p):
@@ -986,6 +1069,8 @@ class ConvUnitFn(Function):
             mask = torch.empty((P, 16), dtype=torch.uint8, device=dev)
             counter = _dropout_counter(dev)
             call('tss_dropout_mask', ptr(counter), ptr(mask), P, cfg.cin, cfg.drop_p, st)
+            if _drop_mask_probe is not None:         # tests read the mask back to hand the oracle the same one
+                _drop_mask_probe.append(mask)
             call('tss_pwconv_fwd_drop', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), _shadow(weight, 0), ptr(bias),
                  ptr(y), ld(y), ptr(mask), cfg.drop_p, ptr(counter), P, cfg.cin, Cout, dt, st)
         elif cfg.kind == 'pw':
@@ -1127,7 +1212,7 @@ class ConvUnitFn(Function):
                 nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin, Cout, dt) if y is not None else 0
                 ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
                 defer = 1 if (ws is not None and need_dx and side is None) else 0   # a backward-data launch carries the reduce
-                # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _pending_wg)
+                # the launch itself waits for the next BatchNorm-backward finalize of this pass and carries it (see _Pass.wg)
                 postponed = bool(defer and postpone_wgrad and dw_ret is None and not getattr(cfg, 'overlapped', False)
                                  and _backward_task() != -1 and not _param_observed(p_weight))
                 if not postponed:
@@ -1238,14 +1323,18 @@ class ConvUnitFn(Function):
                         _flush_wg(st)          # at most one weight gradient waits per stream
                         own = torch.cuda.current_stream(dev)
 
+                        ps = _cur_pass()
+
                         def launch_wg(fin, _keep=(e, y, x, link, il, ws, dw), _args=(gargs, xargs, ptr(dw), ptr(ws), P, Cin, Cout, dt),
-                                      _sid=st, _own=own):
+                                      _sid=st, _own=own, _ps=ps):
                             ga_, xa_, dwp, wsp, P_, K_, N_, dt_ = _args
                             call('tss_pwconv_bwd_weight', *ga_, *xa_, dwp, wsp, 1, P_, K_, N_, dt_,
                                  ctypes.byref(fin) if fin is not None else None, _sid)
-                            _flush_red(_sid)
-                            _pending_red[_sid] = (_keep[5], _keep[6], P_, K_, N_, _keep[0].device, _own)
-                        _pending_wg[st] = (launch_wg, dev, own)
+                            _flush_red(_sid, _ps)
+                            with _lock:
+                                _ps.red[_sid] = (_keep[5], _keep[6], P_, K_, N_, _keep[0].device, _own)
+                        with _lock:
+                            ps.wg[st] = (launch_wg, dev, own)
                 elif cfg.kind == 'dw' and fused_dw and dw_ret is None and batch_dw_reductions:
                     # the rows of per-block partial sums stay in ws; they are added to the (direct) gradient together with
                     # those of every other depthwise layer, in one launch at the end of this backward pass
