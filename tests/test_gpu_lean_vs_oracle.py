@@ -314,7 +314,10 @@ UPDW_CASES = [
 def test_upsample_depthwise_operator_vs_f64_oracle(case, train):
     name, B, c, hs, ws, size, dil = case
     spec = [('up', c, c, {'size': size}), ('dw', c, c, {'dilation': dil}), ('pw', c, c, {'act': False})]
-    bad = check('%s_%s' % (name, 'train' if train else 'frozen'), *run_case(spec, (B, c, hs, ws), train=train))
+    # the gradient of a small source map gathers ~(2 scale)^2 bf16-rounded values per pixel: the noise-derived bound is the criterion
+    # (3 x 3.9e-2 on the 5 x 7 map), the ceiling is the one of the multi-layer blocks
+    bad = check('%s_%s' % (name, 'train' if train else 'frozen'), *run_case(spec, (B, c, hs, ws), train=train), cap=CAP_BLOCK,
+                direct=DIRECT_BLOCK)      # ("general" = upsample and strip kernel as two operators with a bf16 tensor between them: another algorithm)
     assert not bad, bad
 
 
