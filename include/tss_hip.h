@@ -281,14 +281,15 @@ int tss_pwconv_bwd_fused(const void* e, long lde, const void* yraw, long ldyr, c
                          const float* gmu, const float* w, const void* wT_bf16, const void* x, long ldx, const float* in_mean,
                          const float* in_scale, const float* in_bias, int in_relu, int x_pending, void* e_in, long ldei,
                          double* bstats, float* ws, float* bias_ws, long P, int Cin, int Cout, int dtype, void* stream);
-/* The same one sweep for the LARGE 1x1 layers (csrc/pwsweep.hip, round 4; bf16): Cin -> Cout = 128 -> 128, 64 -> 384, 384 -> 64 -- the
+/* The same one sweep for the LARGE 1x1 layers (csrc/pwsweep.hip, round 4; bf16): Cin -> Cout = 128 -> 128, 64 -> 384, 384 -> 64 (and
+ * 32 -> 192, 192 -> 32: the inverted residuals of TSS/models/contextnet.py:129-147 at 1/8 of the context image) -- the
  * classifier / fusion layers and the 6x bottleneck expand / project layers of TSS/models/fastscnn.py:138-161,188-199 at 1/8 and 1/16
  * resolution -- where tss_pwconv_bwd_data + tss_pwconv_bwd_weight read (e, yraw) twice.  One 512-thread block per CU keeps the whole
  * [Cout][Cin] weight-gradient tile in registers; ws receives tss_pwconv_bwd_sweep_rows(P, Cin, Cout) rows of Cout*Cin floats (summed
  * by tss_dw_reduce_many).  wT_bf16: bf16 TRANSPOSE [Cin][Cout] of w (required).  x_pending = 1: x is a producer's raw output (in_*
  * pending): e_in is masked and bstats written as tss_pwconv_bwd_data does.  radd (optional, x_pending = 0 only): the other gradient
  * of the layer's input (the skip of a residual block), added in the epilogue as tss_pwconv_bwd_data_radd does.  P must be a multiple
- * of the tile (64 pixels for 128 -> 128, else 32); 64 -> 384 takes a materialised x only, 384 -> 64 a pending one:
+ * of the tile (64 pixels for 128 -> 128 and 32 -> 192, else 32); the expand shapes take a materialised x only, the project shapes a pending one:
  * tss_pwconv_bwd_sweep_preferred says whether the entry covers the layer and pays. */
 int tss_pwconv_bwd_sweep_preferred(long P, int Cin, int Cout, int x_pending, int dtype);
 int tss_pwconv_bwd_sweep_rows(long P, int Cin, int Cout);

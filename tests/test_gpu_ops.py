@@ -885,7 +885,8 @@ def test_pointwise_one_sweep_backward_matches_two_launches(chans, pending):
 
 @pytest.mark.parametrize('cin,cout,pending,relu,radd,frozen', [
     (128, 128, 1, 0, 0, 0), (128, 128, 1, 1, 0, 0), (128, 128, 0, 0, 1, 0), (128, 128, 0, 0, 0, 1),
-    (64, 384, 0, 0, 0, 0), (64, 384, 0, 0, 1, 0), (384, 64, 1, 1, 0, 0), (384, 64, 1, 0, 0, 1)])
+    (64, 384, 0, 0, 0, 0), (64, 384, 0, 0, 1, 0), (384, 64, 1, 1, 0, 0), (384, 64, 1, 0, 0, 1),
+    (32, 192, 0, 0, 1, 0), (32, 192, 0, 0, 0, 1), (192, 32, 1, 1, 0, 0)])
 def test_large_pointwise_one_sweep_backward_matches_two_launches(cin, cout, pending, relu, radd, frozen):
     """csrc/pwsweep.hip (round 4: input gradient + weight gradient of the 128 -> 128, 64 -> 384 and 384 -> 64 layers from one pass over
     e, y, x; one 512-thread block per CU, inline-assembly tile requests with hand-placed waits) against tss_pwconv_bwd_weight +

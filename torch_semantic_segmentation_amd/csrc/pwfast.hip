@@ -180,23 +180,23 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
   int nfr = (ncw - wn * 64 + 15) >> 4;
   nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
 
-  if (tid < NCH) {   // three independent loads (null-safe pointers + select), not three branches with a wait each
+  // The epilogue constants of this block's channels are REQUESTED here and parked in LDS only at the end of the set-up (round 4): their
+  // round trip used to be exposed in front of everything else -- loads, wait, LDS stores, barrier, and only then the first tile's
+  // requests (2.1 - 2.4 k cycles of the 8 - 10 k-cycle prologue, tools/pw_timing.sh).  Now they fly together with the first tile and
+  // the weights: one round trip instead of two.  Three independent loads (null-safe pointers + select), not three branches with a wait each.
+  float ec0 = 0.f, ec1 = 0.f, ec2 = 0.f, ec_sc = 0.f, ec_mu = 0.f, ec_be = 0.f;
+  bool ec_in = false, ec_hm = false, ec_hs = false, ec_hb = false;
+  if (tid < NCH) {
     const int n = n0 + tid;
     const bool in = n < g.N;
     const int nn = in ? n : 0;
     const bool hj = JB && !g.xm && g.jout && g.jmean;
     const bool hm = BWD ? ((g.xm && g.mm) || hj) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
-    const float e0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
-    const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
-    const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
-    Ec[tid] = (in && hm) ? e0 : 0.f;
-    Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
-    Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
-    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
-      const float sc = g.escale[nn], mu = g.emean ? g.emean[nn] : 0.f, be = g.ebeta ? g.ebeta[nn] : 0.f;
-      Ec[tid] = in ? be + ((hm ? e0 : 0.f) - mu) * sc : 0.f;
-      Ec[NCH + tid] = in ? sc : 0.f;
-    }
+    ec0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
+    ec1 = (hs ? g.ms : g.w)[hs ? nn : 0];
+    ec2 = (hb ? g.mb : g.w)[hb ? nn : 0];
+    ec_in = in; ec_hm = hm; ec_hs = hs; ec_hb = hb;
+    if (!BWD && g.escale) { ec_sc = g.escale[nn]; ec_mu = g.emean ? g.emean[nn] : 0.f; ec_be = g.ebeta ? g.ebeta[nn] : 0.f; }
   }
   const int K = g.K;
   const int kwp = (K + 31) & ~31;          // MFMA k-steps cover kwp columns; columns >= K are zero in both tiles
@@ -216,7 +216,6 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
 
   // epilogue per-lane constants: mask coefficients of the 16 channels this lane owns (4 fragments x 4)
   const int nlane = n0 + wn * 64 + fq * 4;
-  __syncthreads();
 
   // The A-tile loads of tile t+1 are issued right after tile t's registers have been stored to LDS, so the HBM round
   // trip runs under tile t's MFMA + epilogue instead of being exposed at the top of every tile (counters: 76 % of the
@@ -301,6 +300,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_kernel(const FastArgs g) {
     }
   }
 
+  if (tid < NCH) {       // the epilogue constants requested at the top
+    Ec[tid] = (ec_in && ec_hm) ? ec0 : 0.f;
+    Ec[NCH + tid] = (ec_in && ec_hs) ? ec1 : (BWD ? 1.f : 0.f);
+    Ec[2 * NCH + tid] = (ec_in && ec_hb) ? ec2 : 0.f;
+    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
+      Ec[tid] = ec_in ? ec_be + ((ec_hm ? ec0 : 0.f) - ec_mu) * ec_sc : 0.f;
+      Ec[NCH + tid] = ec_in ? ec_sc : 0.f;
+    }
+  }
   __syncthreads();
 
   TSS_T(tq1);
@@ -540,23 +548,23 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
   const int nrows = ((ncw + 15) >> 4) * 16;
   int nfr = (ncw - wn * 64 + 15) >> 4;
   nfr = nfr < 0 ? 0 : (nfr > 4 ? 4 : nfr);
-  if (tid < NCH) {   // three independent loads (null-safe pointers + select), not three branches with a wait each
+  // The epilogue constants of this block's channels are REQUESTED here and parked in LDS only at the end of the set-up (round 4): their
+  // round trip used to be exposed in front of everything else -- loads, wait, LDS stores, barrier, and only then the first tile's
+  // requests (2.1 - 2.4 k cycles of the 8 - 10 k-cycle prologue, tools/pw_timing.sh).  Now they fly together with the first tile and
+  // the weights: one round trip instead of two.  Three independent loads (null-safe pointers + select), not three branches with a wait each.
+  float ec0 = 0.f, ec1 = 0.f, ec2 = 0.f, ec_sc = 0.f, ec_mu = 0.f, ec_be = 0.f;
+  bool ec_in = false, ec_hm = false, ec_hs = false, ec_hb = false;
+  if (tid < NCH) {
     const int n = n0 + tid;
     const bool in = n < g.N;
     const int nn = in ? n : 0;
     const bool hj = JB && !g.xm && g.jout && g.jmean;
     const bool hm = BWD ? ((g.xm && g.mm) || hj) : (g.bias != nullptr), hs = BWD && g.xm && g.ms, hb = BWD && g.xm && g.mb;
-    const float e0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
-    const float e1 = (hs ? g.ms : g.w)[hs ? nn : 0];
-    const float e2 = (hb ? g.mb : g.w)[hb ? nn : 0];
-    Ec[tid] = (in && hm) ? e0 : 0.f;
-    Ec[NCH + tid] = (in && hs) ? e1 : (BWD ? 1.f : 0.f);
-    Ec[2 * NCH + tid] = (in && hb) ? e2 : 0.f;
-    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
-      const float sc = g.escale[nn], mu = g.emean ? g.emean[nn] : 0.f, be = g.ebeta ? g.ebeta[nn] : 0.f;
-      Ec[tid] = in ? be + ((hm ? e0 : 0.f) - mu) * sc : 0.f;
-      Ec[NCH + tid] = in ? sc : 0.f;
-    }
+    ec0 = (hm ? (BWD ? (hj ? g.jmean : g.mm) : g.bias) : g.w)[hm ? nn : 0];
+    ec1 = (hs ? g.ms : g.w)[hs ? nn : 0];
+    ec2 = (hb ? g.mb : g.w)[hb ? nn : 0];
+    ec_in = in; ec_hm = hm; ec_hs = hs; ec_hb = hb;
+    if (!BWD && g.escale) { ec_sc = g.escale[nn]; ec_mu = g.emean ? g.emean[nn] : 0.f; ec_be = g.ebeta ? g.ebeta[nn] : 0.f; }
   }
   const int K = g.K;
   const int nkc = (K + KMAX - 1) / KMAX;
@@ -573,6 +581,15 @@ __global__ __launch_bounds__(NT, 2) void pwfast_mc_kernel(const FastArgs g) {
       Ck[ch] = c0v; Ck[KTOT + ch] = c1v; Ck[2 * KTOT + ch] = -(c0v * c2v) - c1v * c3v;
     } else {         // a = (x - c1)*c0 + c2
       Ck[ch] = c0v; Ck[KTOT + ch] = 0.f; Ck[2 * KTOT + ch] = c2v - c1v * c0v;
+    }
+  }
+  if (tid < NCH) {       // the epilogue constants requested at the top: their round trip ran under the loop above
+    Ec[tid] = (ec_in && ec_hm) ? ec0 : 0.f;
+    Ec[NCH + tid] = (ec_in && ec_hs) ? ec1 : (BWD ? 1.f : 0.f);
+    Ec[2 * NCH + tid] = (ec_in && ec_hb) ? ec2 : 0.f;
+    if (!BWD && g.escale) {         // eval epilogue: v = acc * scale + shift, shift = beta + (bias - mean) * scale
+      Ec[tid] = ec_in ? ec_be + ((ec_hm ? ec0 : 0.f) - ec_mu) * ec_sc : 0.f;
+      Ec[NCH + tid] = ec_in ? ec_sc : 0.f;
     }
   }
 

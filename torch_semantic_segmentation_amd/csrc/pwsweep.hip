@@ -21,7 +21,7 @@
 //   * the images are double-buffered: one barrier per tile;
 //   * W^T (bf16 shadow, [Cin][Cout]) lives in REGISTERS as MFMA fragments for the whole launch (24 - 48 registers): no weight
 //     image in LDS and no weight reads in the loop.
-// Shapes (Cin -> Cout): 128 -> 128 (TM = 64), 64 -> 384 and 384 -> 64 (TM = 32): FastSCNN's classifier / fusion layers at 1/8
+// Shapes (Cin -> Cout): 128 -> 128 (TM = 64), 64 -> 384 and 384 -> 64 (TM = 32), 32 -> 192 (64) and 192 -> 32 (32): FastSCNN's classifier / fusion layers at 1/8
 // resolution and its 6x bottleneck expand / project layers at 1/8 and 1/16 resolution (TSS/models/fastscnn.py:138-161, 188-199);
 // P must be a multiple of TM (else the caller keeps the two-kernel path).
 #include <cstdlib>
@@ -429,14 +429,20 @@ __global__ __launch_bounds__(512, 2) void pwsweep_kernel(const SwArgs g) {
 typedef Cfg<8, 8, 64, 4, 2, 2, 2, 4> CfgSq;          // 128 -> 128
 typedef Cfg<24, 4, 32, 6, 1, 1, 3, 4> CfgExpand;     // 64 -> 384
 typedef Cfg<4, 24, 32, 2, 3, 2, 4, 3, true> CfgProject;    // 384 -> 64
+typedef Cfg<12, 2, 64, 6, 1, 1, 3, 1> CfgExpand32;         // 32 -> 192  (ContextNet's context branch at 1/8 resolution of the 1/4 image)
+typedef Cfg<2, 12, 32, 2, 3, 1, 1, 3> CfgProject32;        // 192 -> 32
 
 inline int shape_kind(int Cin, int Cout) {
   if (Cin == 128 && Cout == 128) return 1;
   if (Cin == 64 && Cout == 384) return 2;
   if (Cin == 384 && Cout == 64) return 3;
+  if (Cin == 32 && Cout == 192) return 4;
+  if (Cin == 192 && Cout == 32) return 5;
   return 0;
 }
-inline int tile_px(int kind) { return kind == 1 ? 64 : 32; }
+inline bool is_expand(int kind) { return kind == 2 || kind == 4; }      // takes a materialised input (a block input)
+inline bool is_project(int kind) { return kind == 3 || kind == 5; }     // takes a producer's raw output (pending BatchNorm + ReLU)
+inline int tile_px(int kind) { return (kind == 1 || kind == 4) ? 64 : 32; }
 
 inline int slots_for(long P, int kind) {
   long gs = (P / tile_px(kind) + 7) / 8;
@@ -465,8 +471,8 @@ int tss_pwconv_bwd_sweep_preferred(long P, int Cin, int Cout, int x_pending, int
   static const int sw = getenv("TSS_PW_SWEEP") ? atoi(getenv("TSS_PW_SWEEP")) : 1;       // A/B switch: 0 = never
   static const long minp = getenv("TSS_PW_SWEEP_MINP") ? atol(getenv("TSS_PW_SWEEP_MINP")) : 32768;
   const int kind = shape_kind(Cin, Cout);
-  if (kind == 2 && x_pending) return 0;       // the expand instance takes a materialised input (a block input), the project instance a pending one
-  if (kind == 3 && !x_pending) return 0;
+  if (is_expand(kind) && x_pending) return 0;       // the expand instances take a materialised input (a block input), the project instances a pending one
+  if (is_project(kind) && !x_pending) return 0;
   return (sw && !g_tss_disable_fast && dtype == TSS_BF16 && kind && P >= minp && (P % tile_px(kind)) == 0) ? 1 : 0;
 }
 
@@ -482,7 +488,7 @@ int tss_pwconv_bwd_sweep(const void* e, long lde, const void* yraw, long ldyr, c
   const int kind = shape_kind(Cin, Cout);
   TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(kind && P > 0 && (P % tile_px(kind)) == 0 && e && x && e_in && ws && wT_bf16, TSS_ERR_SHAPE);
-  TSS_REQUIRE(!(kind == 2 && x_pending) && !(kind == 3 && !x_pending), TSS_ERR_SHAPE);
+  TSS_REQUIRE(!(is_expand(kind) && x_pending) && !(is_project(kind) && !x_pending), TSS_ERR_SHAPE);
   TSS_REQUIRE((lde % 8) == 0 && lde >= Cout && (ldx % 8) == 0 && ldx >= Cin && (ldei % 4) == 0 && ldei >= Cin, TSS_ERR_SHAPE);
   TSS_REQUIRE(lde < (1L << 20) && ldx < (1L << 20) && ldyr < (1L << 20) && ldr < (1L << 20), TSS_ERR_SHAPE);      // 32-bit lane offsets
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= Cout && ga && gb && gce && gmu), TSS_ERR_SHAPE);
@@ -503,7 +509,9 @@ int tss_pwconv_bwd_sweep(const void* e, long lde, const void* yraw, long ldyr, c
   const int gs = slots_for(P, kind);
   if (kind == 1) { if (x_pending) launch<CfgSq, true>(g, gs, (hipStream_t)stream); else launch<CfgSq, false>(g, gs, (hipStream_t)stream); }
   else if (kind == 2) launch<CfgExpand, false>(g, gs, (hipStream_t)stream);
-  else launch<CfgProject, true>(g, gs, (hipStream_t)stream);
+  else if (kind == 3) launch<CfgProject, true>(g, gs, (hipStream_t)stream);
+  else if (kind == 4) launch<CfgExpand32, false>(g, gs, (hipStream_t)stream);
+  else launch<CfgProject32, true>(g, gs, (hipStream_t)stream);
   return tss::check_last("pwconv_bwd_sweep");
 }
 
