@@ -97,6 +97,19 @@ int tss_pwconv_fwd_joined(const void* x, long ldx, const float* in_mean, const f
                           const float* out_mean, const float* out_scale, const float* out_beta,
                           const void* residual, long ldr, int out_relu, void* y, long ldy,
                           long P, int K, int N, int dtype, void* stream);
+/* A whole inverted residual with FROZEN statistics as ONE kernel (csrc/bneck.hip, round 4; bf16): 1x1 expand -> BatchNorm -> ReLU ->
+ * depthwise 3x3 (stride 1 | 2, padding 1) -> BatchNorm -> ReLU -> 1x1 project -> BatchNorm (+ x when residual) -> ReLU.
+ * replaces: BottleneckBlock.forward under model.eval(), TSS/models/fastscnn.py:152-161, TSS/models/contextnet.py:139-147 -- the two
+ *           6x-expanded tensors live in LDS only.  x: materialised NHWC [B][H][W][Cin]; y: NHWC [B][Ho][Wo][Cout], Ho = (H-1)/stride + 1.
+ * w1 [Cmid][Cin], wdw [Cmid][3][3], w3 [Cout][Cmid]: the f32 parameters; w1_bf16 / w3_bf16: optional current bf16 copies (tss_cast_weights).
+ * (mean_i, scale_i, beta_i): the BatchNorm behind layer i as tss_bn_eval_affine / tss_bn_eval_affine_batched write it.
+ * Cin <= 128 (multiple of 8), Cmid a multiple of 64, Cout <= 128 (multiple of 4); residual needs stride 1 and Cin == Cout. */
+int tss_bneck_eval_supported(int Cin, int Cmid, int Cout, int stride, int residual, int dtype);
+int tss_bneck_eval_fwd(const void* x, long ldx, const float* w1, const void* w1_bf16, const float* mean1, const float* scale1,
+                       const float* beta1, const float* wdw, const float* mean2, const float* scale2, const float* beta2,
+                       const float* w3, const void* w3_bf16, const float* mean3, const float* scale3, const float* beta3,
+                       int residual, void* y, long ldy, int B, int H, int W, int Cin, int Cmid, int Cout, int stride, int dtype,
+                       void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
  * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
  * wT_bf16 (optional, bf16 path): a current bf16 TRANSPOSE [K][N] of w written by tss_cast_weights.

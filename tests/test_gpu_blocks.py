@@ -783,3 +783,84 @@ def test_two_trainers_in_two_threads_do_not_share_scheduling_state():
         assert _same(got[i][1], want[i][1])
         for k in want[i][2]:
             assert _same(got[i][2][k], want[i][2][k]), (i, k)
+
+
+# ----------------------------------------------------------------------------- eval-mode inverted residual as one kernel (round 4)
+
+@pytest.mark.parametrize('cin,cout,stride,expansion,shape', [
+    (64, 64, 1, 6, (2, 64, 40, 72)), (64, 64, 2, 6, (2, 64, 40, 72)), (64, 96, 2, 6, (1, 64, 37, 53)), (96, 96, 1, 6, (2, 96, 19, 33)),
+    (96, 128, 1, 6, (1, 96, 32, 64)), (128, 128, 1, 6, (2, 128, 24, 40)), (64, 64, 1, 6, (1, 64, 128, 256)),
+    (32, 32, 1, 6, (2, 32, 30, 50)), (32, 48, 2, 6, (2, 32, 30, 50)), (48, 48, 1, 6, (1, 48, 16, 24))])
+@pytest.mark.parametrize('family', ['fast', 'ctx'])
+def test_eval_bottleneck_in_one_kernel_vs_f64_oracle_and_layer_by_layer(cin, cout, stride, expansion, shape, family):
+    """csrc/bneck.hip (model.eval(), no gradient, bf16: expand -> BN -> ReLU -> depthwise -> BN -> ReLU -> project -> BN -> (+ x) -> ReLU
+    in one kernel, the expanded tensors in LDS) against the reference's block in f64 with the bf16 storage format
+    (TSS/models/fastscnn.py:138-161, TSS/models/contextnet.py:129-147), bound = 3 x the oracle-vs-oracle noise distance + floor, and
+    against the product's own layer-by-layer eval path (TSS_BNECK_EVAL=0) as the yardstick: every tile shape (8 x 16, 8 x 8, stride 2),
+    ragged maps, channel counts of both models; 48 -> 288 is outside the kernel's envelope and must fall back silently."""
+    import importlib
+    import numpy as np
+    from torch import nn
+    import torch_semantic_segmentation_amd as tssa
+    from torch_semantic_segmentation_amd import ops
+    from oracle import nets as O
+    from oracle.bf16_storage import emulate_bf16_storage
+    mod = importlib.import_module('torch_semantic_segmentation_amd.models.' + ('fastscnn' if family == 'fast' else 'contextnet'))
+    torch.manual_seed(17)
+    ref = (O._FastResidual if family == 'fast' else O._CtxResidual)(cin, cout, stride=stride, expansion=expansion)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.copy_(m.weight.to(torch.bfloat16).float())
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    state = {k: v.clone() for k, v in ref.state_dict().items()}
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(*shape, generator=g).to(torch.bfloat16).float()
+
+    def oracle(dither):
+        r = (O._FastResidual if family == 'fast' else O._CtxResidual)(cin, cout, stride=stride, expansion=expansion)
+        r.load_state_dict(state)
+        r.double().eval()
+        emulate_bf16_storage(r, dither=dither)
+        with torch.no_grad():
+            return r(x.double()).numpy()
+    want = oracle(None)
+    na, nb = oracle(torch.Generator().manual_seed(1013)), oracle(torch.Generator().manual_seed(2017))
+
+    def hip(fused):
+        m = mod.BottleneckBlock(cin, cout, stride=stride, expansion=expansion)
+        m.load_state_dict(state, strict=True)
+        m.to(DEV).eval()
+        tssa.set_compute_dtype(m, torch.bfloat16)
+        old = ops.eval_bottleneck
+        ops.eval_bottleneck = fused
+        calls = []
+        orig = ops.bottleneck_eval
+
+        def spy(*a, **k):
+            out = orig(*a, **k)
+            calls.append(out is not None)
+            return out
+        ops.bottleneck_eval = spy
+        try:
+            with torch.no_grad():
+                out = ops.materialize(m(x.to(DEV).to(torch.bfloat16)))
+            torch.cuda.synchronize()
+        finally:
+            ops.eval_bottleneck = old
+            ops.bottleneck_eval = orig
+        return out.float().cpu().double().numpy(), calls
+    lean, calls1 = hip(True)
+    plain, calls0 = hip(False)
+    inside = (cin * expansion) % 64 == 0
+    assert calls1 == [inside] and calls0 == [False]
+    l2 = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    e_lean, e_plain, e_noise = l2(lean, want), l2(plain, want), l2(na, nb)
+    bound = min(3.0 * e_noise + 2e-4, 1e-2)
+    assert e_lean <= bound, (e_lean, e_plain, e_noise, bound)
+    assert e_lean <= 2.0 * e_plain + 4e-3, (e_lean, e_plain)
+    assert np.isfinite(lean).all()

@@ -57,6 +57,11 @@ class BottleneckBlock(nn.Module):
         x = ops.to_nhwc(ops.materialize(input))
         # shape-equal skip: the block input has two consumers; their gradients meet in the epilogue of conv1's backward-data kernel
         # (ops.residual_fork) instead of in an elementwise launch of autograd's
+        if not (has_hooks(self.conv1) or has_hooks(self.conv2) or has_hooks(self.conv3)):
+            # model.eval(), no gradient, bf16: the whole block as one kernel, the 6x-expanded tensors in LDS only (csrc/bneck.hip)
+            out = ops.bottleneck_eval(x, self.conv1, self.conv2, self.conv3)
+            if out is not None:
+                return out
         c1, c2, c3 = self.conv1[0], self.conv2[0], self.conv3[0]
         residual = tuple(c2.stride) == (1, 1) and c1.in_channels == c3.out_channels and not has_hooks(self.conv1)
         xa, xb, fork = ops.residual_fork(x) if residual else (x, x, None)

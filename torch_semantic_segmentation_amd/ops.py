@@ -968,6 +968,64 @@ def conv_unit_joined(x, block, residual=None, relu=True):
     return y
 
 
+eval_bottleneck = os.environ.get('TSS_BNECK_EVAL', '1') != '0'     # A/B: 0 = eval-mode inverted residuals layer by layer
+
+
+def bottleneck_eval(x, conv1, conv2, conv3):
+    """Eval-mode, no-grad form of a whole inverted residual -- conv1 (1x1, BatchNorm, ReLU) -> conv2 (depthwise 3x3, BatchNorm, ReLU) ->
+    conv3 (1x1, BatchNorm) -> (+ x) -> ReLU, each convN a FusedSequential as the block builders make them -- as ONE kernel
+    (csrc/bneck.hip: the expanded tensors live in LDS only; BottleneckBlock.forward of both models under model.eval(),
+    TSS/models/fastscnn.py:152-161, TSS/models/contextnet.py:139-147).  Returns the materialised block output, or None when the call
+    is outside that envelope (gradients, batch statistics, f32, hooks, channel counts: the caller goes layer by layer)."""
+    if not eval_bottleneck or torch.is_grad_enabled() or N.fast_paths_disabled():
+        return None
+    if not (torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16):
+        return None
+    parts = []
+    for blk, want_relu in ((conv1, True), (conv2, True), (conv3, False)):
+        mods = list(blk) if isinstance(blk, torch.nn.Sequential) else None
+        if mods is None or len(mods) != (3 if want_relu else 2) or not isinstance(mods[0], torch.nn.Conv2d) \
+                or not isinstance(mods[1], _BatchNorm) or (want_relu and not isinstance(mods[2], torch.nn.ReLU)):
+            return None
+        conv, bn = mods[0], mods[1]
+        if bn.training or bn.running_mean is None or bn.running_var is None or conv.bias is not None \
+                or conv.weight.dtype != torch.float32 or (bn.weight is not None and bn.weight.dtype != torch.float32):
+            return None
+        parts.append((conv, bn))
+    (c1, bn1), (c2, bn2), (c3, bn3) = parts
+    try:
+        k1, k2, k3 = _classify(c1, False), _classify(c2, False), _classify(c3, False)
+    except NotImplementedError:
+        return None
+    if k1[0] != 'pw' or k3[0] != 'pw' or k2[0] != 'dw' or k2[2] != 1 or k2[1] not in (1, 2):
+        return None
+    B, Cin, H, W = x.shape
+    Cmid, Cout, stride = c1.out_channels, c3.out_channels, k2[1]
+    if c1.in_channels != Cin or c2.in_channels != Cmid or c3.in_channels != Cmid:
+        return None
+    residual = int(stride == 1 and Cin == Cout)
+    dt = N.dtype_code(x.dtype)
+    if not N.lib().tss_bneck_eval_supported(Cin, Cmid, Cout, stride, residual, dt):
+        return None
+    x = to_nhwc(x)
+    dev, st = x.device, stream()
+    links = []
+    for bn, C in ((bn1, Cmid), (bn2, Cmid), (bn3, Cout)):
+        gamma, beta = _f32(bn.weight), _f32(bn.bias)
+        link = BNLink(C, 1, False, gamma, beta, dev, slabs=False)
+        _finalize_forward(link, bn, False, 1, C, gamma, st)
+        links.append((link, beta))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = new_nhwc(B, Cout, Ho, Wo, x.dtype, dev)
+    aff = []
+    for link, beta in links:
+        aff += [ptr(link.mean), ptr(link.scale), ptr(beta if beta is not None else torch.zeros_like(link.mean))]
+    call('tss_bneck_eval_fwd', ptr(x), ld(x), ptr(c1.weight), _shadow(c1.weight, 0), aff[0], aff[1], aff[2],
+         ptr(c2.weight), aff[3], aff[4], aff[5], ptr(c3.weight), _shadow(c3.weight, 0), aff[6], aff[7], aff[8],
+         residual, ptr(y), ld(y), B, H, W, Cin, Cmid, Cout, stride, dt, st)
+    return y
+
+
 def _f32(p):
     if p is None or p.dtype == torch.float32:
         return p
