@@ -790,7 +790,8 @@ def test_two_trainers_in_two_threads_do_not_share_scheduling_state():
 @pytest.mark.parametrize('cin,cout,stride,expansion,shape', [
     (64, 64, 1, 6, (2, 64, 40, 72)), (64, 64, 2, 6, (2, 64, 40, 72)), (64, 96, 2, 6, (1, 64, 37, 53)), (96, 96, 1, 6, (2, 96, 19, 33)),
     (96, 128, 1, 6, (1, 96, 32, 64)), (128, 128, 1, 6, (2, 128, 24, 40)), (64, 64, 1, 6, (1, 64, 128, 256)),
-    (32, 32, 1, 6, (2, 32, 30, 50)), (32, 48, 2, 6, (2, 32, 30, 50)), (48, 48, 1, 6, (1, 48, 16, 24))])
+    (32, 32, 1, 6, (2, 32, 30, 50)), (32, 48, 2, 6, (2, 32, 30, 50)), (48, 48, 1, 6, (1, 48, 16, 24)),
+    (128, 128, 1, 6, (1, 128, 64, 128)), (96, 96, 1, 6, (1, 96, 13, 21))])
 @pytest.mark.parametrize('family', ['fast', 'ctx'])
 def test_eval_bottleneck_in_one_kernel_vs_f64_oracle_and_layer_by_layer(cin, cout, stride, expansion, shape, family):
     """csrc/bneck.hip (model.eval(), no gradient, bf16: expand -> BN -> ReLU -> depthwise -> BN -> ReLU -> project -> BN -> (+ x) -> ReLU
