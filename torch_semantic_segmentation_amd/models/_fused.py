@@ -120,8 +120,9 @@ class FusedSequential(nn.Sequential):
 
     act_dtype = None  # set on stems by set_compute_dtype(): dtype of the first activation
 
-    def unit(self, d):
-        mods = list(self)
+    def unit(self, d, upto=None):
+        """upto: run only the first `upto` children (the caller finishes the chain itself, e.g. with a fused epilogue)"""
+        mods = list(self) if upto is None else list(self)[:upto]
         i, n = 0, len(mods)
         while i < n:
             m = mods[i]

@@ -144,6 +144,17 @@ class FeatureFusionModule(nn.Module):
             Conv2dBlock(highres_channels, out_channels, kernel_size=1, use_activation=False))
 
     def forward(self, lowres, highres):
+        if not torch.is_grad_enabled() and not (has_hooks(self.lowres) or has_hooks(self.highres)) and len(self.lowres) == 3 \
+                and len(self.highres) == 1:
+            # model.eval(), no gradient: no join pass -- the low-resolution branch's last layer writes BN(conv) itself, the high-resolution
+            # layer adds it and applies the ReLU in its own epilogue (tss_pwconv_fwd_joined): two writes + one read instead of
+            # two writes + two reads + one write
+            d2 = self.lowres.unit(lowres, upto=2)
+            low = ops.conv_unit_joined(d2, self.lowres[2], None, relu=False)
+            if low is None:                    # outside the fused epilogue's envelope (f32, channel counts): the ordinary chain
+                return ops.join(run(self.lowres[2], d2), run(self.highres, highres), relu=True)
+            out = ops.conv_unit_joined(highres, self.highres[0], low, relu=True)
+            return out if out is not None else ops.join(low, run(self.highres, highres), relu=True)
         return ops.join(run(self.lowres, lowres), run(self.highres, highres), relu=True)
 
 
