@@ -110,6 +110,28 @@ int tss_bneck_eval_fwd(const void* x, long ldx, const float* w1, const void* w1_
                        const float* w3, const void* w3_bf16, const float* mean3, const float* scale3, const float* beta3,
                        int residual, void* y, long ldy, int B, int H, int W, int Cin, int Cmid, int Cout, int stride, int dtype,
                        void* stream);
+/* ---- cross-replica (Sync) BatchNorm with the exchange INSIDE the finalize kernel (csrc/xchg.hip, round 4) ----------------------
+ * replaces: apex.parallel.convert_syncbn_model's two collectives per layer (TSS scripts/train_fastscnn.py:144-145) for the ranks of ONE
+ * node: every rank owns a mailbox in fine-grained device memory (tss_ipc_alloc, tss_bn_xchg_bytes() bytes), maps the mailboxes of its
+ * peers through HIP IPC (tss_ipc_open on their 64-byte handles) and passes the world's pointers, rank-indexed, to the finalize
+ * kernels below; block b of the grid reduces the slab rows of its 8 channels, writes them into its cell of every mailbox, waits
+ * (bounded: tss_bn_xchg_error) for the peers' cells and adds them up in rank order.  counters: tss_bn_xchg_counters() zero-filled
+ * 64-bit words of ordinary device memory per rank (call counters; a replayed HIP graph advances them on the device).
+ * Semantics of tss_bn_finalize_sync / tss_bn_bwd_finalize_sync (global statistics forward; global sums for the input gradient,
+ * the replica's own for d(gamma), d(beta)).  C <= 768. */
+long tss_bn_xchg_bytes(void);
+int tss_bn_xchg_counters(void);
+int tss_ipc_alloc(long bytes, void** ptr_out, void* handle_out);
+int tss_ipc_open(const void* handle, void** ptr_out);
+int tss_ipc_close(void* ptr);
+int tss_ipc_free(void* ptr);
+int tss_bn_xchg_error(const void* mailbox, long* out);
+int tss_bn_finalize_xchg(const double* sums, double count, const void* const* peers, int rank, int world, void* counters,
+                         const float* gamma, float eps, float momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float* mean_out, float* invstd_out, float* scale, int C, void* stream);
+int tss_bn_bwd_finalize_xchg(const double* bstats, double count, const void* const* peers, int rank, int world, void* counters,
+                             const float* invstd, const float* gamma, int accumulate, float* dgamma, float* dbeta,
+                             float* ga, float* gb, float* gce, int C, void* stream);
 /* e_in[p][k] = relu'(act(x))[p][k] * sum_n g[p][n] w[n][k],  g = ga*(e-gce) + gb*(yraw-gmu);
  * bstats (optional) = partial sums of e_in and e_in * (xraw - in_mean).  xraw/in_* NULL: plain dX, no mask.
  * wT_bf16 (optional, bf16 path): a current bf16 TRANSPOSE [K][N] of w written by tss_cast_weights.

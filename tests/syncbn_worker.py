@@ -54,7 +54,11 @@ if __name__ == '__main__':
         g = p.grad.detach().clone()
         dist.all_reduce(g)                       # sum over the ranks == gradient of the global sum-loss
         grads[n] = g.cpu()
+    from torch_semantic_segmentation_amd import ops
+    exs = [e for e in ops._XCHG.values()]
+    ipc = bool(exs) and all(e is not None for e in exs)
+    xerr = max([e.error() for e in exs if e is not None] or [0])
     if rank == 0:
-        torch.save({'out': out.cpu(), 'grads': grads,
+        torch.save({'out': out.cpu(), 'grads': grads, 'ipc': ipc, 'xerr': xerr,
                     'buffers': {n: b.detach().cpu() for n, b in model.named_buffers()}}, sys.argv[1])
     dist.barrier()

@@ -79,6 +79,8 @@ def lib():
         handle.tss_upsample_ce_ws.restype = ctypes.c_long
         handle.tss_ohem_workspace_bytes.argtypes = []
         handle.tss_ohem_workspace_bytes.restype = ctypes.c_long
+        handle.tss_bn_xchg_bytes.argtypes = []
+        handle.tss_bn_xchg_bytes.restype = ctypes.c_long
         _lib = handle
     return _lib
 

@@ -354,7 +354,14 @@ class Trainer:
             # ~10^3 host launches per step).
             import warnings
             backend = dist.get_backend() if dist.is_initialized() else None
-            if backend != 'nccl':
+            dev = next(self.model.parameters()).device
+            groups = {id(g): g for g in (ops._sync_group(m, any_mode=True) for m in self.model.modules()
+                                         if isinstance(m, nn.modules.batchnorm._BatchNorm)) if g is not None}
+            if groups and all(ops._exchange(g, dev) is not None for g in groups.values()):
+                # round 4: the statistics cross the ranks INSIDE the finalize kernels (mailboxes over HIP IPC, csrc/xchg.hip): the step
+                # contains no collective at all and is captured like any other, whatever the backend of the process group
+                pass
+            elif backend != 'nccl':
                 warnings.warn('SyncBatchNorm over the %s backend: the training step is not captured in a HIP graph' % backend)
                 self.use_graph = False
             else:

@@ -725,6 +725,74 @@ def _sync_group(bn, any_mode=False):
     return group if (dist.get_world_size(group) > 1 or os.environ.get('TSS_SYNCBN_FORCE') == '1') else None
 
 
+# ---- the exchange inside the finalize kernels (csrc/xchg.hip): mailboxes of the ranks of one node, mapped through HIP IPC
+syncbn_ipc = os.environ.get('TSS_SYNCBN_IPC', '1') != '0'       # 0: every BatchNorm statistic through dist.all_reduce (RCCL), as in round 3
+_XCHG = {}
+
+
+class _Exchange:
+    """This rank's mailbox + the peers' mailboxes as mapped into this process, for one (process group, device)."""
+
+    def __init__(self, group, device):
+        import socket
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = device
+        if self.world > 8:
+            raise RuntimeError('more than 8 ranks')
+        nbytes = N.lib().tss_bn_xchg_bytes()
+        own, handle = ctypes.c_void_p(), (ctypes.c_char * 64)()
+        with torch.cuda.device(device):
+            call('tss_ipc_alloc', nbytes, ctypes.byref(own), handle)
+            self.own = own.value
+            me = (socket.gethostname(), os.getpid(), bytes(handle.raw))
+            everyone = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(everyone, me, group=group)       # (also the barrier behind which every mailbox is zero-filled)
+            else:
+                everyone[0] = me
+            if len({h for h, _, _ in everyone}) != 1:
+                call('tss_ipc_free', self.own)
+                raise RuntimeError('the ranks of the group are not on one node')
+            self.mapped = []
+            ptrs = []
+            for r, (_, pid, hb) in enumerate(everyone):
+                if r == self.rank:
+                    ptrs.append(self.own)
+                    continue
+                if pid == os.getpid():
+                    raise RuntimeError('two ranks in one process')
+                p_ = ctypes.c_void_p()
+                call('tss_ipc_open', ctypes.create_string_buffer(hb, 64), ctypes.byref(p_))
+                self.mapped.append(p_.value)
+                ptrs.append(p_.value)
+        self.peers = (ctypes.c_void_p * self.world)(*ptrs)
+        self.counters = torch.zeros(N.lib().tss_bn_xchg_counters(), dtype=torch.int64, device=device)
+        if self.world > 1:
+            dist.barrier(group=group)          # every rank has mapped every mailbox before anybody writes
+
+    def error(self):
+        out = ctypes.c_long(0)
+        with torch.cuda.device(self.device):
+            call('tss_bn_xchg_error', self.own, ctypes.byref(out))
+        return out.value
+
+
+def _exchange(group, device):
+    """The IPC exchange of `group` on `device`, or None (switched off, set-up failed: the caller uses dist.all_reduce)."""
+    if not syncbn_ipc:
+        return None
+    key = (id(group), device.index)
+    if key not in _XCHG:
+        try:
+            _XCHG[key] = _Exchange(group, device)
+        except Exception as exc:       # noqa: BLE001 -- any failure of the IPC set-up: the collective library still works
+            import warnings
+            warnings.warn('SyncBatchNorm: HIP IPC exchange unavailable (%s); using dist.all_reduce' % (exc,))
+            _XCHG[key] = None
+    return _XCHG[key]
+
+
 def _allreduce_stats(slabs, count, C, group, st):
     """slab rows of this replica -> [2C+1] f64 (sums, second moments, count), summed over the ranks."""
     import torch.distributed as dist
@@ -1082,7 +1150,12 @@ def _finalize_forward(link, bn, training, P, Cout, gamma, st):
         run_args = (ptr(rbuf.mean), ptr(rbuf.var),
                     ptr(bn.num_batches_tracked) if (track and bn.num_batches_tracked is not None) else None)
         link.sync = _sync_group(bn)
-        if link.sync is not None:
+        ex = _exchange(link.sync, link.stats.device) if (link.sync is not None and Cout <= 768) else None
+        if ex is not None:
+            # slab rows -> statistics of ALL ranks inside ONE kernel (mailboxes over HIP IPC): no collective, no extra launch
+            call('tss_bn_finalize_xchg', ptr(link.stats), float(P), ex.peers, ex.rank, ex.world, ptr(ex.counters), ptr(gamma),
+                 float(bn.eps), float(bn.momentum), *run_args, ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
+        elif link.sync is not None:
             gs = _allreduce_stats(link.stats, P, Cout, link.sync, st)
             call('tss_bn_finalize_sync', ptr(gs), ptr(gamma), float(bn.eps), float(bn.momentum), *run_args,
                  ptr(link.mean), ptr(link.invstd), ptr(link.scale), Cout, st)
@@ -1201,7 +1274,12 @@ class ConvUnitFn(Function):
                 else:
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
-            if link.sync is not None:
+            ex = _exchange(link.sync, link.bstats.device) if (link.sync is not None and Cout <= 768) else None
+            if ex is not None:
+                _flush_wg(st)
+                call('tss_bn_bwd_finalize_xchg', ptr(link.bstats), float(link.count), ex.peers, ex.rank, ex.world, ptr(ex.counters),
+                     ptr(link.invstd), ptr(link.gamma), acc, ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
+            elif link.sync is not None:
                 _flush_wg(st)
                 gs = _allreduce_stats(link.bstats, link.count, Cout, link.sync, st)
                 call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), acc,
