@@ -43,6 +43,10 @@ extern "C" {
 typedef struct tss_bn_bwd_job {
   const double* bstats; double count; const float* invstd; const float* gamma; int training; int accumulate;
   float* dgamma; float* dbeta; float* ga; float* gb; float* gce; int C;
+  /* cross-replica statistics (round 4, csrc/xchg.hip): xchg_world > 0 -- the sums cross the ranks inside the finalize blocks, as
+   * tss_bn_bwd_finalize_xchg does (peers: the world's mailboxes as mapped into this process, rank-indexed; counters: this rank's
+   * call counters); xchg_world == 0: this replica's own statistics */
+  int xchg_world; int xchg_rank; void* xchg_peers[8]; void* xchg_counters;
 } tss_bn_bwd_job;
 
 /* kernel ids for the profiler (tss_prof_*) */

@@ -47,11 +47,87 @@ __device__ __forceinline__ void slab_sum(const double* slabs, int C, int blk, do
 }
 
 
+// ---- the exchange of cross-replica BatchNorm statistics inside a finalize block (see csrc/xchg.hip for the protocol)
+constexpr int XMAXB = 96;                 // blocks per exchange: channels <= 768, 8 per block
+constexpr int XCELL = 18;                 // 64-bit words per cell: 16 sums, the count, the flag
+constexpr int XSLOTS = 4;
+constexpr int XMAXW = 8;                  // ranks of one node
+constexpr long XHEAD = 8;                 // header words: [0] error code (1: a peer's flag did not arrive in time)
+
+__host__ __device__ inline long cell_off(int slot, int rank, int blk) { return XHEAD + (((long)slot * XMAXW + rank) * XMAXB + blk) * XCELL; }
+
+struct Xchg {
+  unsigned long long* peers[XMAXW];       // every rank's mailbox as mapped into THIS process (peers[rank] = our own)
+  int rank, world;
+  unsigned long long* ctr;                // [XMAXB] call counters of this rank (ordinary device memory)
+};
+
+__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// (a, b) of thread t < FIN_CH: this rank's two sums of channel blk * FIN_CH + t; cnt: its element count.  Returns the sums over
+// all ranks (valid for t < FIN_CH) and the global count.  The whole exchange is done by WAVE 0 of the block (the 8 threads that hold
+// the sums, the <= 8 pollers and the flag writer are all in it), so the only ordering it needs is the wave's own: data stores
+// (system scope: write-through, past every cache) -> s_waitcnt vmcnt(0) -> flag store; flag poll -> data loads, all system-scope loads.
+// No __threadfence_system (an L2 write-back + invalidate, ~3.5 us each way) and no block barrier.
+__device__ __forceinline__ void exchange(const Xchg& x, int blk, double& a, double& b, double& cnt) {
+  const int t = threadIdx.x;
+  if (t >= 64) return;
+  unsigned long long seq = (t == 0) ? x.ctr[blk] + 1ull : 0ull;
+  seq = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(seq >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)seq);
+  const int slot = (int)(seq % XSLOTS);
+  if (t < FIN_CH) {
+    for (int p = 0; p < x.world; ++p) {
+      unsigned long long* cell = x.peers[p] + cell_off(slot, x.rank, blk);
+      st_sys(cell + 2 * t, (unsigned long long)__double_as_longlong(a));
+      st_sys(cell + 2 * t + 1, (unsigned long long)__double_as_longlong(b));
+      if (t == 0) st_sys(cell + 16, (unsigned long long)__double_as_longlong(cnt));
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every data store of the wave has been acknowledged
+  if (t == 0) {
+    for (int p = 0; p < x.world; ++p) st_sys(x.peers[p] + cell_off(slot, x.rank, blk) + 17, seq);
+  }
+  // the peers' cells arrive in OUR mailbox: one poller per rank, bounded (~4 s of the 100 MHz wall clock)
+  if (t < x.world) {
+    const unsigned long long* flag = x.peers[x.rank] + cell_off(slot, t, blk) + 17;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (ld_sys(flag) != seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+        st_sys(x.peers[x.rank], 1ull);          // error word of our own mailbox (tss_bn_xchg_error)
+        break;
+      }
+    }
+  }
+  // (the wave reconverges here: every poller has seen its flag before any lane loads a cell)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    double sa = 0.0, sb = 0.0, sc = 0.0;
+    const int tt = t < FIN_CH ? t : 0;
+    for (int p = 0; p < x.world; ++p) {    // rank order: the same sum, bit for bit, on every rank
+      const unsigned long long* cell = x.peers[x.rank] + cell_off(slot, p, blk);
+      sa += __longlong_as_double((long long)ld_sys(cell + 2 * tt));
+      sb += __longlong_as_double((long long)ld_sys(cell + 2 * tt + 1));
+      sc += __longlong_as_double((long long)ld_sys(cell + 16));
+    }
+    if (t < FIN_CH) { a = sa; b = sb; }
+    cnt = sc;
+  }
+  if (t == 0) x.ctr[blk] = seq;
+}
+
+
 // bstats = [sum(e), sum(e*(y-mean))] over the N = count elements of each channel (centred: no cancellation).
 // training: g = k*(e - c1 - xhat*c2), k = gamma*invstd, c1 = sum(e)/N, c2 = sum(e*xhat)/N, xhat = (y-mean)*invstd
 //           =>  g = ga*(e - ce) + gb*(y - mean)   with ga = k, ce = c1, gb = -k*c2*invstd
 // frozen  : g = k*e
-// One block of FIN_NT threads finalizes channels [blk * FIN_CH, (blk + 1) * FIN_CH).
+// One block of FIN_NT threads finalizes channels [blk * FIN_CH, (blk + 1) * FIN_CH).  j.xchg_world > 0 (cross-replica statistics,
+// apex semantics): the input gradient uses the GLOBAL sums, d(gamma) / d(beta) this replica's own.
 __device__ __forceinline__ void bn_bwd_finalize_block(const tss_bn_bwd_job& j, int blk) {
   const int C = j.C;
   const int cp = min(blk * FIN_CH + (int)(threadIdx.x & (FIN_CH - 1)), C - 1);
@@ -62,15 +138,22 @@ __device__ __forceinline__ void bn_bwd_finalize_block(const tss_bn_bwd_job& j, i
   double se, sey;
   int c;
   slab_sum(j.bstats, C, blk, &se, &sey, &c);
+  const double se_l = se, sey_l = sey;
+  double cnt = j.count;
+  if (j.xchg_world > 0) {
+    Xchg x;
+#pragma unroll
+    for (int p = 0; p < XMAXW; ++p) x.peers[p] = (unsigned long long*)j.xchg_peers[p];
+    x.rank = j.xchg_rank; x.world = j.xchg_world; x.ctr = (unsigned long long*)j.xchg_counters;
+    exchange(x, blk, se, sey, cnt);
+  }
   if (threadIdx.x >= FIN_CH || c >= C) return;
   const double r = r_in;
-  const double dg = r * sey;
-  const double db = se;
-  if (j.dgamma) j.dgamma[c] = (j.accumulate ? dg_in : 0.f) + (float)dg;
-  if (j.dbeta) j.dbeta[c] = (j.accumulate ? db_in : 0.f) + (float)db;
+  if (j.dgamma) j.dgamma[c] = (j.accumulate ? dg_in : 0.f) + (float)(r * sey_l);
+  if (j.dbeta) j.dbeta[c] = (j.accumulate ? db_in : 0.f) + (float)se_l;
   const double k = (j.gamma ? (double)g_in : 1.0) * r;
   if (j.training) {
-    const double c1 = db / j.count, c2 = dg / j.count;
+    const double c1 = se / cnt, c2 = r * sey / cnt;
     j.ga[c] = (float)k;
     j.gb[c] = (float)(-k * c2 * r);
     j.gce[c] = (float)c1;

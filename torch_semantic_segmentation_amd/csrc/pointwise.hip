@@ -603,7 +603,7 @@ int tss_bn_bwd_finalize(const double* bstats, double count, const float* invstd,
                         float* ga, float* gb, float* gce, int C, void* stream) {
   TSS_REQUIRE(C > 0 && count >= 1.0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
-  const tss_bn_bwd_job j = {bstats, count, invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C};
+  tss_bn_bwd_job j = {bstats, count, invstd, gamma, training, accumulate, dgamma, dbeta, ga, gb, gce, C};      // (xchg_world = 0: local statistics)
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(fin_blocks(C)), dim3(FIN_NT), 0, (hipStream_t)stream, j);
   return tss::check_last("bn_bwd_finalize");
 }

@@ -23,81 +23,7 @@
 
 namespace {
 
-using namespace tss_fin;
-
-constexpr int XMAXB = 96;                 // blocks per exchange: channels <= 768, 8 per block
-constexpr int XCELL = 18;                 // 64-bit words per cell: 16 sums, the count, the flag
-constexpr int XSLOTS = 4;
-constexpr int XMAXW = 8;                  // ranks of one node
-constexpr long XHEAD = 8;                 // header words: [0] error code (1: a peer's flag did not arrive in time)
-
-__host__ __device__ inline long cell_off(int slot, int rank, int blk) { return XHEAD + (((long)slot * XMAXW + rank) * XMAXB + blk) * XCELL; }
-
-struct Xchg {
-  unsigned long long* peers[XMAXW];       // every rank's mailbox as mapped into THIS process (peers[rank] = our own)
-  int rank, world;
-  unsigned long long* ctr;                // [XMAXB] call counters of this rank (ordinary device memory)
-};
-
-__device__ __forceinline__ void st_sys(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned long long ld_sys(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// (a, b) of thread t < FIN_CH: this rank's two sums of channel blk * FIN_CH + t; cnt: its element count.  Returns the sums over
-// all ranks (valid for t < FIN_CH) and the global count.
-__device__ __forceinline__ void exchange(const Xchg& x, int blk, double& a, double& b, double& cnt) {
-  __shared__ unsigned long long s_seq;
-  const int t = threadIdx.x;
-  if (t == 0) s_seq = x.ctr[blk] + 1ull;
-  __syncthreads();
-  const unsigned long long seq = s_seq;
-  const int slot = (int)(seq % XSLOTS);
-  if (t < FIN_CH) {
-    for (int p = 0; p < x.world; ++p) {
-      unsigned long long* cell = x.peers[p] + cell_off(slot, x.rank, blk);
-      st_sys(cell + 2 * t, (unsigned long long)__double_as_longlong(a));
-      st_sys(cell + 2 * t + 1, (unsigned long long)__double_as_longlong(b));
-      if (t == 0) st_sys(cell + 16, (unsigned long long)__double_as_longlong(cnt));
-    }
-    __threadfence_system();                // the data before the flag, for every observer of the node
-  }
-  __syncthreads();
-  if (t == 0) {
-    for (int p = 0; p < x.world; ++p) st_sys(x.peers[p] + cell_off(slot, x.rank, blk) + 17, seq);
-  }
-  // the peers' cells arrive in OUR mailbox: one poller per rank, bounded (~4 s of the 100 MHz wall clock)
-  if (t < x.world) {
-    const unsigned long long* flag = x.peers[x.rank] + cell_off(slot, t, blk) + 17;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    bool ok = true;
-    while (ld_sys(flag) != seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) { ok = false; break; }
-    }
-    if (!ok) st_sys(x.peers[x.rank], 1ull);          // error word of our own mailbox (tss_bn_xchg_error)
-    __threadfence_system();
-  }
-  __syncthreads();
-  if (t < FIN_CH) {
-    double sa = 0.0, sb = 0.0;
-    for (int p = 0; p < x.world; ++p) {    // rank order: the same sum, bit for bit, on every rank
-      const unsigned long long* cell = x.peers[x.rank] + cell_off(slot, p, blk);
-      sa += __longlong_as_double((long long)ld_sys(cell + 2 * t));
-      sb += __longlong_as_double((long long)ld_sys(cell + 2 * t + 1));
-    }
-    a = sa; b = sb;
-  }
-  {
-    double sc = 0.0;
-    for (int p = 0; p < x.world; ++p) sc += __longlong_as_double((long long)ld_sys(x.peers[x.rank] + cell_off(slot, p, blk) + 16));
-    cnt = sc;
-  }
-  __syncthreads();
-  if (t == 0) x.ctr[blk] = seq;
-}
+using namespace tss_fin;      // Xchg, exchange(), cell_off() live in bnfin.h: the riding finalize blocks of wgrad.hip use them too
 
 __global__ __launch_bounds__(FIN_NT) void bn_finalize_xchg_kernel(const double* sums, double count, const Xchg x, const float* gamma,
                                                                   float eps, float momentum, float* running_mean, float* running_var,
@@ -129,31 +55,7 @@ __global__ __launch_bounds__(FIN_NT) void bn_finalize_xchg_kernel(const double* 
   }
 }
 
-// apex semantics: the input gradient uses the GLOBAL sums of e and e * (y - mean), d(gamma) / d(beta) this replica's own
-// (the gradient all-reduce of the data-parallel step adds those)
-__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_xchg_kernel(const double* bstats, double count, const Xchg x, const float* invstd,
-                                                                      const float* gamma, int accumulate, float* dgamma, float* dbeta,
-                                                                      float* ga, float* gb, float* gce, int C) {
-  const int cp = min(blockIdx.x * FIN_CH + (int)(threadIdx.x & (FIN_CH - 1)), C - 1);
-  const float r_in = invstd[cp];
-  const float g_in = (gamma ? gamma : invstd)[cp];
-  const float dg_in = (dgamma ? dgamma : invstd)[cp];
-  const float db_in = (dbeta ? dbeta : invstd)[cp];
-  double se, sey, cnt = count;
-  int c;
-  slab_sum(bstats, C, blockIdx.x, &se, &sey, &c);
-  const double se_l = se, sey_l = sey;
-  exchange(x, blockIdx.x, se, sey, cnt);
-  if (threadIdx.x >= FIN_CH || c >= C) return;
-  const double r = r_in;
-  if (dgamma) dgamma[c] = (accumulate ? dg_in : 0.f) + (float)(r * sey_l);
-  if (dbeta) dbeta[c] = (accumulate ? db_in : 0.f) + (float)se_l;
-  const double k = (gamma ? (double)g_in : 1.0) * r;
-  const double c1 = se / cnt, c2 = r * sey / cnt;       // global means of e and e * xhat
-  ga[c] = (float)k;
-  gb[c] = (float)(-k * c2 * r);
-  gce[c] = (float)c1;
-}
+__global__ __launch_bounds__(FIN_NT) void bn_bwd_finalize_xchg_kernel(const tss_bn_bwd_job j) { bn_bwd_finalize_block(j, blockIdx.x); }
 
 bool fill(Xchg& x, const void* const* peers, int rank, int world, unsigned long long* ctr) {
   if (!peers || !ctr || world < 1 || world > XMAXW || rank < 0 || rank >= world) return false;
@@ -234,8 +136,10 @@ int tss_bn_bwd_finalize_xchg(const double* bstats, double count, const void* con
   Xchg x = {};
   TSS_REQUIRE(fill(x, peers, rank, world, (unsigned long long*)counters), TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_BN_BWD_FINALIZE, (hipStream_t)stream, 48.0 * C, 0);
-  hipLaunchKernelGGL(bn_bwd_finalize_xchg_kernel, dim3(fin_blocks(C)), dim3(FIN_NT), 0, (hipStream_t)stream, bstats, count, x, invstd,
-                     gamma, accumulate, dgamma, dbeta, ga, gb, gce, C);
+  tss_bn_bwd_job j = {bstats, count, invstd, gamma, 1, accumulate, dgamma, dbeta, ga, gb, gce, C};
+  j.xchg_world = world; j.xchg_rank = rank; j.xchg_counters = counters;
+  for (int p = 0; p < world; ++p) j.xchg_peers[p] = (void*)peers[p];
+  hipLaunchKernelGGL(bn_bwd_finalize_xchg_kernel, dim3(fin_blocks(C)), dim3(FIN_NT), 0, (hipStream_t)stream, j);
   return tss::check_last("bn_bwd_finalize_xchg");
 }
 

@@ -97,7 +97,8 @@ class BnBwdJob(ctypes.Structure):
     """tss_bn_bwd_job of include/tss_hip.h."""
     _fields_ = [('bstats', ctypes.c_void_p), ('count', ctypes.c_double), ('invstd', ctypes.c_void_p), ('gamma', ctypes.c_void_p),
                 ('training', ctypes.c_int), ('accumulate', ctypes.c_int), ('dgamma', ctypes.c_void_p), ('dbeta', ctypes.c_void_p),
-                ('ga', ctypes.c_void_p), ('gb', ctypes.c_void_p), ('gce', ctypes.c_void_p), ('C', ctypes.c_int)]
+                ('ga', ctypes.c_void_p), ('gb', ctypes.c_void_p), ('gce', ctypes.c_void_p), ('C', ctypes.c_int),
+                ('xchg_world', ctypes.c_int), ('xchg_rank', ctypes.c_int), ('xchg_peers', ctypes.c_void_p * 8), ('xchg_counters', ctypes.c_void_p)]
 
 
 def _backward_task():
@@ -187,8 +188,19 @@ def _end_of_backward(task):
 
 def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
     """BatchNorm-backward coefficients + d(gamma), d(beta) of `link`: in front of a postponed weight-gradient grid of the same
-    stream (and the same pass) when there is one (no launch of its own), else tss_bn_bwd_finalize."""
+    stream (and the same pass) when there is one (no launch of its own), else tss_bn_bwd_finalize.  A cross-replica BatchNorm
+    (link.sync): the sums cross the ranks inside the same finalize blocks, riding or not (IPC exchange, csrc/xchg.hip) -- or, without
+    the exchange, through the process group's all-reduce."""
     training = int(link.training if training is None else training)
+    ex = None
+    if link.sync is not None:
+        ex = _exchange(link.sync, link.bstats.device) if C <= 768 else None
+        if ex is None:
+            _flush_wg(st)
+            gs = _allreduce_stats(link.bstats, link.count, C, link.sync, st)
+            call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), int(acc),
+                 ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
+            return
     ps = _cur_pass()
     ent = None
     if ps is not None:
@@ -201,7 +213,15 @@ def _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st, training=None):
     if ent is not None:
         job = BnBwdJob(ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
                        ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), int(C))
+        if ex is not None:
+            job.xchg_world, job.xchg_rank, job.xchg_counters = ex.world, ex.rank, ptr(ex.counters)
+            for r_ in range(ex.world):
+                job.xchg_peers[r_] = ex.peers[r_]
         ent[0](job)
+        return
+    if ex is not None:
+        call('tss_bn_bwd_finalize_xchg', ptr(link.bstats), float(link.count), ex.peers, ex.rank, ex.world, ptr(ex.counters),
+             ptr(link.invstd), ptr(link.gamma), int(acc), ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
         return
     call('tss_bn_bwd_finalize', ptr(link.bstats), float(link.count), ptr(link.invstd), ptr(link.gamma), training, int(acc),
          ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), C, st)
@@ -1274,18 +1294,7 @@ class ConvUnitFn(Function):
                 else:
                     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
                     dgamma, dbeta = dgb[0], dgb[1]
-            ex = _exchange(link.sync, link.bstats.device) if (link.sync is not None and Cout <= 768) else None
-            if ex is not None:
-                _flush_wg(st)
-                call('tss_bn_bwd_finalize_xchg', ptr(link.bstats), float(link.count), ex.peers, ex.rank, ex.world, ptr(ex.counters),
-                     ptr(link.invstd), ptr(link.gamma), acc, ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
-            elif link.sync is not None:
-                _flush_wg(st)
-                gs = _allreduce_stats(link.bstats, link.count, Cout, link.sync, st)
-                call('tss_bn_bwd_finalize_sync', ptr(link.bstats), ptr(gs), ptr(link.invstd), ptr(link.gamma), acc,
-                     ptr(dgamma), ptr(dbeta), ptr(link.ga), ptr(link.gb), ptr(link.gce), Cout, st)
-            else:
-                _bn_bwd_finalize(link, Cout, acc, dgamma, dbeta, st)
+            _bn_bwd_finalize(link, Cout, acc, dgamma, dbeta, st)       # (local or cross-replica statistics: link.sync)
             if acc:
                 dgamma = dbeta = None
             ga, gb, gce, gmu = link.ga, link.gb, link.gce, link.mean
@@ -1737,7 +1746,7 @@ def upsample_dw_unit(x, size, block):
     gamma = beta = None
     if bn is not None:
         cfg.training = bn.training or (bn.running_mean is None and bn.running_var is None)
-        if (cfg.training and bn.momentum is None) or (cfg.training and _sync_group(bn) is not None):
+        if cfg.training and bn.momentum is None:
             return None
         gamma, beta = bn.weight, bn.bias
     cfg.params = (conv.weight, gamma, beta)
@@ -2172,8 +2181,6 @@ class StandaloneBNFn(Function):
             else:
                 dgb = torch.empty((2, C), dtype=torch.float32, device=z.device)
                 dgamma, dbeta = dgb[0], dgb[1]
-        if link.sync is not None:
-            raise NotImplementedError('HIP path: cross-replica statistics for a stand-alone BatchNorm')
         _bn_bwd_finalize(link, C, acc, dgamma, dbeta, st)
         if acc:
             dgamma = dbeta = None
