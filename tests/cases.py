@@ -191,3 +191,19 @@ def zero_all_dropout(m):
     for mod in m.modules():
         if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout2d)):
             mod.p = 0.0
+
+
+
+def load_fixture_buffers(m, g, name):
+    """running statistics of a whole-model fixture (tests/golden/zoo_frozen.npz: '<name>/buf.<buffer>') into the module's buffers"""
+    import numpy as np
+    bufs = dict(m.named_buffers())
+    n = 0
+    with torch.no_grad():
+        for k in g:
+            if k.startswith(name + '/buf.'):
+                b = bufs[k[len(name) + 5:]]
+                b.copy_(torch.from_numpy(np.asarray(g[k])).to(b.device).reshape(b.shape))
+                n += 1
+    assert n > 0
+    return n

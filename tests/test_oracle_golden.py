@@ -223,3 +223,25 @@ def test_esnet_whole_model_bit_identical(golden_dir):
     m.train()
     out = m(x)
     assert np.array_equal(out[:, :, ::2, ::2].detach().numpy(), g['train/es_net/out_sub2'])
+
+
+
+@pytest.mark.parametrize('name', ['led_net', 'es_net'])
+def test_zoo_whole_model_frozen_gradients_bit_identical(golden_dir, name):
+    """oracle/zoo.py's whole LedNet / ESNet == the imported reference (tests/golden/make_golden.py gen_zoo_frozen, round 4): built under
+    torch.manual_seed(0) it has the reference's default-init weights (per-tensor checksums of the fixture), and one backward pass with
+    the BatchNorms frozen on the fixture's statistics gives the reference's f32 loss and EVERY parameter's gradient norm, bit for bit."""
+    from oracle.recipe import synthetic_batch
+    g = cases.load_npz(os.path.join(golden_dir, 'zoo_frozen.npz'))
+    torch.manual_seed(0)
+    m = cases.oracle_zoo(name)
+    cases.zero_all_dropout(m)
+    assert np.array_equal(np.array([p.detach().double().abs().sum().item() for p in m.parameters()]), g[name + '/wsum'])
+    cases.load_fixture_buffers(m, g, name)
+    m.eval()
+    x, y = synthetic_batch(2, 64, 128)
+    loss = torch.nn.CrossEntropyLoss(ignore_index=255)(m(x), y)
+    loss.backward()
+    assert loss.item() == float(g[name + '/loss32'])
+    norms = np.array([p.grad.double().norm().item() for _, p in m.named_parameters()])
+    assert np.array_equal(norms, g[name + '/grad_norms32'])
