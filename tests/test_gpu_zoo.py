@@ -393,10 +393,13 @@ def test_zoo_whole_model_frozen_gradients_vs_reference(golden_dir, name):
             i = names.index(pname)
             got = m.get_parameter(pname).grad.double().cpu().numpy()
             err = np.linalg.norm(got - g[key]) / max(np.linalg.norm(g[key]), 1e-30)
-            # floor: the f32 forward of these 40-layer stacks is held to 1e-3 on the logits (the eval tests above), and a gradient of the last
-            # layers inherits the deviation of the logits it is computed from (measured 1.4e-3 on ESNet's last factorized unit, where
-            # every operator on its own is at 1e-7 of f64: tools/fcu_diag.py, tools/ce_diag.py)
-            assert err <= 3 * e32[i] + 2e-3, (pname, err, e32[i])
+            # floor: ReLU decisions at the logits.  ESNet's classifier ends in BatchNorm + ReLU, and an f32 forward opens / closes a handful of
+            # the 311 296 output units differently from the f64 run (measured: torch f32 5, HIP f32 6 -- tools/zoo_fwd_diag.py); a unit at
+            # a LABEL pixel carries (p - 1) / N ~ 1 / 15 579 of the cross-entropy gradient, 6e-4 of |d(bn.bias)| ~ 0.1, so which units flip
+            # (luck, not accuracy: same logits error 7e-5 vs 6e-5, same d(logits) error 1.9e-5 vs 1.6e-5, every kernel of the block at
+            # 1e-7 of f64 on the same input -- tools/cls_diag.py, tools/zoo_mix2_diag.py) moves the last layers' gradients by 1e-3 - 3e-3.
+            # The reference's own f32 distance does not cover this for the last block, hence a floor of a few flips' worth.
+            assert err <= 3 * e32[i] + 6e-3, (pname, err, e32[i])
             checked += 1
     assert checked == 5
     print(name, 'HIP f32 vs reference f64: loss', loss.item(), l64, ' max |norm - norm64| / bound', float((np.abs(norms - n64) / bound).max()))
