@@ -215,6 +215,10 @@ int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* bf16 unfold for the weight gradient of a three-tap layer: col[p][c*3 + tap] = act(x[p + off(tap)][c]) (0 outside the image); dW in torch's
+ * [N][C][1][3] / [N][C][3][1] layout is then tss_pwconv_bwd_weight(e, ..., x = col, ldx = 3*C, no affine, K = 3*C). */
+int tss_im2col1d3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                  void* col, int B, int H, int W, int C, int axis, int dil, int dtype, void* stream);
 /* ---- general dense convolution: kh x kw taps (odd sides), padding = dilation * (k - 1) / 2 on each axis, any stride, optional bias ---
  * replaces: the strided 3x3 / 5x5 / 7x7 ConvBlocks of APNModule TSS/models/lednet.py:62-64, the strided 3x3 (with bias) of
  *           DownsamplingBlock lednet.py:130-131 / esnet.py:54-56, and the 1x5 / 5x1 layers of FCUBlock esnet.py:83-113.

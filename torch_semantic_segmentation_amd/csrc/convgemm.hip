@@ -503,6 +503,14 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 }  // namespace
 
 extern int g_tss_disable_fast;   // pwfast.hip
+// fc1d.hip: lean bf16 kernels of the three-tap layers (false: shape not covered)
+bool tss_fc1d_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                  const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                  int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream);
+bool tss_fc1d_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                       const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                       const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                       void* e_in, long ldei, double* bstats, int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream);
 // conv3x3.hip
 bool tss_conv3x3_lean_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                           const void* w9, void* y, long ldy, double* stats, int B, int H, int W, int Cin, int N,
@@ -710,6 +718,11 @@ int tss_conv1d3_fwd(const void* x, long ldx, const float* in_mean, const float* 
   TSS_REQUIRE(Cin > 0 && N > 0 && (Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && dil >= 1 &&
               (axis == 0 || axis == 1) && w_tnc, TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && (N == 16 || N == 32 || N == 64)) {   // lean kernel (fc1d.hip)
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)B * H * W * (Cin + N) * 2.0, 2.0 * B * H * W * 3.0 * Cin * N);
+    if (tss_fc1d_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
+      return tss::check_last("fc1d_fwd");
+  }
   GemmArgs g = {};
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = 1; g.Cin = Cin;
   g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;
@@ -730,6 +743,13 @@ int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
               (axis == 0 || axis == 1) && w_tcn, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && (N == 16 || N == 32 || N == 64)) {
+    tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (double)B * H * W * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * 2.0,
+                        2.0 * B * H * W * 3.0 * Cin * N);
+    if (tss_fc1d_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+                          B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
+      return tss::check_last("fc1d_bwd_data");
+  }
   GemmArgs g = {};
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = -1; g.Cin = N;
   g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;

@@ -67,6 +67,19 @@ sweep_pw_backward = os.environ.get('TSS_PW_SWEEP', '1') != '0'        # csrc/pws
 # Everything left over is flushed by the end-of-pass callback, so gradients are complete when backward() returns (and not before:
 # see direct_grads).
 postpone_wgrad = os.environ.get('TSS_POSTPONE_WGRAD', '1') != '0'
+# weight gradient of the three-tap (1x3 / 3x1) layers: unfold + the pipelined pointwise kernel (0: the generic tap-loop kernel)
+unfold_1d_wgrad = os.environ.get('TSS_FC1D_WGRAD', '1') != '0'
+_CONST_ROWS = {}
+
+
+def _const_rows(dev, n):
+    """(ones, zeros) f32 rows of at least n channels on `dev`: BatchNorm-backward coefficients of a layer that has none."""
+    key = (dev.type, dev.index)
+    got = _CONST_ROWS.get(key)
+    if got is None or got[0].numel() < n:
+        m = max(768, n)
+        got = _CONST_ROWS[key] = (torch.ones(m, dtype=torch.float32, device=dev), torch.zeros(m, dtype=torch.float32, device=dev))
+    return got
 # Layers that run inside a two-stream region of the forward pass (ContextNet's branches, `overlap_region`) are not postponed: there
 # the other stream's kernels already fill the launch gaps, and what postponing leaves for the end of the pass (a weight gradient and
 # its slot reduction per stream, un-overlapped) costs more than the finalize launches it saves (measured: 6.32 vs 6.21 ms per step).
@@ -1373,8 +1386,22 @@ class ConvUnitFn(Function):
                 if not fused_dw:
                     call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
             elif cfg.kind in ('dense1d_w', 'dense1d_h'):
-                call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout,
-                     0 if cfg.kind == 'dense1d_w' else 1, d, dt, wst)
+                axis = 0 if cfg.kind == 'dense1d_w' else 1
+                if (e.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and unfold_1d_wgrad and not N.fast_paths_disabled()):
+                    # unfold once (bf16 [P][Cin*3], column c*3 + tap), then the pipelined pointwise MFMA weight-gradient kernel with
+                    # K = 3*Cin writes torch's [N][Cin][1][3] / [N][Cin][3][1] layout directly (as the dense 3x3 below)
+                    col = torch.empty((P, Cin * 3), dtype=torch.bfloat16, device=dev)
+                    call('tss_im2col1d3', *xargs, ptr(col), B, Hin, Win, Cin, axis, d, dt, wst)
+                    g_ = gargs
+                    if y is None:        # no BatchNorm behind this layer (or a frozen one): g = ga * e, written as ga * e + 0 * e + 0
+                        one, zero = _const_rows(dev, Cout)
+                        g_ = (ptr(e), ld(e), ptr(e), ld(e), ptr(ga) if ga is not None else ptr(one), ptr(zero), ptr(zero), ptr(zero))
+                    nws = N.lib().tss_pwconv_bwd_weight_ws(P, Cin * 3, Cout, dt)
+                    ws = torch.empty(nws, dtype=torch.float32, device=dev) if nws else None
+                    call('tss_pwconv_bwd_weight', *g_, ptr(col), Cin * 3, None, None, None, 0, ptr(dw), ptr(ws), 0,
+                         P, Cin * 3, Cout, dt, None, wst)
+                else:
+                    call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, axis, d, dt, wst)
             elif cfg.kind == 'ckk':
                 call('tss_convkxk_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, cfg.kh, cfg.kw, s, d, dt, wst)
             elif (e.dtype == torch.bfloat16 and s == 1 and y is not None and (Cin * 9) % 8 == 0 and Cout % 8 == 0
