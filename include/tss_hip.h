@@ -215,6 +215,14 @@ int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* weight gradient of a square 16 / 32 / 64-channel three-tap layer in ONE sweep over e, y and x (bf16; csrc/fc1d.hip): every block leaves a
+ * row of partial sums (3 * N * Cin floats, torch's [N][Cin][taps] order) in ws[tss_conv1d3_bwd_weight_rows(...)][3*N*Cin]; the rows are
+ * added to the gradient by tss_dw_reduce_many.  _rows returns 0 when the shape is not covered (use tss_conv1d3_bwd_weight). */
+int tss_conv1d3_bwd_weight_rows(long P, int Cin, int N, int dtype);
+int tss_conv1d3_bwd_weight_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                                 const float* ga, const float* gb, const float* gce, const float* gmu,
+                                 const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
+                                 int in_relu, float* ws, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
 /* bf16 unfold for the weight gradient of a three-tap layer: col[p][c*3 + tap] = act(x[p + off(tap)][c]) (0 outside the image); dW in torch's
  * [N][C][1][3] / [N][C][3][1] layout is then tss_pwconv_bwd_weight(e, ..., x = col, ldx = 3*C, no affine, K = 3*C). */
 int tss_im2col1d3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

@@ -92,6 +92,25 @@ for (B, H, W, C, axis, dil) in CASES:
             ys[0].copy_(keep)
         print('%-9s %dx%dx%d C=%d axis=%d dil=%2d  lean %7.1f us (%5.0f GB/s)  generic %7.1f us   rel %s' % (
             tag, B, H, W, C, axis, dil, t1, alg / t1 / 1e3, t0, ' '.join('%.2e' % rl(a, b) for a, b in zip(lean, gen))), flush=True)
+    rows = N.lib().tss_conv1d3_bwd_weight_rows(P, C, C, BF)
+    wsr = torch.empty(max(rows, 1), 3 * C * C, device=dev)
+
+    def wg_sweep():
+        for e, y, x in zip(es, ys, xs):
+            N.call('tss_conv1d3_bwd_weight_sweep', *gargs(e, y), *xargs(x), N.ptr(wsr), B, H, W, C, C, axis, dil, BF, st)
+            ops._reduce_rows_now(wsr, dw, 3 * C * C, rows)
+
+    def wg_sweep_plain():
+        for e, x in zip(es, xs):
+            N.call('tss_conv1d3_bwd_weight_sweep', *gplain(e), N.ptr(x), C, None, None, None, 1, N.ptr(wsr), B, H, W, C, C, axis, dil, BF, st)
+            ops._reduce_rows_now(wsr, dw, 3 * C * C, rows)
+    if rows:
+        dw.zero_(); wg_sweep(); torch.cuda.synchronize(); d2 = dw.clone() / nset
+        t2 = timeit(wg_sweep) / nset
+        t3 = timeit(wg_sweep_plain) / nset
+        dw.zero_(); wg_generic(); torch.cuda.synchronize(); d0 = dw.clone() / nset
+        print('%-9s %dx%dx%d C=%d axis=%d dil=%2d  one sweep %7.1f us (%5.0f GB/s), no BatchNorm behind %7.1f us (%5.0f GB/s)  rows %d  rel %.2e' % (
+            'wgrad', B, H, W, C, axis, dil, t2, P * C * 2 * 3 / t2 / 1e3, t3, P * C * 2 * 2 / t3 / 1e3, rows, rl(d2, d0)), flush=True)
     dw.zero_(); wg_unfold(); torch.cuda.synchronize(); d1 = dw.clone() / nset
     t1 = timeit(wg_unfold) / nset
     dw.zero_(); wg_generic(); torch.cuda.synchronize(); d0 = dw.clone() / nset

@@ -384,6 +384,229 @@ __global__ __launch_bounds__(256) void im2col1d3_kernel(const T* x, long ldx, co
   }
 }
 
+// ---- weight gradient of a three-tap layer in one sweep: dW[n][c][tap] = sum_p g[p][n] * a[p + off(tap)][c], g the BatchNorm-backward
+// combination of e and y (or e alone), a the activated input.  The contraction runs over PIXELS, so both MFMA operands are needed
+// pixel-major: a stage of PT pixels of g and of the three shifted copies of a is normalised in registers, written once to LDS as
+// [pixel][channel] rows of the dual-use image of pwsweep.hip (16-byte row writes, ds_read_b64_tr_b16 transposed reads: no bank
+// conflicts either way) and read back as k-major fragments.  One barrier per stage (two buffers); the next stage's loads are issued
+// when the current stage's registers are free and land under its MFMAs.  A block owns a contiguous range of stages and leaves one
+// row of partial sums in the workspace (torch's [N][C][taps] order); the rows are added by tss_dw_reduce_many.
+// (unfold + pointwise kernel, round 4 first version: 9 C bytes per pixel instead of 3 C -- 428 us on the 1/2-resolution layers.)
+typedef __attribute__((ext_vector_type(4))) short v4s;
+__device__ __forceinline__ int img_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ bf16x8 tr_pair(const unsigned char* lo, const unsigned char* hi) {
+  union { v4s h[2]; bf16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)lo);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)hi);
+  return u.v;
+}
+
+struct FwArgs {
+  long P; int B, H, W, D, axis;
+  const T* e; long lde; const T* y; long ldyr; const float* ga; const float* gb; const float* gce; const float* gmu;
+  const T* x; long ldx; const float* xm; const float* xs; const float* xb; int x_relu;
+  float* ws;                                           // [gridDim.x][C * C * 3]
+};
+
+template <int C, bool HASY>
+__global__ __launch_bounds__(NT, 2) void fc1d_wgrad_kernel(const FwArgs g) {
+  constexpr int NF = C / 16, NV = C / 8, PT = C == 64 ? 64 : 128, RPP = NT / NV, NP = PT / RPP, NIMG = (4 * NV + 15) / 16;
+  constexpr int BUF = NIMG * PT * 256, NKS = PT / 32, NJ = C == 64 ? 4 : 1;
+  extern __shared__ __align__(16) unsigned char smem[];          // two stage buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int cv = tid % NV, r = tid / NV;
+
+  // ---- folded constants of this thread's channel vector
+  float ca[8], cb[HASY ? 8 : 1], cc[HASY ? 8 : 1], as[8], ab[8];
+  const bool gplain = !HASY && !g.ga, aplain = !g.xs && !g.xm && !g.xb && !g.x_relu;
+  {
+    const float* safe = reinterpret_cast<const float*>(g.e);
+    float v0[8], v1[8], v2[8], v3[8], w0[8], w1[8], w2[8];
+    const float* p0 = g.ga ? g.ga + cv * 8 : safe; const float* p1 = (HASY && g.gb) ? g.gb + cv * 8 : safe;
+    const float* p2 = (HASY && g.gce) ? g.gce + cv * 8 : safe; const float* p3 = (HASY && g.gmu) ? g.gmu + cv * 8 : safe;
+    const float* q0 = g.xs ? g.xs + cv * 8 : safe; const float* q1 = g.xm ? g.xm + cv * 8 : safe; const float* q2 = g.xb ? g.xb + cv * 8 : safe;
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      V4<float>::load(p0 + h, v0 + h); V4<float>::load(p1 + h, v1 + h); V4<float>::load(p2 + h, v2 + h); V4<float>::load(p3 + h, v3 + h);
+      V4<float>::load(q0 + h, w0 + h); V4<float>::load(q1 + h, w1 + h); V4<float>::load(q2 + h, w2 + h);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gav = g.ga ? v0[j] : 1.f;
+      ca[j] = gav;
+      if (HASY) { cb[j] = v1[j]; cc[j] = -(gav * v2[j]) - v1[j] * v3[j]; }      // g = ga*e + gb*y + cc
+      const float sc = g.xs ? w0[j] : 1.f;
+      as[j] = sc; ab[j] = (g.xb ? w2[j] : 0.f) - (g.xm ? w1[j] : 0.f) * sc;      // a = relu?(x*as + ab)
+    }
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+
+  // ---- this wave's part of the output and its transposed-read offsets
+  const int fi = C == 64 ? wave : (C == 32 ? (wave & 1) : 0);          // fragment of output channels n
+  const int fj0 = C == 32 ? (wave >> 1) : 0;                           // first fragment of input channels c
+  int troffG[2], troffA[3][NJ][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = fq * 8 + 4 * h + (fr >> 2);
+    troffG[h] = img_off(row, (fi & 7) * 2 + ((fr & 3) >> 1)) + 8 * (fr & 1);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int F = (1 + t) * NF + fj0 + j;
+        troffA[t][j][h] = (F >> 3) * PT * 256 + img_off(row, (F & 7) * 2 + ((fr & 3) >> 1)) + 8 * (fr & 1);
+      }
+  }
+  // staging offsets of this thread's chunk: g at column chunk cv, tap t of a at (1 + t) * NV + cv
+  int stG[NP], stA[NP][3];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int row = r + u * RPP;
+    stG[u] = img_off(row, cv);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const int gc = (1 + t) * NV + cv; stA[u][t] = (gc >> 4) * PT * 256 + img_off(row, gc & 15); }
+  }
+
+  f32x4 acc[3][NJ];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[t][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long nstage = (g.P + PT - 1) / PT;
+  const long per = (nstage + gridDim.x - 1) / gridDim.x;
+  const long s_begin = (long)blockIdx.x * per;
+  long s_end = s_begin + per;
+  if (s_end > nstage) s_end = nstage;
+  const int lim = g.axis ? g.H : g.W;
+  const long pstep = g.axis ? g.W : 1;
+
+  uint4 re[NP], ry[HASY ? NP : 1], rx[NP][3];
+  uint32_t okb = 0;                                    // bits u*4 + t: tap t of pass u is inside the image; u*4 + 3: the pixel exists
+#define FW_ISSUE(S)                                                                                      \
+  {                                                                                                        \
+    okb = 0;                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < NP; ++u) {                                                      \
+      const long p = (S) * PT + r + u * RPP;                                                               \
+      const bool in = p < g.P;                                                                             \
+      const long pcl = in ? p : g.P - 1;                                                                   \
+      const int xx = (int)(pcl % g.W);                                                                     \
+      const int yy = (int)((pcl / g.W) % g.H);                                                             \
+      okb |= in ? (8u << (u * 4)) : 0u;                                                                    \
+      re[u] = *reinterpret_cast<const uint4*>(g.e + pcl * g.lde + cv * 8);                                 \
+      if (HASY) ry[u] = *reinterpret_cast<const uint4*>(g.y + pcl * g.ldyr + cv * 8);                      \
+      _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                     \
+        const int sh = (t - 1) * g.D;                                                                      \
+        const int c1 = (g.axis ? yy : xx) + sh;                                                            \
+        const bool ok = in && c1 >= 0 && c1 < lim;                                                         \
+        okb |= ok ? (1u << (u * 4 + t)) : 0u;                                                              \
+        rx[u][t] = *reinterpret_cast<const uint4*>(g.x + (ok ? pcl + sh * pstep : pcl) * g.ldx + cv * 8);  \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  if (s_begin < s_end) FW_ISSUE(s_begin);
+  int b = 0;
+  for (long s = s_begin; s < s_end; ++s) {
+    unsigned char* img = smem + b * BUF;
+    // ---- registers -> normalised bf16 rows in LDS
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      uint4 og = re[u];
+      if (!gplain) {
+        const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[u]);
+        const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[HASY ? u : 0]);
+        bf16x8 o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          float lo = ca[2 * h] * blo(ue[h]), hi = ca[2 * h + 1] * bhi(ue[h]);
+          if (HASY) { lo += cb[2 * h] * blo(uy[h]) + cc[2 * h]; hi += cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]; }
+          o[2 * h] = (T)lo; o[2 * h + 1] = (T)hi;
+        }
+        og = *reinterpret_cast<const uint4*>(&o);
+      }
+      if (!((okb >> (u * 4 + 3)) & 1u)) og = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(img + stG[u]) = og;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        uint4 oa = rx[u][t];
+        if (!aplain) {
+          const uint32_t* ux = reinterpret_cast<const uint32_t*>(&rx[u][t]);
+          bf16x8 o;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            o[2 * h] = (T)fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
+            o[2 * h + 1] = (T)fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
+          }
+          oa = *reinterpret_cast<const uint4*>(&o);
+        }
+        if (!((okb >> (u * 4 + t)) & 1u)) oa = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(img + stA[u][t]) = oa;
+      }
+    }
+    if (s + 1 < s_end) FW_ISSUE(s + 1);
+    __syncthreads();
+    // ---- D[n][c] += sum over the stage's pixels, tap by tap
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      if (C == 16 && ks != wave) continue;             // 16 channels: one fragment per tap, the four waves split the pixels
+      const unsigned char* base = img + ks * 32 * 256;
+      const bf16x8 gA = tr_pair(base + troffG[0], base + troffG[1]);
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const bf16x8 aB = tr_pair(base + troffA[t][j][0], base + troffA[t][j][1]);
+          acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gA, aB, acc[t][j], 0, 0, 0);
+        }
+    }
+    b ^= 1;
+  }
+#undef FW_ISSUE
+
+  // ---- this block's row of partial sums: lane holds n = 16 fi + 4 fq + q, c = 16 (fj0 + j) + fr, tap t
+  float* row = g.ws + (long)blockIdx.x * (3 * C * C);
+  if (C == 16) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);       // [3 * C * C]
+    for (int i = tid; i < 3 * C * C; i += NT) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(&red[((fq * 4 + q) * C + fr) * 3 + t], acc[t][0][q]);
+    __syncthreads();
+    for (int i = tid; i < 3 * C * C; i += NT) row[i] = red[i];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) row[((long)(16 * fi + 4 * fq + q) * C + 16 * (fj0 + j) + fr) * 3 + t] = acc[t][j][q];
+  }
+}
+
+template <int C> constexpr int wg_smem() { return 2 * (((4 * (C / 8) + 15) / 16) * (C == 64 ? 64 : 128) * 256); }
+
+template <int C, bool HASY>
+void launch_fw(const FwArgs& g, int grid, hipStream_t stream) {
+  static tss::DevOnce attr;
+  if (attr.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fc1d_wgrad_kernel<C, HASY>), hipFuncAttributeMaxDynamicSharedMemorySize, wg_smem<C>());
+  hipLaunchKernelGGL((fc1d_wgrad_kernel<C, HASY>), dim3(grid), dim3(NT), wg_smem<C>(), stream, g);
+}
+
+int wg_rows(long P, int C) {
+  const int PT = C == 64 ? 64 : 128;
+  const long nstage = (P + PT - 1) / PT;
+  long grid = nstage < 512 ? nstage : 512;
+  // every block should sweep at least 4 stages: its row of partial sums costs 12 C^2 bytes twice
+  if (grid > (nstage + 3) / 4) grid = (nstage + 3) / 4;
+  return (int)(grid < 1 ? 1 : grid);
+}
+
 bool fc_enabled() {
   static int v = -1;
   if (v < 0) { const char* s = getenv("TSS_FC1D"); v = (s && s[0] == '0') ? 0 : 1; }
@@ -438,4 +661,37 @@ extern "C" int tss_im2col1d3(const void* x, long ldx, const float* in_mean, cons
   hipLaunchKernelGGL(im2col1d3_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const T*)x, ldx, in_mean, in_scale,
                      in_bias, in_relu, (T*)col, B, H, W, C, axis, dil);
   return tss::check_last("im2col1d3");
+}
+
+/* weight gradient of a three-tap layer in one sweep; rows of partial sums (tss_conv1d3_bwd_weight_rows of them, 3 * N * Cin floats each,
+ * torch's [N][Cin][taps] order) go to ws and are added to the gradient by tss_dw_reduce_many.  rows == 0: shape not covered. */
+extern "C" int tss_conv1d3_bwd_weight_rows(long P, int Cin, int N, int dtype) {
+  extern int g_tss_disable_fast;
+  if (dtype != TSS_BF16 || g_tss_disable_fast || !fc_enabled() || Cin != N || (N != 16 && N != 32 && N != 64) || P <= 0) return 0;
+  static int v = -1;
+  if (v < 0) { const char* s = getenv("TSS_FC1D_WGRAD_SWEEP"); v = (s && s[0] == '0') ? 0 : 1; }
+  return v ? wg_rows(P, N) : 0;
+}
+
+extern "C" int tss_conv1d3_bwd_weight_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                                            const float* ga, const float* gb, const float* gce, const float* gmu,
+                                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
+                                            int in_relu, float* ws, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype,
+                                            void* stream) {
+  TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(Cin == N && (N == 16 || N == 32 || N == 64) && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin && dil >= 1 &&
+              (axis == 0 || axis == 1) && e && xraw && ws && (long)B * H * W > 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw) && (!yraw || tss::aligned16(yraw)), TSS_ERR_ALIGN);
+  FwArgs g = {};
+  g.P = (long)B * H * W; g.B = B; g.H = H; g.W = W; g.D = dil; g.axis = axis;
+  g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
+  g.x = (const T*)xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
+  g.ws = ws;
+  const int grid = wg_rows(g.P, N);
+  tss::ProfScope prof(TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream, (double)g.P * N * (yraw ? 3 : 2) * 2.0, 2.0 * g.P * 3.0 * N * N);
+  if (N == 64) { if (yraw) launch_fw<64, true>(g, grid, (hipStream_t)stream); else launch_fw<64, false>(g, grid, (hipStream_t)stream); }
+  else if (N == 32) { if (yraw) launch_fw<32, true>(g, grid, (hipStream_t)stream); else launch_fw<32, false>(g, grid, (hipStream_t)stream); }
+  else { if (yraw) launch_fw<16, true>(g, grid, (hipStream_t)stream); else launch_fw<16, false>(g, grid, (hipStream_t)stream); }
+  return tss::check_last("fc1d_wgrad");
 }

@@ -1337,6 +1337,7 @@ class ConvUnitFn(Function):
             wst = side.cuda_stream
         fused_pw = False
         fused_dbias = None
+        rows_after_join = None
         if cfg.kind == 'stem':
             ws = torch.empty((N.stat_slabs(), Cout * 28), dtype=torch.float32, device=dev)
             call('tss_stem3x3_bwd_weight', *gargs, ptr(x), int(cfg.image_f32), ptr(dw), ptr(ws),
@@ -1387,7 +1388,14 @@ class ConvUnitFn(Function):
                     call('tss_dwconv3x3_bwd_weight', *gargs, *xargs, ptr(dw), ptr(ws), defer, B, Hin, Win, Cout, s, d, dt, wst)
             elif cfg.kind in ('dense1d_w', 'dense1d_h'):
                 axis = 0 if cfg.kind == 'dense1d_w' else 1
-                if (e.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and unfold_1d_wgrad and not N.fast_paths_disabled()):
+                rows = N.lib().tss_conv1d3_bwd_weight_rows(P, Cin, Cout, dt)
+                if rows:
+                    # one sweep over e, y and x (csrc/fc1d.hip); the rows of per-block partial sums are added to the gradient together with
+                    # those of every other such layer, in one launch at the end of this backward pass
+                    ws = torch.empty((rows, Cout * Cin * 3), dtype=torch.float32, device=dev)
+                    call('tss_conv1d3_bwd_weight_sweep', *gargs, *xargs, ptr(ws), B, Hin, Win, Cin, Cout, axis, d, dt, wst)
+                    rows_after_join = (ws, rows)      # the sweep may be on the side stream: its rows are queued / added after the join below
+                elif (e.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and unfold_1d_wgrad and not N.fast_paths_disabled()):
                     # unfold once (bf16 [P][Cin*3], column c*3 + tap), then the pipelined pointwise MFMA weight-gradient kernel with
                     # K = 3*Cin writes torch's [N][Cin][1][3] / [N][Cin][3][1] layout directly (as the dense 3x3 below)
                     col = torch.empty((P, Cin * 3), dtype=torch.bfloat16, device=dev)
@@ -1565,6 +1573,12 @@ class ConvUnitFn(Function):
                 _bias_grad_into(e, P, Cout, dbias, dt, st)
         if side is not None:
             main.wait_stream(side)
+        if rows_after_join is not None:
+            ws_, rows_ = rows_after_join
+            if dw_ret is None and batch_dw_reductions:
+                _defer_dw_reduction(ws_, dw, Cout * Cin * 3, rows_, p_weight)
+            else:
+                _reduce_rows_now(ws_, dw, Cout * Cin * 3, rows_)
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
 
 
