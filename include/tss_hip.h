@@ -215,6 +215,17 @@ int tss_conv1d3_bwd_weight(const void* e, long lde, const void* yraw, long ldyr,
                            const float* ga, const float* gb, const float* gce, const float* gmu,
                            const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                            float* dw, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* forward / backward-data on the layer's own weight tensor (torch's [N][Cin][1][3] / [N][Cin][3][1]; no permuted copy) where the lean bf16
+ * kernels cover the shape (tss_conv1d3_lean_supported: square 16 / 32 / 64-channel layers; csrc/fc1d.hip) */
+int tss_conv1d3_lean_supported(int Cin, int N, int dtype);
+int tss_conv1d3_fwd_w(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                      const float* w, const float* bias, void* y, long ldy, double* stats,
+                      int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+int tss_conv1d3_bwd_data_w(const void* e, long lde, const void* yraw, long ldyr,
+                           const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                           void* e_in, long ldei, double* bstats,
+                           int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
 /* weight gradient of a square 16 / 32 / 64-channel three-tap layer in ONE sweep over e, y and x (bf16; csrc/fc1d.hip): every block leaves a
  * row of partial sums (3 * N * Cin floats, torch's [N][Cin][taps] order) in ws[tss_conv1d3_bwd_weight_rows(...)][3*N*Cin]; the rows are
  * added to the gradient by tss_dw_reduce_many.  _rows returns 0 when the shape is not covered (use tss_conv1d3_bwd_weight). */
@@ -259,7 +270,9 @@ int tss_convkxk_transposed_fwd(const void* x, long ldx, const float* w_tcn, cons
  * tss_pool_concat_*: z = cat([y1 + bias (N1 channels), max_pool2d(x, 2) (Cin channels)]); x is addressed by element strides
  *   (an NHWC activation, or the NCHW f32 image: x_f32 = 1); bwd writes dx ([B][Hin][Win][Cin], dtype) from dz[:, N1:];
  * tss_mul_addrows_*: out = u * a + r[image] of APNModule lednet.py:86-90; ws: B * tss_rows_slices(B, HW) * C floats;
- * tss_scale_rows: out = x * m[image][channel] (nn.Dropout2d with the mask m drawn by the caller; its own backward). */
+ * tss_scale_rows: out = x * m[image][channel] (nn.Dropout2d with the mask m drawn by the caller; its own backward);
+ * tss_cat2_add: out = cat([gl, gr], channels) + gs (gs may be NULL): the input gradient of a unit that splits its input with
+ *   torch.chunk(input, 2, 1) and also uses it whole (SSnbtBlock TSS/models/lednet.py:112-124). */
 int tss_tensor_stats(const void* z, long ldz, long P, int C, double* stats, int dtype, void* stream);
 int tss_bn_bwd_apply(const void* e, long lde, const void* z, long ldz, const float* ga, const float* gb, const float* gce,
                      const float* gmu, void* dz, long lddz, long P, int C, int dtype, void* stream);
@@ -273,6 +286,8 @@ int tss_mul_addrows_fwd(const void* u, long ldu, const void* a, long lda, const 
 int tss_mul_addrows_bwd(const void* g, long ldg, const void* u, long ldu, const void* a, long lda, void* du, long lddu, void* da,
                         long ldda, void* dr, long lddr, float* ws, int B, long HW, int C, int dtype, void* stream);
 int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream);
+int tss_cat2_add(const void* gl, long ldl, const void* gr, long ldr, const void* gs, long lds, void* out, long ldo, long P, int half,
+                 int dtype, void* stream);
 
 /* channel_shuffle(x, groups) TSS/models/lednet.py:183-188: y[:, j * groups + i] = x[:, i * (C / groups) + j] (its own inverse with
  * groups' = C / groups: the backward is the same entry) */

@@ -505,10 +505,10 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 extern int g_tss_disable_fast;   // pwfast.hip
 // fc1d.hip: lean bf16 kernels of the three-tap layers (false: shape not covered)
 bool tss_fc1d_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                  const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                  const float* w_tnc, int torch_layout, const float* bias, void* y, long ldy, double* stats,
                   int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream);
 bool tss_fc1d_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                       const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                       const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn, int torch_layout,
                        const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                        void* e_in, long ldei, double* bstats, int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream);
 // conv3x3.hip
@@ -720,7 +720,7 @@ int tss_conv1d3_fwd(const void* x, long ldx, const float* in_mean, const float* 
   TSS_REQUIRE(tss::aligned16(x) && tss::aligned16(y), TSS_ERR_ALIGN);
   if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && (N == 16 || N == 32 || N == 64)) {   // lean kernel (fc1d.hip)
     tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)B * H * W * (Cin + N) * 2.0, 2.0 * B * H * W * 3.0 * Cin * N);
-    if (tss_fc1d_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
+    if (tss_fc1d_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, 0, bias, y, ldy, stats, B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
       return tss::check_last("fc1d_fwd");
   }
   GemmArgs g = {};
@@ -746,7 +746,7 @@ int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && (N == 16 || N == 32 || N == 64)) {
     tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (double)B * H * W * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * 2.0,
                         2.0 * B * H * W * 3.0 * Cin * N);
-    if (tss_fc1d_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+    if (tss_fc1d_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, 0, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
                           B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
       return tss::check_last("fc1d_bwd_data");
   }

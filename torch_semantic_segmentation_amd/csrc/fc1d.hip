@@ -29,7 +29,7 @@ struct FcArgs {
   int B, H, W, D, axis, tap_sign;                     // axis 0: taps along W (1x3), 1: along H (3x1); source = p + tap_sign * (tap - 1) * D
   const T* a0; long lda0; const T* a1; long lda1;     // fwd: x (a1 unused)   bwd: e, yraw
   const float* c0; const float* c1; const float* c2; const float* c3; int a_relu;
-  const float* w;                                     // [3][C outputs][C contraction] f32
+  const float* w; int w_os, w_ks, w_ts;               // f32 weights: element (tap, output o, contraction k) at w[o * w_os + k * w_ks + tap * w_ts]
   const float* bias;
   T* y; long ldy; double* stats;
   const T* xm; long ldxm; const float* mm; const float* ms; const float* mb; int m_relu;
@@ -59,9 +59,9 @@ __global__ __launch_bounds__(NT, 2) void fc1d_kernel(const FcArgs g) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (T)0.f;
     if (tap < 3) {
-      const float* src = g.w + ((long)tap * C + n) * C + c;
-      const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-      o[0] = (T)a.x; o[1] = (T)a.y; o[2] = (T)a.z; o[3] = (T)a.w; o[4] = (T)b.x; o[5] = (T)b.y; o[6] = (T)b.z; o[7] = (T)b.w;
+      const float* src = g.w + (long)n * g.w_os + (long)c * g.w_ks + (long)tap * g.w_ts;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (T)src[(long)j * g.w_ks];
     }
     Wl[e] = *reinterpret_cast<const uint4*>(&o);
   }
@@ -617,23 +617,25 @@ bool fc_enabled() {
 
 // forward / backward-data of the three-tap layers on the lean kernel; false: shape not covered, the caller takes the generic kernel
 bool tss_fc1d_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
-                  const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                  const float* w_tnc, int torch_layout, const float* bias, void* y, long ldy, double* stats,
                   int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream) {
-  if (!fc_enabled() || Cin != N || (N != 16 && N != 32 && N != 64) || (ldx % 8) || (ldy % 4) || !tss::aligned16(x) || !tss::aligned16(w_tnc) ||
+  if (!fc_enabled() || Cin != N || (N != 16 && N != 32 && N != 64) || (ldx % 8) || (ldy % 4) || !tss::aligned16(x) || !w_tnc ||
       (reinterpret_cast<uintptr_t>(y) & 7u) || (long)B * H * W <= 0)
     return false;
   FcArgs g = {};
   g.B = B; g.H = H; g.W = W; g.D = dil; g.axis = axis; g.tap_sign = 1;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w_tnc; g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
+  if (torch_layout) { g.w_os = 3 * Cin; g.w_ks = 3; g.w_ts = 1; }      // [N][Cin][taps]
+  else { g.w_os = Cin; g.w_ks = 1; g.w_ts = N * Cin; }                  // [taps][N][Cin]
   return dispatch_fc<0>(g, N, stream);
 }
 
 bool tss_fc1d_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
-                       const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                       const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn, int torch_layout,
                        const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                        void* e_in, long ldei, double* bstats, int B, int H, int W, int Cin, int N, int axis, int dil, hipStream_t stream) {
-  if (!fc_enabled() || Cin != N || (N != 16 && N != 32 && N != 64) || (lde % 8) || (ldei % 4) || !tss::aligned16(e) || !tss::aligned16(w_tcn) ||
+  if (!fc_enabled() || Cin != N || (N != 16 && N != 32 && N != 64) || (lde % 8) || (ldei % 4) || !tss::aligned16(e) || !w_tcn ||
       (reinterpret_cast<uintptr_t>(e_in) & 7u) || (long)B * H * W <= 0)
     return false;
   if (yraw && ((ldyr % 8) || !tss::aligned16(yraw) || !ga || !gb || !gce || !gmu)) return false;
@@ -644,6 +646,8 @@ bool tss_fc1d_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.c0 = ga;
   if (yraw) { g.c1 = gb; g.c2 = gce; g.c3 = gmu; }
   g.w = w_tcn; g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
+  if (torch_layout) { g.w_os = 3; g.w_ks = 3 * Cin; g.w_ts = 1; }      // [N][Cin][taps]: output = input channel, contraction = n
+  else { g.w_os = N; g.w_ks = 1; g.w_ts = Cin * N; }                    // [taps][Cin][N]
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
   return yraw ? dispatch_fc<2>(g, N, stream) : dispatch_fc<1>(g, N, stream);
 }
@@ -694,4 +698,34 @@ extern "C" int tss_conv1d3_bwd_weight_sweep(const void* e, long lde, const void*
   else if (N == 32) { if (yraw) launch_fw<32, true>(g, grid, (hipStream_t)stream); else launch_fw<32, false>(g, grid, (hipStream_t)stream); }
   else { if (yraw) launch_fw<16, true>(g, grid, (hipStream_t)stream); else launch_fw<16, false>(g, grid, (hipStream_t)stream); }
   return tss::check_last("fc1d_wgrad");
+}
+
+/* the same two operators on the layer's own weight tensor (torch's [N][Cin][1][3] / [N][Cin][3][1]), no permuted copy: 1 when the lean
+ * kernels cover the shape (then tss_conv1d3_fwd_w / tss_conv1d3_bwd_data_w may be called), 0: permute and use tss_conv1d3_fwd / _bwd_data */
+extern "C" int tss_conv1d3_lean_supported(int Cin, int N, int dtype) {
+  extern int g_tss_disable_fast;
+  return (dtype == TSS_BF16 && !g_tss_disable_fast && fc_enabled() && Cin == N && (N == 16 || N == 32 || N == 64)) ? 1 : 0;
+}
+extern "C" int tss_conv1d3_fwd_w(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                 const float* w, const float* bias, void* y, long ldy, double* stats,
+                                 int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(tss_conv1d3_lean_supported(Cin, N, dtype) && (ldx % 8) == 0 && ldx >= Cin && (ldy % 4) == 0 && ldy >= N && dil >= 1 &&
+              (axis == 0 || axis == 1) && w, TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)B * H * W * (Cin + N) * 2.0, 2.0 * B * H * W * 3.0 * Cin * N);
+  TSS_REQUIRE(tss_fc1d_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w, 1, bias, y, ldy, stats, B, H, W, Cin, N, axis, dil, (hipStream_t)stream),
+              TSS_ERR_ALIGN);
+  return tss::check_last("fc1d_fwd");
+}
+extern "C" int tss_conv1d3_bwd_data_w(const void* e, long lde, const void* yraw, long ldyr,
+                                      const float* ga, const float* gb, const float* gce, const float* gmu, const float* w,
+                                      const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                                      void* e_in, long ldei, double* bstats,
+                                      int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream) {
+  TSS_REQUIRE(tss_conv1d3_lean_supported(Cin, N, dtype) && (lde % 8) == 0 && lde >= N && (ldei % 4) == 0 && ldei >= Cin && dil >= 1 &&
+              (axis == 0 || axis == 1) && w && (!bstats || xraw), TSS_ERR_SHAPE);
+  tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (double)B * H * W * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * 2.0,
+                      2.0 * B * H * W * 3.0 * Cin * N);
+  TSS_REQUIRE(tss_fc1d_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w, 1, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+                                B, H, W, Cin, N, axis, dil, (hipStream_t)stream), TSS_ERR_ALIGN);
+  return tss::check_last("fc1d_bwd_data");
 }

@@ -209,6 +209,29 @@ __global__ __launch_bounds__(NT) void scale_rows_kernel(const T* x, long ldx, co
   }
 }
 
+// gradient of the input of a split unit: out[p] = cat(gl[p], gr[p]) + gs[p] (gs may be absent) -- the two halves the branches of an
+// SS-nbt unit hand back and the gradient of the skip connection, in one pass (autograd's own route is two zero-filled full tensors,
+// two slice copies and two adds: 9 C bytes per pixel instead of 2 - 3 C).
+template <typename T>
+__global__ __launch_bounds__(NT) void cat2_add_kernel(const T* gl, long ldl, const T* gr, long ldr, const T* gs, long lds, T* out, long ldo,
+                                                      long P, int half) {
+  const int HV = half >> 3, CV = 2 * HV;
+  const long total = P * CV;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const int cv = (int)(i % CV);
+    const long p = i / CV;
+    float a[8], b[8];
+    if (cv < HV) V8<T>::load(gl + p * ldl + cv * 8, a);
+    else V8<T>::load(gr + p * ldr + (cv - HV) * 8, a);
+    if (gs) {
+      V8<T>::load(gs + p * lds + cv * 8, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += b[j];
+    }
+    V8<T>::store(out + p * ldo + cv * 8, a);
+  }
+}
+
 inline int grid_for(long total) {
   long g = (total + NT - 1) / NT;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -325,6 +348,23 @@ int tss_mul_addrows_bwd(const void* g, long ldg, const void* u, long ldu, const 
   if (dtype == TSS_BF16) { TSS_MAR_BWD(bf16_t); } else { TSS_MAR_BWD(float); }
 #undef TSS_MAR_BWD
   return tss::check_last("mul_addrows_bwd");
+}
+
+int tss_cat2_add(const void* gl, long ldl, const void* gr, long ldr, const void* gs, long lds, void* out, long ldo, long P, int half,
+                 int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(half > 0 && (half % 8) == 0 && (ldl % 8) == 0 && ldl >= half && (ldr % 8) == 0 && ldr >= half && (ldo % 8) == 0 && ldo >= 2 * half &&
+              gl && gr && out && (!gs || ((lds % 8) == 0 && lds >= 2 * half)), TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(gl) && tss::aligned16(gr) && tss::aligned16(out) && (!gs || tss::aligned16(gs)), TSS_ERR_ALIGN);
+  if (P == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_JOIN_BWD, (hipStream_t)stream, (double)P * half * (gs ? 6.0 : 4.0) * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(cat2_add_kernel<bf16_t>, dim3(grid_for(P * (half / 4))), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)gl, ldl,
+                       (const bf16_t*)gr, ldr, (const bf16_t*)gs, lds, (bf16_t*)out, ldo, P, half);
+  else
+    hipLaunchKernelGGL(cat2_add_kernel<float>, dim3(grid_for(P * (half / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)gl, ldl,
+                       (const float*)gr, ldr, (const float*)gs, lds, (float*)out, ldo, P, half);
+  return tss::check_last("cat2_add");
 }
 
 int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream) {

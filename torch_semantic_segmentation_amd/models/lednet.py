@@ -226,11 +226,11 @@ class SSnbtBlock(nn.Module):
 
     def forward(self, input):
         x = ops.to_nhwc(ops.materialize(input))
-        half = x.shape[1] // 2
-        if half % 8:
+        if x.shape[1] % 16:
             raise NotImplementedError('HIP path: SSnbtBlock needs a multiple of 16 channels')
-        left = run(self.left, x[:, :half])            # torch.chunk(input, 2, 1): two views of the same NHWC rows
-        right = run(self.right, x[:, half:])
+        xl, xr, x = ops.split_fork(x)                 # torch.chunk(input, 2, 1) + the skip: three views of the same NHWC rows
+        left = run(self.left, xl)
+        right = run(self.right, xr)
         y = ops.concat_joined([left, right], relu=False)
         y = ops.channel_dropout(y, self.dropout.p, self.training)
         y = ops.join(y, x, relu=True)                 # activation(input + x)

@@ -1265,10 +1265,15 @@ class ConvUnitFn(Function):
             call('tss_conv3x3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(w_tnc16),
                  ptr(y), ld(y), stats, B, Hin, Win, cfg.cin, Cout, s, d, dt, st)
         elif cfg.kind in ('dense1d_w', 'dense1d_h'):
-            w_tnc = torch.empty((3, Cout, cfg.cin), dtype=torch.float32, device=dev)
-            call('tss_permute_wtaps', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, 3, st)
-            call('tss_conv1d3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(bias), ptr(y), ld(y), stats,
-                 B, Hin, Win, cfg.cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
+            axis = 0 if cfg.kind == 'dense1d_w' else 1
+            if N.lib().tss_conv1d3_lean_supported(cfg.cin, Cout, dt):      # reads the layer's own weight tensor
+                call('tss_conv1d3_fwd_w', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(weight), ptr(bias), ptr(y), ld(y), stats,
+                     B, Hin, Win, cfg.cin, Cout, axis, d, dt, st)
+            else:
+                w_tnc = torch.empty((3, Cout, cfg.cin), dtype=torch.float32, device=dev)
+                call('tss_permute_wtaps', ptr(weight), ptr(w_tnc), None, Cout, cfg.cin, 3, st)
+                call('tss_conv1d3_fwd', ptr(x), ld(x), *aff, int(cfg.in_relu), ptr(w_tnc), ptr(bias), ptr(y), ld(y), stats,
+                     B, Hin, Win, cfg.cin, Cout, axis, d, dt, st)
         else:  # stem
             if bias is not None:
                 raise NotImplementedError('HIP path: stem convolution with bias')
@@ -1529,10 +1534,14 @@ class ConvUnitFn(Function):
                     call('tss_dwconv3x3_bwd_data', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
                          ptr(ws) if defer else None, ptr(dw) if defer else None, B, Hin, Win, Cout, s, d, dt, st)
                 elif cfg.kind in ('dense1d_w', 'dense1d_h'):
-                    w_tcn = torch.empty((3, Cin, Cout), dtype=torch.float32, device=dev)
-                    call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Cout, Cin, 3, st)
-                    call('tss_conv1d3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
-                         B, Hin, Win, Cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
+                    if N.lib().tss_conv1d3_lean_supported(Cin, Cout, dt):
+                        call('tss_conv1d3_bwd_data_w', *gargs, ptr(weight), *margs, ptr(e_in), ld(e_in), bst,
+                             B, Hin, Win, Cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
+                    else:
+                        w_tcn = torch.empty((3, Cin, Cout), dtype=torch.float32, device=dev)
+                        call('tss_permute_wtaps', ptr(weight), None, ptr(w_tcn), Cout, Cin, 3, st)
+                        call('tss_conv1d3_bwd_data', *gargs, ptr(w_tcn), *margs, ptr(e_in), ld(e_in), bst,
+                             B, Hin, Win, Cin, Cout, 0 if cfg.kind == 'dense1d_w' else 1, d, dt, st)
                 elif cfg.kind == 'ckk' or s != 1:
                     # general tap grid / transposed gather of a strided layer (generic implicit-GEMM kernel)
                     nt = cfg.kh * cfg.kw
@@ -2031,6 +2040,40 @@ class ChannelShuffleFn(Function):
         call('tss_channel_shuffle', ptr(dy), ld(dy), ptr(dx), ld(dx), npix(dy), dy.shape[1], dy.shape[1] // ctx.groups,
              N.dtype_code(dy.dtype), stream())
         return dx, None
+
+
+def split_fork(x):
+    """(x[:, :C/2], x[:, C/2:], x) for a unit that runs two branches on torch.chunk(input, 2, 1) and adds the whole input back
+    (SSnbtBlock, TSS/models/lednet.py:112-124): three views, no copy; the gradient is cat(g_left, g_right) + g_skip in ONE pass
+    (tss_cat2_add) instead of autograd's two zero-filled tensors, two slice copies and two additions."""
+    x = to_nhwc(materialize(x))
+    if x.shape[1] % 16:
+        raise NotImplementedError('HIP path: a split unit needs a multiple of 16 channels')
+    return SplitForkFn.apply(x)
+
+
+class SplitForkFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        half = x.shape[1] // 2
+        return x[:, :half], x[:, half:], x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gl, gr, gs):
+        ref = gl if gl is not None else (gr if gr is not None else gs)
+        if ref is None:
+            return None
+        B, _, H, W = ref.shape
+        half = (ref.shape[1] // 2) if (gl is None and gr is None) else ref.shape[1]
+        if gl is None and gr is None:
+            return gs
+        gl = to_nhwc(gl) if gl is not None else new_nhwc(B, half, H, W, ref.dtype, ref.device).zero_()
+        gr = to_nhwc(gr) if gr is not None else new_nhwc(B, half, H, W, ref.dtype, ref.device).zero_()
+        gs = to_nhwc(gs) if gs is not None else None
+        out = new_nhwc(B, 2 * half, H, W, ref.dtype, ref.device)
+        call('tss_cat2_add', ptr(gl), ld(gl), ptr(gr), ld(gr), ptr(gs), ld(gs) if gs is not None else 0, ptr(out), ld(out),
+             B * H * W, half, N.dtype_code(ref.dtype), stream())
+        return out
 
 
 def concat(tensors):
