@@ -40,12 +40,15 @@ tools/trace_step.sh --model contextnet14
 cp gpurun_out/gaps.txt $out/${tag}_step_kernels_contextnet14.txt
 TRACE_MARK=upsample_head tools/trace_step.sh --mode eval --model fastscnn_aspp
 cp gpurun_out/gaps.txt $out/${tag}_eval_c5_aspp_kernels.txt
+tools/trace_step.sh --model lednet
+cp gpurun_out/gaps.txt $out/${tag}_step_kernels_lednet.txt
 echo "trace done"
 # 4. the bench lines themselves
 python3 bench.py --host-batch > $out/${tag}_bench_default.json 2> $out/default.err     # the driver's command + the PCIe-inclusive legs; extras = configs 3 and 5
 python3 bench.py --model contextnet14 --no-cpu-baseline --no-extras > $out/${tag}_bench_contextnet14.json 2> $out/ctx.err
 python3 bench.py --mode eval --model fastscnn_aspp --steps 50 --warmup 5 > $out/${tag}_bench_eval_c5_aspp.json 2> $out/eval3.err
-TSS_SYNCBN_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --syncbn --no-cpu-baseline --no-extras --no-roofline > $out/${tag}_bench_syncbn_1rank.json 2> $out/syncbn.err
+TSS_SYNCBN_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --syncbn --no-cpu-baseline --no-extras --no-roofline 2> $out/syncbn.err | grep "^{" > $out/${tag}_bench_syncbn_1rank.json
+TSS_SYNCBN_IPC=0 TSS_SYNCBN_FORCE=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 1 --syncbn --no-cpu-baseline --no-extras --no-roofline 2> $out/syncbn2.err | grep "^{" > $out/${tag}_bench_syncbn_1rank_allreduce.json
 python3 tools/graph_memset_probe.py > $out/${tag}_memset_probe.log 2>&1; cp gpurun_out/memset_probe.txt $out/${tag}_memset_probe.txt
 python3 tools/micro_atrous.py 2>&1 | grep dil > $out/${tag}_micro_atrous.txt
 TSS_CONV3X3_WSTAT=0 python3 tools/micro_atrous.py 2>&1 | grep dil >> $out/${tag}_micro_atrous.txt
@@ -53,6 +56,7 @@ python3 bench.py --model lednet --steps 20 --warmup 3 --no-cpu-baseline --no-ext
 # "what you get without this project" (SURVEY 8d): the oracle's modules on the stock PyTorch-ROCm / MIOpen path, same batch, beside the headline
 python3 bench.py --stock --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_stock.json 2> $out/stock.err
 python3 tools/micro_sweep.py > $out/${tag}_micro_sweep.txt 2>&1
+python3 tools/micro_fc1d.py 2>&1 | grep -v "amdgpu\|Warn" > $out/${tag}_micro_fc1d.txt
 echo "bench done"
 # 5. the parity table of the benchmarked kernels against the f64 oracle, written by the test itself: the tracked copy can not lag the code
 python3 -m pytest tests/test_gpu_lean_vs_oracle.py -q -x > $out/lean_parity_pytest.log 2>&1 || true
