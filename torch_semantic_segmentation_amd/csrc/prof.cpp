@@ -13,9 +13,10 @@ const KernelInfo kInfo[TSS_K_COUNT] = {
     // symbol = the kernels rocprofv3 lists for the entry point on the bf16 path (rocprofv3 prints the bool template
     // argument: <false> forward, <true> backward-data), then the general kernel the f32 / ragged shapes fall back to
     {"pwconv_fwd", "pwfast_kernel<false>|pwfast_mc_kernel<false>|convgemm_kernel"},
-    {"pwconv_bwd_data", "pwfast_kernel<true>|pwfast_mc_kernel<true>|convgemm_kernel"},
+    // (pwconv_bwd_data also carries the one-sweep backward kernels, pwbwd_kernel / pwsweep_kernel: input gradient + weight gradient)
+    {"pwconv_bwd_data", "pwfast_kernel<true>|pwfast_mc_kernel<true>|pwbwd_kernel|pwsweep_kernel|convgemm_kernel"},
     {"pwconv_bwd_weight", "wgfast_kernel|wgrad_kernel"},
-    {"conv3x3_fwd", "conv3x3_wstat_kernel|conv3x3_stream_kernel|conv3x3_lean_kernel<false>|convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "conv3x3_lean_kernel<true>|convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "wgrad_kernel"},
+    {"conv3x3_fwd", "conv3x3_wstat_kernel|conv3x3_stream_kernel|conv3x3_lean_kernel<false>|fc1d_kernel|convgemm_kernel<fwd>"}, {"conv3x3_bwd_data", "conv3x3_lean_kernel<true>|fc1d_kernel|convgemm_kernel<bwd>"}, {"conv3x3_bwd_weight", "fc1d_wgrad_kernel|wgrad_kernel"},
     {"stem3x3_fwd", "stem_fwd_mfma_kernel|convgemm_kernel"}, {"stem3x3_bwd_weight", "stem_wgrad_mfma_kernel|stem_wgrad_kernel"},
     // (dwconv3x3_bwd_data also carries the one-sweep backward, dw_bwd_roll_s{1,2}_kernel: input gradient + weight gradient)
     {"dwconv3x3_fwd", "dw_fwd_roll_kernel|dw_fwd_strip_kernel"}, {"dwconv3x3_bwd_data", "dw_bwd_roll_s1_kernel|dw_bwd_roll_s2_kernel|dw_bwd_data_strip_kernel"},
