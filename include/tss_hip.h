@@ -234,6 +234,15 @@ int tss_conv1d3_bwd_weight_sweep(const void* e, long lde, const void* yraw, long
                                  const float* ga, const float* gb, const float* gce, const float* gmu,
                                  const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
                                  int in_relu, float* ws, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* weight gradient of a square 32 / 64-channel stride-2 dense 3x3 (padding 1) in one sweep (bf16; csrc/sconv.hip): per-block rows of partial
+ * sums (9 * N * Cin floats, torch's [N][Cin][3][3] order) in ws[tss_sconv_bwd_weight_rows(...)][9*N*Cin], added by tss_dw_reduce_many.
+ * replaces: the convolution arm of DownsamplingBlock, TSS/models/lednet.py:130-131, TSS/models/esnet.py:54-56.  rows == 0: not covered.
+ * (Forward and backward-data of these layers are taken inside tss_conv3x3_fwd / tss_convkxk_fwd / tss_convkxk_bwd_data.) */
+int tss_sconv_bwd_weight_rows(int B, int Hin, int Win, int Cin, int N, int dtype);
+int tss_sconv_bwd_weight_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                               const float* ga, const float* gb, const float* gce, const float* gmu,
+                               const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
+                               int in_relu, float* ws, int B, int Hin, int Win, int Cin, int N, int dtype, void* stream);
 /* bf16 unfold for the weight gradient of a three-tap layer: col[p][c*3 + tap] = act(x[p + off(tap)][c]) (0 outside the image); dW in torch's
  * [N][C][1][3] / [N][C][3][1] layout is then tss_pwconv_bwd_weight(e, ..., x = col, ldx = 3*C, no affine, K = 3*C). */
 int tss_im2col1d3(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,

@@ -82,6 +82,9 @@ def product_chain(spec):
             blocks.append(nn.UpsamplingBilinear2d(size=kw.get('size'), scale_factor=kw.get('scale')))
         elif kind == 'bneck':
             blocks.append(F.BottleneckBlock(cin, cout, stride=kw.get('stride', 1), expansion=kw.get('expansion', 6)))
+        elif kind == 'down':    # LEDNet's DownsamplingBlock: stride-2 3x3 (csrc/sconv.hip) || 2x2 max-pool -> BatchNorm -> ReLU
+            L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
+            blocks.append(L.DownsamplingBlock(cin, cout))
         elif kind == 'fc':      # LEDNet's 1x3 -> ReLU -> 3x1 -> BatchNorm -> [ReLU] (csrc/fc1d.hip)
             L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
             blocks.append(L.FactorizedConvBlock(cin, cout, kw.get('dilation', 1), use_relu=act))
@@ -105,6 +108,9 @@ def oracle_chain(spec):
             blocks.append(nn.UpsamplingBilinear2d(size=kw.get('size'), scale_factor=kw.get('scale')))
         elif kind == 'bneck':
             blocks.append(O._FastResidual(cin, cout, stride=kw.get('stride', 1), expansion=kw.get('expansion', 6)))
+        elif kind == 'down':
+            from oracle import zoo as OZ
+            blocks.append(OZ.Down(cin, cout))
         elif kind == 'fc':
             from oracle import aspp as OA
             blocks.append(OA.factorized(cin, kw.get('dilation', 1), act=act))
@@ -339,6 +345,22 @@ FC_CASES = [
     ('baseline_ssnbt_16', [('fc', 16, 16, {}), ('fc', 16, 16, {'act': False})], (2, 16, 512, 1024)),
     ('baseline_ssnbt_64_d9', [('fc', 64, 64, {}), ('fc', 64, 64, {'dilation': 9, 'act': False})], (8, 64, 128, 256)),
 ]
+
+
+# the stride-2 3x3 arm of the downsampling blocks (csrc/sconv.hip: forward, parity-class backward-data, one-sweep weight gradient), with a
+# 1x1 consumer behind the block so that its BatchNorm + ReLU stay pending; odd widths / heights of the OUTPUT map, both channel counts
+DOWN_CASES = [
+    ('down_32_64', [('down', 32, 64, {}), ('pw', 64, 48, {})], (2, 32, 38, 70)),
+    ('down_64_128', [('down', 64, 128, {}), ('pw', 128, 64, {})], (3, 64, 22, 36)),
+    ('baseline_down_32_64', [('down', 32, 64, {}), ('pw', 64, 64, {})], (2, 32, 256, 512)),
+]
+
+
+@pytest.mark.parametrize('case', DOWN_CASES, ids=[c[0] for c in DOWN_CASES])
+def test_downsampling_block_vs_f64_oracle(case):
+    name, spec, shape = case
+    bad = check(name, *run_case(spec, shape), cap=CAP_BLOCK, direct=DIRECT_BLOCK)
+    assert not bad, bad
 
 
 @pytest.mark.parametrize('train', [True, False], ids=['train', 'frozen'])

@@ -503,6 +503,14 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 }  // namespace
 
 extern int g_tss_disable_fast;   // pwfast.hip
+// sconv.hip: lean bf16 kernels of the stride-2 dense 3x3 (false: shape not covered)
+bool tss_sconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                   const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                   int B, int Hin, int Win, int Cin, int N, hipStream_t stream);
+bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                        const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                        const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                        void* e_in, long ldei, double* bstats, int B, int Hin, int Win, int Cin, int N, hipStream_t stream);
 // fc1d.hip: lean bf16 kernels of the three-tap layers (false: shape not covered)
 bool tss_fc1d_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                   const float* w_tnc, int torch_layout, const float* bias, void* y, long ldy, double* stats,
@@ -673,6 +681,11 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* 
       return tss::check_last("conv3x3_lean_fwd");
   }
   TSS_REQUIRE(w_tnc, TSS_ERR_SHAPE);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {   // sconv.hip
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes, 18.0 * (double)g.P * Cin * N);
+    if (tss_sconv_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, nullptr, y, ldy, stats, B, Hin, Win, Cin, N, (hipStream_t)stream))
+      return tss::check_last("sconv_fwd");
+  }
   return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes);
 }
 
@@ -782,6 +795,11 @@ int tss_convkxk_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {   // sconv.hip
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * Hin * Win * Cin + (double)g.P * N) * 2.0, 18.0 * (double)g.P * Cin * N);
+    if (tss_sconv_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, Hin, Win, Cin, N, (hipStream_t)stream))
+      return tss::check_last("sconv_fwd");
+  }
   return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * Hin * Win * Cin + (double)g.P * N) * esz(dtype));
 }
 
@@ -796,6 +814,14 @@ int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
               stride >= 1 && dil >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81 && w_tcn, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {
+    const double po = (double)B * ((Hin - 1) / 2 + 1) * ((Win - 1) / 2 + 1);
+    tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (po * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin * (xraw ? 2 : 1)) * 2.0,
+                        18.0 * po * Cin * N);
+    if (tss_sconv_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+                           B, Hin, Win, Cin, N, (hipStream_t)stream))
+      return tss::check_last("sconv_bwd_data");
+  }
   GemmArgs g = {};
   g.Hin = (Hin - 1) / stride + 1; g.Win = (Win - 1) / stride + 1;      // the SOURCE grid of the gather: the layer's output
   g.Hout = Hin; g.Wout = Win; g.stride = 1; g.tstride = stride; g.dil = dil; g.tap_sign = -1; g.Cin = N; g.gkh = kh; g.gkw = kw;

@@ -180,8 +180,14 @@ def downsampling_unit(x, conv, bn, act_dtype=None):
     n1 = conv.out_channels
     cp = ops.round_up(n1, 8)
     w = conv.weight if cp == n1 else F.pad(conv.weight, (0, 0, 0, 0, 0, 0, 0, cp - n1))
-    y1 = ops.conv_unit(x, conv, None, False, out_dtype=act_dtype, weight=w, bias=None, cout=cp)
-    z = ops.pool_concat(y1.raw, conv.bias, x, n1)
+    is_image = x.shape[1] % 8 != 0
+    if is_image or conv.bias is None:      # the stem kernel has no bias input: the bias is added while the halves are written side by side
+        y1 = ops.conv_unit(x, conv, None, False, out_dtype=act_dtype, weight=w, bias=None, cout=cp)
+        z = ops.pool_concat(y1.raw, conv.bias, x, n1)
+    else:                                   # bias in the convolution's epilogue: conv(x) + bias is rounded once, as the reference's tensor is
+        b = conv.bias if cp == n1 else F.pad(conv.bias, (0, cp - n1))
+        y1 = ops.conv_unit(x, conv, None, False, out_dtype=act_dtype, weight=w, bias=b, cout=cp)
+        z = ops.pool_concat(y1.raw, None, x, n1)
     return ops.batch_norm(z, bn, relu=True)
 
 

@@ -1399,7 +1399,7 @@ class ConvUnitFn(Function):
                     # those of every other such layer, in one launch at the end of this backward pass
                     ws = torch.empty((rows, Cout * Cin * 3), dtype=torch.float32, device=dev)
                     call('tss_conv1d3_bwd_weight_sweep', *gargs, *xargs, ptr(ws), B, Hin, Win, Cin, Cout, axis, d, dt, wst)
-                    rows_after_join = (ws, rows)      # the sweep may be on the side stream: its rows are queued / added after the join below
+                    rows_after_join = (ws, rows, Cout * Cin * 3)      # the sweep may be on the side stream: its rows are queued / added after the join below
                 elif (e.dtype == torch.bfloat16 and Cin % 8 == 0 and Cout % 8 == 0 and unfold_1d_wgrad and not N.fast_paths_disabled()):
                     # unfold once (bf16 [P][Cin*3], column c*3 + tap), then the pipelined pointwise MFMA weight-gradient kernel with
                     # K = 3*Cin writes torch's [N][Cin][1][3] / [N][Cin][3][1] layout directly (as the dense 3x3 below)
@@ -1417,6 +1417,12 @@ class ConvUnitFn(Function):
                     call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, axis, d, dt, wst)
             elif cfg.kind == 'ckk':
                 call('tss_convkxk_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, cfg.kh, cfg.kw, s, d, dt, wst)
+            elif (cfg.kind == 'dense' and s == 2 and d == 1 and N.lib().tss_sconv_bwd_weight_rows(B, Hin, Win, Cin, Cout, dt)):
+                # stride-2 3x3 of the downsampling blocks: one sweep over e and x (csrc/sconv.hip), rows added at the end of the pass
+                rows = N.lib().tss_sconv_bwd_weight_rows(B, Hin, Win, Cin, Cout, dt)
+                ws = torch.empty((rows, Cout * Cin * 9), dtype=torch.float32, device=dev)
+                call('tss_sconv_bwd_weight_sweep', *gargs, *xargs, ptr(ws), B, Hin, Win, Cin, Cout, dt, wst)
+                rows_after_join = (ws, rows, Cout * Cin * 9)
             elif (e.dtype == torch.bfloat16 and s == 1 and y is not None and (Cin * 9) % 8 == 0 and Cout % 8 == 0
                   and not N.fast_paths_disabled()):
                 # unfold once (bf16 [P][Cin*9], column c*9 + tap), then the pointwise MFMA weight-gradient kernel with
@@ -1583,11 +1589,11 @@ class ConvUnitFn(Function):
         if side is not None:
             main.wait_stream(side)
         if rows_after_join is not None:
-            ws_, rows_ = rows_after_join
+            ws_, rows_, ncols_ = rows_after_join
             if dw_ret is None and batch_dw_reductions:
-                _defer_dw_reduction(ws_, dw, Cout * Cin * 3, rows_, p_weight)
+                _defer_dw_reduction(ws_, dw, ncols_, rows_, p_weight)
             else:
-                _reduce_rows_now(ws_, dw, Cout * Cin * 3, rows_)
+                _reduce_rows_now(ws_, dw, ncols_, rows_)
         return e_in, dw_ret, dgamma, dbeta, dbias_ret, None
 
 
