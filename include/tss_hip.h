@@ -297,6 +297,20 @@ int tss_mul_addrows_bwd(const void* g, long ldg, const void* u, long ldu, const 
 int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream);
 int tss_cat2_add(const void* gl, long ldl, const void* gr, long ldr, const void* gs, long lds, void* out, long ldo, long P, int half,
                  int dtype, void* stream);
+/* ---- tail of LEDNet's SS-nbt unit in one pass each way (csrc/ssnbt.hip) ------------------------------------------------------------
+ * replaces: cat([left(l), right(r)]) -> Dropout2d -> activation(input + x) -> channel_shuffle(x, 2) of SSnbtBlock.forward,
+ *           TSS/models/lednet.py:112-124.  left / right: the branches' raw convolution outputs [P][C/2] with their pending BatchNorm as
+ *           (mean, scale, shift); m: [B][C] dropout multipliers (0 or 1/(1-p)) or NULL.
+ * fwd: out[p][2j+g] = relu(x[p][g C/2 + j] + m[b][g C/2 + j] * bn_g(raw_g[p][j])).
+ * bwd: gs = unshuffle(d(out) * [out > 0]) (gradient of the skip); e = gs * m ([P][C] = left | right; NULL with m NULL: e == gs);
+ *      stats_l / stats_r: BatchNorm-backward slab rows of the branches (sum e, sum e (raw - mean); [tss_stat_slabs()][C]). */
+int tss_ssnbt_tail_fwd(const void* left, long ldl, const float* mean_l, const float* scale_l, const float* shift_l,
+                       const void* right, long ldr, const float* mean_r, const float* scale_r, const float* shift_r,
+                       const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream);
+int tss_ssnbt_tail_bwd(const void* dout, long lddo, const void* out, long ldo,
+                       const void* left, long ldl, const float* mean_l, const void* right, long ldr, const float* mean_r,
+                       const float* m, void* e, long lde, void* gs, long ldgs, double* stats_l, double* stats_r,
+                       int B, long HW, int C, int dtype, void* stream);
 
 /* channel_shuffle(x, groups) TSS/models/lednet.py:183-188: y[:, j * groups + i] = x[:, i * (C / groups) + j] (its own inverse with
  * groups' = C / groups: the backward is the same entry) */

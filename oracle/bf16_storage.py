@@ -64,8 +64,10 @@ class _DitherBF16(torch.autograd.Function):
         return _DitherBF16._dither(g, ctx.gen), None
 
 
+from . import aspp as _aspp
+
 _STORED = (nn.Conv2d, nn.AdaptiveAvgPool2d, nn.UpsamplingBilinear2d, nn.Upsample,
-           nets.InvertedResidual, nets.Pyramid, nets.FastFusion, nets.CtxFusion)
+           nets.InvertedResidual, nets.Pyramid, nets.FastFusion, nets.CtxFusion, _aspp.SSnbt)
 
 
 def emulate_bf16_storage(module, root=True, dither=None):

@@ -237,7 +237,5 @@ class SSnbtBlock(nn.Module):
         xl, xr, x = ops.split_fork(x)                 # torch.chunk(input, 2, 1) + the skip: three views of the same NHWC rows
         left = run(self.left, xl)
         right = run(self.right, xr)
-        y = ops.concat_joined([left, right], relu=False)
-        y = ops.channel_dropout(y, self.dropout.p, self.training)
-        y = ops.join(y, x, relu=True)                 # activation(input + x)
-        return channel_shuffle(y, 2)
+        # cat -> Dropout2d -> activation(input + x) -> channel_shuffle(x, 2): one pass (csrc/ssnbt.hip)
+        return ops.ssnbt_tail(left, right, x, self.dropout.p, self.training)

@@ -2082,6 +2082,60 @@ class SplitForkFn(Function):
         return out
 
 
+fuse_ssnbt_tail = os.environ.get('TSS_SSNBT_TAIL', '1') != '0'     # A/B: 0 = concat_joined, channel_dropout, join, channel_shuffle as four operators
+
+
+def ssnbt_tail(left, right, x, drop_p, training):
+    """channel_shuffle(relu(x + dropout2d(cat([bn(left), bn(right)], 1))), 2): the tail of SSnbtBlock.forward (TSS/models/lednet.py:112-124)
+    in one pass each way (csrc/ssnbt.hip).  left / right: Deferreds whose BatchNorm (no ReLU) is still pending; x: the unit's input."""
+    dl, dr = as_deferred(left), as_deferred(right)
+    x = to_nhwc(materialize(x))
+    ok = (fuse_ssnbt_tail and dl.link is not None and dr.link is not None and not dl.relu and not dr.relu
+          and dl.raw.shape == dr.raw.shape and dl.raw.dtype == dr.raw.dtype == x.dtype and dl.raw.shape[1] % 8 == 0
+          and x.shape[1] == 2 * dl.raw.shape[1] and tuple(x.shape[2:]) == tuple(dl.raw.shape[2:]) and x.shape[0] == dl.raw.shape[0])
+    if not ok:
+        y = concat_joined([dl, dr], relu=False)
+        y = channel_dropout(y, drop_p, training)
+        return channel_shuffle(join(y, x, relu=True), 2)
+    dl.take(); dr.take()
+    m = None
+    if training and drop_p > 0.0:
+        keep = 1.0 - float(drop_p)
+        m = (torch.rand((x.shape[0], x.shape[1]), device=x.device) < keep).to(torch.float32)
+        if keep > 0.0:
+            m = m / keep
+    cfg = JoinCfg()
+    cfg.links = [dl.link, dr.link]
+    return SSnbtTailFn.apply(cfg, dl.raw, dr.raw, x, m)
+
+
+class SSnbtTailFn(Function):
+    @staticmethod
+    def forward(ctx, cfg, l, r, x, m):
+        B, C, H, W = x.shape
+        out = new_nhwc(B, C, H, W, x.dtype, x.device)
+        call('tss_ssnbt_tail_fwd', ptr(l), ld(l), *_aff(cfg.links[0]), ptr(r), ld(r), *_aff(cfg.links[1]), ptr(x), ld(x), ptr(m),
+             ptr(out), ld(out), B, H * W, C, N.dtype_code(x.dtype), stream())
+        ctx.cfg = cfg
+        ctx.save_for_backward(out, l, r, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, l, r, m = ctx.saved_tensors
+        ll, lr = ctx.cfg.links
+        dout = to_nhwc(dout)
+        B, C, H, W = out.shape
+        half = C // 2
+        gs = new_nhwc(B, C, H, W, dout.dtype, dout.device)
+        e = new_nhwc(B, C, H, W, dout.dtype, dout.device) if m is not None else None
+        call('tss_ssnbt_tail_bwd', ptr(dout), ld(dout), ptr(out), ld(out), ptr(l), ld(l), ptr(ll.mean), ptr(r), ld(r), ptr(lr.mean),
+             ptr(m), ptr(e), ld(e) if e is not None else 0, ptr(gs), ld(gs), ptr(ll.bstats), ptr(lr.bstats), B, H * W, C,
+             N.dtype_code(dout.dtype), stream())
+        ee = e if e is not None else gs
+        return None, ee[:, :half], ee[:, half:], gs, None
+
+
 def concat(tensors):
     """torch.cat(tensors, dim=1) of equally sized activation tensors into one NHWC buffer (tss_copy_nhwc per operand; the
     gradient is a channel slice of the incoming one, no copy).  Channel counts must be multiples of 8."""
