@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18', 'fastscnn_aspp', 'lednet'])
+    ap.add_argument('--model', default='fastscnn', choices=['fastscnn', 'contextnet12', 'contextnet14', 'contextnet18', 'fastscnn_aspp', 'lednet', 'esnet'])
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--mode', default='train', choices=['train', 'eval'],
                     help='eval = SURVEY config C5: eval-mode no-grad forward, default 1 x 3 x 2048 x 4096 (never the headline line)')
@@ -73,7 +73,8 @@ def build_model(name):
     C = importlib.import_module('torch_semantic_segmentation_amd.models.contextnet')
     A = importlib.import_module('torch_semantic_segmentation_amd.models.aspp')
     L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
-    ctor = {'lednet': L.lednet, 'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12, 'contextnet14': C.contextnet14,
+    E = importlib.import_module('torch_semantic_segmentation_amd.models.esnet')
+    ctor = {'esnet': E.ESNet, 'lednet': L.lednet, 'fastscnn': F.fastscnn, 'contextnet12': C.contextnet12, 'contextnet14': C.contextnet14,
             'contextnet18': C.contextnet18, 'fastscnn_aspp': A.fastscnn_aspp}[name]
     torch.manual_seed(0)
     return ctor(3, 19), tssa

@@ -234,6 +234,15 @@ int tss_conv1d3_bwd_weight_sweep(const void* e, long lde, const void* yraw, long
                                  const float* ga, const float* gb, const float* gce, const float* gmu,
                                  const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
                                  int in_relu, float* ws, int B, int H, int W, int Cin, int N, int axis, int dil, int dtype, void* stream);
+/* weight gradient of a square T-tap layer along one axis -- 64 channels x 5 taps (FCUBlock(64, 5), TSS/models/esnet.py:83-123) or 128 channels
+ * x 3 taps (FPCUBlock, esnet.py:126-166) -- in one sweep (bf16; csrc/fcg.hip): per-block rows of partial sums (T * N * Cin floats, torch's
+ * [N][Cin][taps] order) in ws[tss_convtap_bwd_weight_rows(...)][T*N*Cin], added by tss_dw_reduce_many.  rows == 0: not covered.
+ * (Forward and backward-data of these layers are taken inside tss_conv1d3_* / tss_convkxk_*.) */
+int tss_convtap_bwd_weight_rows(long P, int Cin, int N, int T, int dtype);
+int tss_convtap_bwd_weight_sweep(const void* e, long lde, const void* yraw, long ldyr,
+                                 const float* ga, const float* gb, const float* gce, const float* gmu,
+                                 const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
+                                 int in_relu, float* ws, int B, int H, int W, int Cin, int N, int T, int axis, int dil, int dtype, void* stream);
 /* weight gradient of a square 32 / 64-channel stride-2 dense 3x3 (padding 1) in one sweep (bf16; csrc/sconv.hip): per-block rows of partial
  * sums (9 * N * Cin floats, torch's [N][Cin][3][3] order) in ws[tss_sconv_bwd_weight_rows(...)][9*N*Cin], added by tss_dw_reduce_many.
  * replaces: the convolution arm of DownsamplingBlock, TSS/models/lednet.py:130-131, TSS/models/esnet.py:54-56.  rows == 0: not covered.

@@ -85,6 +85,9 @@ def product_chain(spec):
         elif kind == 'down':    # LEDNet's DownsamplingBlock: stride-2 3x3 (csrc/sconv.hip) || 2x2 max-pool -> BatchNorm -> ReLU
             L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
             blocks.append(L.DownsamplingBlock(cin, cout))
+        elif kind in ('fcu', 'pfcu'):   # ESNet's factorized units: 64 channels x 5 taps, 128 channels x 3 dilated taps (csrc/fcg.hip), 16 x 3 (fc1d.hip)
+            E = importlib.import_module('torch_semantic_segmentation_amd.models.esnet')
+            blocks.append(E.FCUBlock(cin, cout, kw['k']) if kind == 'fcu' else E.FPCUBlock(cin, cout, kw['dil']))
         elif kind == 'ssnbt':   # a whole split-shuffle unit: split (ops.split_fork), two branches (fc1d.hip), fused tail (ssnbt.hip)
             L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
             blocks.append(L.SSnbtBlock(cin, cout, dilation=kw.get('dilation', 1), dropout_p=0.0))
@@ -114,6 +117,9 @@ def oracle_chain(spec):
         elif kind == 'down':
             from oracle import zoo as OZ
             blocks.append(OZ.Down(cin, cout))
+        elif kind in ('fcu', 'pfcu'):
+            from oracle import zoo as OZ
+            blocks.append(OZ.FactorizedUnit(cin, kw['k']) if kind == 'fcu' else OZ.ParallelFactorizedUnit(cin, kw['dil']))
         elif kind == 'ssnbt':
             from oracle import aspp as OA
             blocks.append(OA.SSnbt(cin, kw.get('dilation', 1)))
@@ -222,6 +228,11 @@ def check(case, want, lean, general, cap=None, direct=None):
         e_lean, e_gen, e_dir = l2f(lean[k], want[k], kind), l2f(general[k], want[k], kind), l2f(lean[k], general[k], kind)
         e_noise = l2f(noise_a[k], noise_b[k], kind)
         bound = min(NOISE_K * e_noise + NOISE_FLOOR[kind], cap[kind])
+        if e_noise > cap[kind]:
+            # two runs of the ORACLE under the storage format's noise model already differ by more than the ceiling: the tensor is not determined
+            # at this precision (e.g. the bias of a convolution directly in front of a train-mode BatchNorm, whose gradient is analytically
+            # zero -- ESNet's factorized pairs have one each); the noise-derived bound alone applies, and lean must still equal general
+            bound = NOISE_K * e_noise
         ok = e_lean <= bound and e_dir <= direct
         _ROWS.append('%-30s %-30s lean %.3e  general %.3e  noise %.3e  bound %.3e  lean-vs-general %.3e%s'
                      % (case, k, e_lean, e_gen, e_noise, bound, e_dir, '' if ok else '  <-- FAIL'))
@@ -374,6 +385,27 @@ SSNBT_CASES = [
 @pytest.mark.parametrize('train', [True, False], ids=['train', 'frozen'])
 @pytest.mark.parametrize('case', SSNBT_CASES, ids=[c[0] for c in SSNBT_CASES])
 def test_split_shuffle_unit_vs_f64_oracle(case, train):
+    name, spec, shape = case
+    if not train and name.startswith('baseline'):
+        pytest.skip('frozen statistics at the small sizes only')
+    bad = check('%s_%s' % (name, 'train' if train else 'frozen'), *run_case(spec, shape, train=train), cap=CAP_BLOCK, direct=DIRECT_BLOCK)
+    assert not bad, bad
+
+
+# ESNet's factorized units on the tap-by-tap kernels (csrc/fcg.hip): FCUBlock(64, K = 5) and FPCUBlock(128, dilations 2 / 5 / 9), biases in the
+# convolutions' epilogues, ragged widths / row groups, and both at a benchmark-sized map
+ES_CASES = [
+    ('fcu_64_k5', [('fcu', 64, 64, {'k': 5})], (2, 64, 21, 38)),
+    ('pfcu_128', [('pfcu', 128, 128, {'dil': [2, 5, 9]})], (2, 128, 19, 26)),
+    ('fcu_16_k3', [('fcu', 16, 16, {'k': 3}), ('fcu', 16, 16, {'k': 3})], (2, 16, 22, 40)),
+    ('baseline_fcu_64_k5', [('fcu', 64, 64, {'k': 5})], (2, 64, 256, 512)),
+    ('baseline_pfcu_128', [('pfcu', 128, 128, {'dil': [2, 5, 9]})], (2, 128, 128, 256)),
+]
+
+
+@pytest.mark.parametrize('train', [True, False], ids=['train', 'frozen'])
+@pytest.mark.parametrize('case', ES_CASES, ids=[c[0] for c in ES_CASES])
+def test_esnet_factorized_units_vs_f64_oracle(case, train):
     name, spec, shape = case
     if not train and name.startswith('baseline'):
         pytest.skip('frozen statistics at the small sizes only')

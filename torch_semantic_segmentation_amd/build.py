@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 LIB = os.path.join(HERE, 'libtss_hip.so')
-SOURCES = ['convgemm.hip', 'pwfast.hip', 'pwbwd.hip', 'pwsweep.hip', 'bneck.hip', 'conv3x3.hip', 'fc1d.hip', 'sconv.hip', 'atrous.hip', 'wstat.hip', 'stem.hip', 'wgrad.hip', 'dwconv.hip', 'dwroll.hip', 'updw.hip', 'pointwise.hip', 'xchg.hip', 'resample.hip', 'ppm.hip', 'loss.hip', 'ohem.hip', 'hostio.hip', 'gate.hip', 'zoo.hip', 'ssnbt.hip', 'prof.cpp']
+SOURCES = ['convgemm.hip', 'pwfast.hip', 'pwbwd.hip', 'pwsweep.hip', 'bneck.hip', 'conv3x3.hip', 'fc1d.hip', 'fcg.hip', 'sconv.hip', 'atrous.hip', 'wstat.hip', 'stem.hip', 'wgrad.hip', 'dwconv.hip', 'dwroll.hip', 'updw.hip', 'pointwise.hip', 'xchg.hip', 'resample.hip', 'ppm.hip', 'loss.hip', 'ohem.hip', 'hostio.hip', 'gate.hip', 'zoo.hip', 'ssnbt.hip', 'prof.cpp']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function',
          '-I' + INCLUDE, '-I' + CSRC]

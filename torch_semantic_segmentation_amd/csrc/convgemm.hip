@@ -503,6 +503,14 @@ inline size_t esz(int dtype) { return dtype == TSS_BF16 ? 2 : 4; }
 }  // namespace
 
 extern int g_tss_disable_fast;   // pwfast.hip
+// fcg.hip: lean bf16 kernels of the 64-channel five-tap and 128-channel three-tap layers (false: shape not covered)
+bool tss_fcg_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                 const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
+                 int B, int H, int W, int Cin, int N, int T, int axis, int dil, hipStream_t stream);
+bool tss_fcg_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
+                      const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
+                      const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
+                      void* e_in, long ldei, double* bstats, int B, int H, int W, int Cin, int N, int T, int axis, int dil, hipStream_t stream);
 // sconv.hip: lean bf16 kernels of the stride-2 dense 3x3 (false: shape not covered)
 bool tss_sconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
@@ -736,6 +744,11 @@ int tss_conv1d3_fwd(const void* x, long ldx, const float* in_mean, const float* 
     if (tss_fc1d_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, 0, bias, y, ldy, stats, B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
       return tss::check_last("fc1d_fwd");
   }
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && N == 128) {   // fcg.hip
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)B * H * W * (Cin + N) * 2.0, 2.0 * B * H * W * 3.0 * Cin * N);
+    if (tss_fcg_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, H, W, Cin, N, 3, axis, dil, (hipStream_t)stream))
+      return tss::check_last("fcg_fwd");
+  }
   GemmArgs g = {};
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = 1; g.Cin = Cin;
   g.tap0 = axis == 0 ? 3 : 1; g.tstep1 = axis == 0 ? 0 : 2;
@@ -762,6 +775,13 @@ int tss_conv1d3_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
     if (tss_fc1d_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, 0, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
                           B, H, W, Cin, N, axis, dil, (hipStream_t)stream))
       return tss::check_last("fc1d_bwd_data");
+  }
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && Cin == N && N == 128) {
+    tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (double)B * H * W * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * 2.0,
+                        2.0 * B * H * W * 3.0 * Cin * N);
+    if (tss_fcg_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+                         B, H, W, Cin, N, 3, axis, dil, (hipStream_t)stream))
+      return tss::check_last("fcg_bwd_data");
   }
   GemmArgs g = {};
   g.Hin = H; g.Win = W; g.Hout = H; g.Wout = W; g.stride = 1; g.dil = dil; g.tap_sign = -1; g.Cin = N;
@@ -795,6 +815,12 @@ int tss_convkxk_fwd(const void* x, long ldx, const float* in_mean, const float* 
   g.a0 = x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w_tnc; g.wrs = Cin; g.wcs = 1; g.wts = (long)N * Cin; g.bias = bias;
   g.y = y; g.ldy = ldy; g.stats = stats;
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && stride == 1 && Cin == N && N == 64 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1))) {   // fcg.hip
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, (double)g.P * (Cin + N) * 2.0, 2.0 * (double)g.P * 5.0 * Cin * N);
+    if (tss_fcg_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, Hin, Win, Cin, N, 5, kh == 1 ? 0 : 1, dil,
+                    (hipStream_t)stream))
+      return tss::check_last("fcg_fwd");
+  }
   if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {   // sconv.hip
     tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * Hin * Win * Cin + (double)g.P * N) * 2.0, 18.0 * (double)g.P * Cin * N);
     if (tss_sconv_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, Hin, Win, Cin, N, (hipStream_t)stream))
@@ -814,6 +840,13 @@ int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
               stride >= 1 && dil >= 1 && kh >= 1 && kw >= 1 && (kh & 1) && (kw & 1) && kh * kw <= 81 && w_tcn, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N), TSS_ERR_SHAPE);
   TSS_REQUIRE(!bstats || xraw, TSS_ERR_SHAPE);
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && stride == 1 && Cin == N && N == 64 && ((kh == 1 && kw == 5) || (kh == 5 && kw == 1))) {
+    const double px = (double)B * Hin * Win;
+    tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, px * (N * (yraw ? 2 : 1) + Cin * (xraw ? 2 : 1)) * 2.0, 2.0 * px * 5.0 * Cin * N);
+    if (tss_fcg_bwd_data(e, lde, yraw, ldyr, ga, gb, gce, gmu, w_tcn, xraw, ldx, in_mean, in_scale, in_bias, in_relu, e_in, ldei, bstats,
+                         B, Hin, Win, Cin, N, 5, kh == 1 ? 0 : 1, dil, (hipStream_t)stream))
+      return tss::check_last("fcg_bwd_data");
+  }
   if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {
     const double po = (double)B * ((Hin - 1) / 2 + 1) * ((Win - 1) / 2 + 1);
     tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (po * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin * (xraw ? 2 : 1)) * 2.0,

@@ -1394,7 +1394,12 @@ class ConvUnitFn(Function):
             elif cfg.kind in ('dense1d_w', 'dense1d_h'):
                 axis = 0 if cfg.kind == 'dense1d_w' else 1
                 rows = N.lib().tss_conv1d3_bwd_weight_rows(P, Cin, Cout, dt)
-                if rows:
+                rows_w = 0 if rows else N.lib().tss_convtap_bwd_weight_rows(P, Cin, Cout, 3, dt)      # 128-channel layers (csrc/fcg.hip)
+                if rows_w:
+                    ws = torch.empty((rows_w, Cout * Cin * 3), dtype=torch.float32, device=dev)
+                    call('tss_convtap_bwd_weight_sweep', *gargs, *xargs, ptr(ws), B, Hin, Win, Cin, Cout, 3, axis, d, dt, wst)
+                    rows_after_join = (ws, rows_w, Cout * Cin * 3)
+                elif rows:
                     # one sweep over e, y and x (csrc/fc1d.hip); the rows of per-block partial sums are added to the gradient together with
                     # those of every other such layer, in one launch at the end of this backward pass
                     ws = torch.empty((rows, Cout * Cin * 3), dtype=torch.float32, device=dev)
@@ -1415,6 +1420,13 @@ class ConvUnitFn(Function):
                          P, Cin * 3, Cout, dt, None, wst)
                 else:
                     call('tss_conv1d3_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, axis, d, dt, wst)
+            elif (cfg.kind == 'ckk' and s == 1 and (cfg.kh, cfg.kw) in ((1, 5), (5, 1))
+                  and N.lib().tss_convtap_bwd_weight_rows(P, Cin, Cout, 5, dt)):
+                # ESNet's 64-channel 1x5 / 5x1 layers: one sweep over e, y and x (csrc/fcg.hip), rows added at the end of the pass
+                rows = N.lib().tss_convtap_bwd_weight_rows(P, Cin, Cout, 5, dt)
+                ws = torch.empty((rows, Cout * Cin * 5), dtype=torch.float32, device=dev)
+                call('tss_convtap_bwd_weight_sweep', *gargs, *xargs, ptr(ws), B, Hin, Win, Cin, Cout, 5, 0 if cfg.kh == 1 else 1, d, dt, wst)
+                rows_after_join = (ws, rows, Cout * Cin * 5)
             elif cfg.kind == 'ckk':
                 call('tss_convkxk_bwd_weight', *gargs, *xargs, ptr(dw), B, Hin, Win, Cin, Cout, cfg.kh, cfg.kw, s, d, dt, wst)
             elif (cfg.kind == 'dense' and s == 2 and d == 1 and N.lib().tss_sconv_bwd_weight_rows(B, Hin, Win, Cin, Cout, dt)):
