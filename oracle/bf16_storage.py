@@ -67,7 +67,7 @@ class _DitherBF16(torch.autograd.Function):
 from . import aspp as _aspp
 from . import zoo as _zoo
 
-_STORED = (nn.Conv2d, nn.AdaptiveAvgPool2d, nn.UpsamplingBilinear2d, nn.Upsample,
+_STORED = (nn.Conv2d, nn.ConvTranspose2d, nn.AdaptiveAvgPool2d, nn.UpsamplingBilinear2d, nn.Upsample,
            nets.InvertedResidual, nets.Pyramid, nets.FastFusion, nets.CtxFusion, _aspp.SSnbt,
            _zoo.FactorizedUnit, _zoo.ParallelFactorizedUnit)
 

@@ -85,6 +85,9 @@ def product_chain(spec):
         elif kind == 'down':    # LEDNet's DownsamplingBlock: stride-2 3x3 (csrc/sconv.hip) || 2x2 max-pool -> BatchNorm -> ReLU
             L = importlib.import_module('torch_semantic_segmentation_amd.models.lednet')
             blocks.append(L.DownsamplingBlock(cin, cout))
+        elif kind == 'esup':    # ESNet's UpsamplingBlock: ConvTranspose2d(3, stride 2) + bias -> BatchNorm -> ReLU (parity-class kernel of csrc/sconv.hip)
+            E = importlib.import_module('torch_semantic_segmentation_amd.models.esnet')
+            blocks.append(E.UpsamplingBlock(cin, cout))
         elif kind in ('fcu', 'pfcu'):   # ESNet's factorized units: 64 channels x 5 taps, 128 channels x 3 dilated taps (csrc/fcg.hip), 16 x 3 (fc1d.hip)
             E = importlib.import_module('torch_semantic_segmentation_amd.models.esnet')
             blocks.append(E.FCUBlock(cin, cout, kw['k']) if kind == 'fcu' else E.FPCUBlock(cin, cout, kw['dil']))
@@ -117,6 +120,9 @@ def oracle_chain(spec):
         elif kind == 'down':
             from oracle import zoo as OZ
             blocks.append(OZ.Down(cin, cout))
+        elif kind == 'esup':
+            from oracle import zoo as OZ
+            blocks.append(OZ.Up(cin, cout))
         elif kind in ('fcu', 'pfcu'):
             from oracle import zoo as OZ
             blocks.append(OZ.FactorizedUnit(cin, kw['k']) if kind == 'fcu' else OZ.ParallelFactorizedUnit(cin, kw['dil']))
@@ -395,6 +401,8 @@ def test_split_shuffle_unit_vs_f64_oracle(case, train):
 # ESNet's factorized units on the tap-by-tap kernels (csrc/fcg.hip): FCUBlock(64, K = 5) and FPCUBlock(128, dilations 2 / 5 / 9), biases in the
 # convolutions' epilogues, ragged widths / row groups, and both at a benchmark-sized map
 ES_CASES = [
+    ('up_64_16', [('esup', 64, 16, {}), ('fcu', 16, 16, {'k': 3})], (2, 64, 11, 19)),
+    ('up_16_19', [('esup', 16, 19, {})], (2, 16, 13, 20)),
     ('fcu_64_k5', [('fcu', 64, 64, {'k': 5})], (2, 64, 21, 38)),
     ('pfcu_128', [('pfcu', 128, 128, {'dil': [2, 5, 9]})], (2, 128, 19, 26)),
     ('fcu_16_k3', [('fcu', 16, 16, {'k': 3}), ('fcu', 16, 16, {'k': 3})], (2, 16, 22, 40)),

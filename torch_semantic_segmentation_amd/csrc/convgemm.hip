@@ -519,6 +519,8 @@ bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats, int B, int Hin, int Win, int Cin, int N, hipStream_t stream);
+bool tss_sconv_transposed_fwd(const void* x, long ldx, const float* w_tcn, const float* bias, void* y, long ldy,
+                              int B, int Hout, int Wout, int Cout, int Cin_t, hipStream_t stream);
 // fc1d.hip: lean bf16 kernels of the three-tap layers (false: shape not covered)
 bool tss_fc1d_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                   const float* w_tnc, int torch_layout, const float* bias, void* y, long ldy, double* stats,
@@ -885,6 +887,12 @@ int tss_convkxk_transposed_fwd(const void* x, long ldx, const float* w_tcn, cons
   g.a0 = x; g.lda0 = ldx;
   g.w = w_tcn; g.wrs = Cin_t; g.wcs = 1; g.wts = (long)Cout * Cin_t; g.bias = bias;
   g.y = y; g.ldy = ldy;
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2) {      // parity-class kernel of sconv.hip (small channel counts)
+    tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * g.Hin * g.Win * Cin_t + (double)g.P * Cout) * 2.0,
+                        2.0 * (double)g.P * 2.25 * Cin_t * Cout);
+    if (tss_sconv_transposed_fwd(x, ldx, w_tcn, bias, y, ldy, B, Hout, Wout, Cout, Cin_t, (hipStream_t)stream))
+      return tss::check_last("sconv_transposed_fwd");
+  }
   return launch(g, dtype, TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * g.Hin * g.Win * Cin_t + (double)g.P * Cout) * esz(dtype));
 }
 

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint4 convert8(const uint4& ra, const uint4& rb, bool
 
 // per-block statistics -> slab row (as conv3x3.hip / fc1d.hip)
 template <int C, int NF>
-__device__ __forceinline__ void flush_stats(const float (&st1)[NF][4], const float (&st2)[NF][4], double* stats, float (*red)[2][C]) {
+__device__ __forceinline__ void flush_stats(const float (&st1)[NF][4], const float (&st2)[NF][4], double* stats, float (*red)[2][C], int CR = C) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int i = 0; i < NF; ++i)
@@ -90,15 +90,15 @@ __device__ __forceinline__ void flush_stats(const float (&st1)[NF][4], const flo
       if (fr == 0) { red[wave][0][i * 16 + fq * 4 + q] = u; red[wave][1][i * 16 + fq * 4 + q] = w2; }
     }
   __syncthreads();
-  if (tid < C) {
+  if (tid < CR) {                                      // CR real channels (slab rows are [2 * CR] wide), C = padded fragment width
     const double a = ((double)red[0][0][tid] + (double)red[1][0][tid]) + ((double)red[2][0][tid] + (double)red[3][0][tid]);
     const double b = ((double)red[0][1][tid] + (double)red[1][1][tid]) + ((double)red[2][1][tid] + (double)red[3][1][tid]);
     const int row = blockIdx.x, rows_used = gridDim.x;
-    stats[(long)row * 2 * C + tid] = a;
-    stats[(long)row * 2 * C + C + tid] = b;
+    stats[(long)row * 2 * CR + tid] = a;
+    stats[(long)row * 2 * CR + CR + tid] = b;
     for (int rr = row + rows_used; rr < TSS_STAT_SLABS; rr += rows_used) {
-      stats[(long)rr * 2 * C + tid] = 0.0;
-      stats[(long)rr * 2 * C + C + tid] = 0.0;
+      stats[(long)rr * 2 * CR + tid] = 0.0;
+      stats[(long)rr * 2 * CR + CR + tid] = 0.0;
     }
   }
 }
@@ -251,13 +251,15 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------- backward-data
-// MODE 1: g = c0 * e   2: g = c0 (e - c2) + c1 (y - c3)
-template <int C, int MODE, int MT>
+// MODE 1: g = c0 * e   2: g = c0 (e - c2) + c1 (y - c3).  CK contraction channels (the layer's N; multiples of 8, zero-padded to whole 32-wide
+// k-steps), CN outputs (the layer's input channels; multiples of 8, padded to whole 16-wide fragments): the same kernel is the FORWARD of
+// nn.ConvTranspose2d(CK, CN, 3, stride=2, padding=1, output_padding=1) (UpsamplingBlock, TSS/models/esnet.py:71-80), with its bias.
+template <int CK, int CN, int MODE, int MT>
 __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
-  constexpr int NF = C / 16, NKT = C / 32, NCS = NKT, TWV = 16 * MT;
+  constexpr int NF = (CN + 15) / 16, C = NF * 16, NKT = (CK + 31) / 32, NCS = NKT, TWV = 16 * MT;
   extern __shared__ __align__(16) unsigned char smem[];
   uint4* Wl = reinterpret_cast<uint4*>(smem);         // [9 taps][NF][NKT][64 lanes]; output = input channel, contraction = n
-  __shared__ __align__(16) float Ec[3][C];
+  __shared__ __align__(16) float Ec[4][C];
   __shared__ float red[4][2][C];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
 
@@ -265,20 +267,24 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
     const int f = e >> 6, l = e & 63;
     const int ks = f % NKT, i = (f / NKT) % NF, tap = f / (NKT * NF);
     const int o_ = i * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8;
-    const float* src = g.w + (long)o_ * g.w_os + (long)k * g.w_ks + (long)tap * g.w_t9;
+    const bool in = o_ < CN && k < CK;
+    const float* src = g.w + (in ? (long)o_ * g.w_os + (long)k * g.w_ks + (long)tap * g.w_t9 : 0);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (T)src[(long)j * g.w_ks];
+    for (int j = 0; j < 8; ++j) o[j] = in ? (T)src[(long)j * g.w_ks] : (T)0.f;
     Wl[e] = *reinterpret_cast<const uint4*>(&o);
   }
   if (tid < C) {
-    float em = 0.f, es = 1.f, eh = 0.f;
-    if (g.xm) { if (g.mm) em = g.mm[tid]; if (g.ms) es = g.ms[tid]; if (g.mb) eh = g.mb[tid]; }
-    Ec[0][tid] = em; Ec[1][tid] = es; Ec[2][tid] = eh;
+    float em = 0.f, es = 1.f, eh = 0.f, eb = 0.f;
+    if (tid < CN) {
+      if (g.xm) { if (g.mm) em = g.mm[tid]; if (g.ms) es = g.ms[tid]; if (g.mb) eh = g.mb[tid]; }
+      if (g.bias) eb = g.bias[tid];
+    }
+    Ec[0][tid] = em; Ec[1][tid] = es; Ec[2][tid] = eh; Ec[3][tid] = eb;
   }
   float k0[NCS][8], k1[NCS][8], kadd[NCS][8];
 #pragma unroll
-  for (int s = 0; s < NCS; ++s) fold8<MODE>(g, s * 32 + fq * 8, k0[s], k1[s], kadd[s]);
+  for (int s = 0; s < NCS; ++s) fold8<MODE>(g, (s * 32 + fq * 8 < CK) ? s * 32 + fq * 8 : 0, k0[s], k1[s], kadd[s]);
   const bool plain = MODE == 1 && !g.c0;
 
   float st1[NF][4], st2[NF][4];
@@ -331,8 +337,9 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
               okb |= ok ? (1u << (slot * MT + m)) : 0u;                                                           \
               const long q = prow + (ok ? xo : 0);                                                                \
               _Pragma("unroll") for (int ks = 0; ks < NKT; ++ks) {                                               \
-                ra[slot][m][ks] = *reinterpret_cast<const uint4*>(g.a0 + q * g.lda0 + ks * 32 + fq * 8);          \
-                if (MODE == 2) rb[slot][m][ks] = *reinterpret_cast<const uint4*>(g.a1 + q * g.lda1 + ks * 32 + fq * 8); \
+                const int kc = (ks * 32 + fq * 8 < CK) ? ks * 32 + fq * 8 : 0;                                    \
+                ra[slot][m][ks] = *reinterpret_cast<const uint4*>(g.a0 + q * g.lda0 + kc);                        \
+                if (MODE == 2) rb[slot][m][ks] = *reinterpret_cast<const uint4*>(g.a1 + q * g.lda1 + kc);         \
               }                                                                                                   \
             }                                                                                                     \
           }                                                                                                       \
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
       const int xi = 2 * (j0_l + m * 16 + fr) + par_l;                                                            \
       const long p = pei_l + (xi < g.Wi ? xi : 0);                                                                \
       _Pragma("unroll") for (int i = 0; i < NF; ++i)                                                             \
-        rxm[m][i] = *reinterpret_cast<const uint2*>(g.xm + p * g.ldxm + i * 16 + fq * 4);                         \
+        rxm[m][i] = *reinterpret_cast<const uint2*>(g.xm + p * g.ldxm + ((i * 16 + fq * 4 < CN) ? i * 16 + fq * 4 : 0)); \
     }                                                                                                             \
   }
 
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
 #pragma unroll
           for (int ks = 0; ks < NKT; ++ks) {
             const uint4 r = convert8<MODE>(ra[slot][m][ks], rb[MODE == 2 ? slot : 0][MODE == 2 ? m : 0][MODE == 2 ? ks : 0], plain,
-                                           (okb >> (slot * MT + m)) & 1u, k0[ks], k1[ks], kadd[ks], 0.f);
+                                           ((okb >> (slot * MT + m)) & 1u) && (CK % 32 == 0 || ks * 32 + fq * 8 < CK), k0[ks], k1[ks], kadd[ks], 0.f);
             op[slot][m][ks] = *reinterpret_cast<const bf16x8*>(&r);
           }
       }
@@ -405,14 +412,17 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
         const float4 e1 = *reinterpret_cast<const float4*>(&Ec[0][nl]);
         const float4 e2 = *reinterpret_cast<const float4*>(&Ec[1][nl]);
         const float4 e3 = *reinterpret_cast<const float4*>(&Ec[2][nl]);
+        const float4 e4 = *reinterpret_cast<const float4*>(&Ec[3][nl]);
         const float cmm[4] = {e1.x, e1.y, e1.z, e1.w}, cms[4] = {e2.x, e2.y, e2.z, e2.w}, cmb[4] = {e3.x, e3.y, e3.z, e3.w};
+        const float cbi[4] = {e4.x, e4.y, e4.z, e4.w};
+        if (CN % 16 != 0 && nl >= CN) continue;          // padded output channels are never stored
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int xi = 2 * (j0 + m * 16 + fr) + par;
           if (xi < g.Wi) {
             float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q];
+            for (int q = 0; q < 4; ++q) v[q] = acc[m][i][q] + cbi[q];
             bf16x4 o;
             if (g.xm) {
               const uint2 xr = rxm[m][i];
@@ -441,7 +451,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_bwd_kernel(const ScArgs g) {
 #undef SB_GEOM
 #undef SB_ISSUE
 #undef SB_ISSUE_XM
-  if (g.stats) flush_stats<C, NF>(st1, st2, g.stats, red);
+  if (g.stats) flush_stats<C, NF>(st1, st2, g.stats, red, CN);
 }
 
 // ------------------------------------------------------------------------------------------------------------------- weight gradient
@@ -650,19 +660,19 @@ void launch_fwd(const ScArgs& g, hipStream_t stream) {
   hipLaunchKernelGGL((sc2_fwd_kernel<C, MT>), dim3((int)grid), dim3(NT), smem, stream, g);
 }
 
-template <int C, int MODE, int MT>
+template <int CK, int CN, int MODE, int MT>
 void launch_bwd(const ScArgs& g, hipStream_t stream) {
-  constexpr int smem = 9 * (C / 16) * (C / 32) * 64 * 16;
+  constexpr int smem = 9 * ((CN + 15) / 16) * ((CK + 31) / 32) * 64 * 16;
   static tss::DevOnce attr;
   static int per_cu = 0;
-  if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc2_bwd_kernel<C, MODE, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  if (per_cu == 0) per_cu = blocks_per_cu(sc2_bwd_kernel<C, MODE, MT>, smem);
+  if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc2_bwd_kernel<CK, CN, MODE, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (per_cu == 0) per_cu = blocks_per_cu(sc2_bwd_kernel<CK, CN, MODE, MT>, smem);
   const long tpr = (((g.Wi + 1) >> 1) + 16 * MT - 1) / (16 * MT);
   const long nblk = (((long)g.B * g.Hi + 3) >> 2) * 2 * tpr;
   long grid = 256L * per_cu;
   if (grid > TSS_STAT_SLABS) grid = TSS_STAT_SLABS;
   if (grid > nblk) grid = nblk;
-  hipLaunchKernelGGL((sc2_bwd_kernel<C, MODE, MT>), dim3((int)grid), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL((sc2_bwd_kernel<CK, CN, MODE, MT>), dim3((int)grid), dim3(NT), smem, stream, g);
 }
 
 template <int C, bool HASY>
@@ -709,7 +719,7 @@ bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.w = w_tcn; g.w_os = N; g.w_ks = 1; g.w_t9 = (long)Cin * N;
   g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  if (N == 64) launch_bwd<64, 1, 2>(g, stream); else launch_bwd<32, 1, 4>(g, stream);
+  if (N == 64) launch_bwd<64, 64, 1, 2>(g, stream); else launch_bwd<32, 32, 1, 4>(g, stream);
   return true;
 }
 
@@ -738,4 +748,23 @@ extern "C" int tss_sconv_bwd_weight_sweep(const void* e, long lde, const void* y
   if (N == 64) { if (yraw) launch_sw<64, true>(g, grid, (hipStream_t)stream); else launch_sw<64, false>(g, grid, (hipStream_t)stream); }
   else { if (yraw) launch_sw<32, true>(g, grid, (hipStream_t)stream); else launch_sw<32, false>(g, grid, (hipStream_t)stream); }
   return tss::check_last("sconv_wgrad");
+}
+
+// forward of nn.ConvTranspose2d(Cin_t, Cout, 3, stride=2, padding=1, output_padding=1) + bias on [9][Cout][Cin_t] f32 weights (tss_permute_wtaps of
+// the layer's [Cin_t][Cout][3][3] tensor): the parity-class gather above with x as the source grid.  false: shape not covered.
+bool tss_sconv_transposed_fwd(const void* x, long ldx, const float* w_tcn, const float* bias, void* y, long ldy,
+                              int B, int Hout, int Wout, int Cout, int Cin_t, hipStream_t stream) {
+  if (!sc_enabled() || (Hout & 1) || (Wout & 1) || Hout < 2 || Wout < 2 || (ldx % 8) || (ldy % 4) || !tss::aligned16(x) ||
+      (reinterpret_cast<uintptr_t>(y) & 7u) || !w_tcn || B <= 0)
+    return false;
+  ScArgs g = {};
+  g.B = B; g.Hi = Hout; g.Wi = Wout; g.Ho = Hout / 2; g.Wo = Wout / 2;
+  g.a0 = (const T*)x; g.lda0 = ldx;
+  g.w = w_tcn; g.w_os = Cin_t; g.w_ks = 1; g.w_t9 = (long)Cout * Cin_t;
+  g.bias = bias; g.y = (T*)y; g.ldy = ldy;
+  if (Cin_t == 64 && Cout == 16) launch_bwd<64, 16, 1, 2>(g, stream);
+  else if (Cin_t == 16 && Cout == 24) launch_bwd<16, 24, 1, 4>(g, stream);
+  else if (Cin_t == 16 && Cout == 16) launch_bwd<16, 16, 1, 4>(g, stream);
+  else return false;
+  return true;
 }
