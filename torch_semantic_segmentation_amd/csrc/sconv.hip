@@ -104,9 +104,11 @@ __device__ __forceinline__ void flush_stats(const float (&st1)[NF][4], const flo
 }
 
 // ------------------------------------------------------------------------------------------------------------------- forward
-template <int C, int MT>
+// CK contraction channels per tap (multiples of 8, zero-padded to whole 32-wide k-steps), CN outputs (multiples of 8, padded to whole fragments):
+// rectangular instances serve the INPUT gradient of nn.ConvTranspose2d (UpsamplingBlock, TSS/models/esnet.py:71-80), which is this convolution.
+template <int CK, int CN, int MT>
 __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
-  constexpr int NF = C / 16, NKS = 3 * C / 32, NCS = C == 64 ? 2 : 1, TWV = 16 * MT;
+  constexpr int NF = (CN + 15) / 16, C = NF * 16, KPT = (CK + 31) / 32, NKS = 3 * KPT, NCS = KPT, TWV = 16 * MT;
   extern __shared__ __align__(16) unsigned char smem[];
   uint4* Wl = reinterpret_cast<uint4*>(smem);         // [3 kernel rows][NF][NKS][64 lanes]
   __shared__ __align__(16) float Ec[C];
@@ -117,20 +119,21 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
     const int f = e >> 6, l = e & 63;
     const int ks = f % NKS, i = (f / NKS) % NF, dy = f / (NKS * NF);
     const int n = i * 16 + (l & 15), k = ks * 32 + (l >> 4) * 8;
-    const int dx = k / C, c = k - dx * C;
-    const float* src = g.w + (long)n * g.w_os + (long)c * g.w_ks + (long)(dy * 3 + dx) * g.w_t9;
+    const int dx = k / (KPT * 32), c = k - dx * (KPT * 32);
+    const bool in = n < CN && c < CK;
+    const float* src = g.w + (in ? (long)n * g.w_os + (long)c * g.w_ks + (long)(dy * 3 + dx) * g.w_t9 : 0);
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (T)src[(long)j * g.w_ks];
+    for (int j = 0; j < 8; ++j) o[j] = in ? (T)src[(long)j * g.w_ks] : (T)0.f;
     Wl[e] = *reinterpret_cast<const uint4*>(&o);
   }
-  if (tid < C) Ec[tid] = g.bias ? g.bias[tid] : 0.f;
+  if (tid < C) Ec[tid] = (g.bias && tid < CN) ? g.bias[tid] : 0.f;
 
   int cch[NCS];
   float k0[NCS][8], k1[NCS][8], kadd[NCS][8];
 #pragma unroll
   for (int s = 0; s < NCS; ++s) {
-    cch[s] = C == 64 ? s * 32 + fq * 8 : fq * 8;
+    cch[s] = (s * 32 + fq * 8 < CK) ? s * 32 + fq * 8 : 0;
     fold8<0>(g, cch[s], k0[s], k1[s], kadd[s]);
   }
   const bool plain = !g.c0 && !g.c1 && !g.c2 && !g.a_relu;
@@ -173,11 +176,11 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                            \
       const int xo = x0_l + m * 16 + fr;                                                                         \
       _Pragma("unroll") for (int ks = 0; ks < NKS; ++ks) {                                                      \
-        const int dx = (ks * 32) / C;                                                                            \
+        const int dx = ks / KPT;                                                                                 \
         const int xi = 2 * xo + dx - 1;                                                                          \
-        const bool ok = rowok && xo < g.Wo && xi >= 0 && xi < g.Wi;                                              \
+        const bool ok = rowok && xo < g.Wo && xi >= 0 && xi < g.Wi && (CK % 32 == 0 || (ks % KPT) * 32 + fq * 8 < CK); \
         okb |= ok ? (1u << (m * NKS + ks)) : 0u;                                                                 \
-        ra[m][ks] = *reinterpret_cast<const uint4*>(g.a0 + (pin_l + (ok ? xi : 0)) * g.lda0 + cch[C == 64 ? (ks & 1) : 0]); \
+        ra[m][ks] = *reinterpret_cast<const uint4*>(g.a0 + (pin_l + (ok ? xi : 0)) * g.lda0 + cch[ks % KPT]); \
       }                                                                                                          \
     }                                                                                                            \
   }
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const int s = C == 64 ? (ks & 1) : 0;
+        const int s = ks % KPT;
         const uint4 r = convert8<0>(ra[m][ks], ra[m][ks], plain, (okb >> (m * NKS + ks)) & 1u, k0[s], k1[s], kadd[s], relu_lo);
         op[m][ks] = *reinterpret_cast<const bf16x8*>(&r);
       }
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
         const int nl = i * 16 + fq * 4;
         const float4 e0 = *reinterpret_cast<const float4*>(&Ec[nl]);
         const float cbias[4] = {e0.x, e0.y, e0.z, e0.w};
+        if (CN % 16 != 0 && nl >= CN) continue;          // padded output channels are never stored
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const int px = m * 16 + fr;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(NT, 2) void sc2_fwd_kernel(const ScArgs g) {
   }
 #undef SC_GEOM
 #undef SC_ISSUE
-  if (g.stats) flush_stats<C, NF>(st1, st2, g.stats, red);
+  if (g.stats) flush_stats<C, NF>(st1, st2, g.stats, red, CN);
 }
 
 // ------------------------------------------------------------------------------------------------------------------- backward-data
@@ -645,19 +649,19 @@ int blocks_per_cu(K kernel, int smem) {
   return nb > 2 ? 2 : nb;
 }
 
-template <int C, int MT>
+template <int CK, int CN, int MT>
 void launch_fwd(const ScArgs& g, hipStream_t stream) {
-  constexpr int smem = 3 * (C / 16) * (3 * C / 32) * 64 * 16;
+  constexpr int smem = 3 * ((CN + 15) / 16) * (3 * ((CK + 31) / 32)) * 64 * 16;
   static tss::DevOnce attr;
   static int per_cu = 0;
-  if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc2_fwd_kernel<C, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  if (per_cu == 0) per_cu = blocks_per_cu(sc2_fwd_kernel<C, MT>, smem);
+  if (attr.first()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc2_fwd_kernel<CK, CN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  if (per_cu == 0) per_cu = blocks_per_cu(sc2_fwd_kernel<CK, CN, MT>, smem);
   const long tpr = (g.Wo + 16 * MT - 1) / (16 * MT);
   const long nblk = (((long)g.B * g.Ho + 3) >> 2) * tpr;
   long grid = 256L * per_cu;
   if (grid > TSS_STAT_SLABS) grid = TSS_STAT_SLABS;
   if (grid > nblk) grid = nblk;
-  hipLaunchKernelGGL((sc2_fwd_kernel<C, MT>), dim3((int)grid), dim3(NT), smem, stream, g);
+  hipLaunchKernelGGL((sc2_fwd_kernel<CK, CN, MT>), dim3((int)grid), dim3(NT), smem, stream, g);
 }
 
 template <int CK, int CN, int MODE, int MT>
@@ -691,14 +695,19 @@ bool covered(int Hin, int Win, int Cin, int N) { return sc_enabled() && Cin == N
 bool tss_sconv_fwd(const void* x, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                    const float* w_tnc, const float* bias, void* y, long ldy, double* stats,
                    int B, int Hin, int Win, int Cin, int N, hipStream_t stream) {
-  if (!covered(Hin, Win, Cin, N) || (ldx % 8) || (ldy % 4) || !tss::aligned16(x) || (reinterpret_cast<uintptr_t>(y) & 7u) || !w_tnc || B <= 0)
+  if (!sc_enabled() || Hin < 2 || Win < 2 || (ldx % 8) || (ldy % 4) || !tss::aligned16(x) || (reinterpret_cast<uintptr_t>(y) & 7u) || !w_tnc || B <= 0)
     return false;
   ScArgs g = {};
   g.B = B; g.Hi = Hin; g.Wi = Win; g.Ho = (Hin - 1) / 2 + 1; g.Wo = (Win - 1) / 2 + 1;
   g.a0 = (const T*)x; g.lda0 = ldx; g.c0 = in_scale; g.c1 = in_mean; g.c2 = in_bias; g.a_relu = in_relu;
   g.w = w_tnc; g.w_os = Cin; g.w_ks = 1; g.w_t9 = (long)N * Cin;
   g.bias = bias; g.y = (T*)y; g.ldy = ldy; g.stats = stats;
-  if (N == 64) launch_fwd<64, 1>(g, stream); else launch_fwd<32, 2>(g, stream);
+  if (N == 64 && Cin == 64) launch_fwd<64, 64, 1>(g, stream);
+  else if (N == 32 && Cin == 32) launch_fwd<32, 32, 2>(g, stream);
+  else if (N == 64 && Cin == 16) launch_fwd<16, 64, 2>(g, stream);      // input gradient of ConvTranspose2d(64, 16)
+  else if (N == 16 && Cin == 24) launch_fwd<24, 16, 4>(g, stream);      // ... of ConvTranspose2d(16, 19 padded to 24)
+  else if (N == 16 && Cin == 16) launch_fwd<16, 16, 4>(g, stream);
+  else return false;
   return true;
 }
 
