@@ -626,6 +626,202 @@ __global__ __launch_bounds__(NT, C == 64 ? 1 : 2) void sc2_wgrad_kernel(const Sw
       for (int q = 0; q < 4; ++q) row[((long)(16 * fi + 4 * fq + q) * C + 16 * (fj0 + j) + fr) * 9 + t] = acc[t][j][q];
 }
 
+// Rectangular form: NE channels on the OUTPUT grid ("e"), NX channels on the input grid ("x", padded to whole fragments in LDS).  Serves the
+// weight gradient of nn.ConvTranspose2d(NE, NX, 3, stride 2) (UpsamplingBlock, TSS/models/esnet.py:71-80: e := the layer's input on the
+// low-resolution grid, x := the gradient of its output), whose [NE][NX][3][3] layout this is.  64-pixel stages; wave w owns fragment
+// w % NFE of the NE channels and the taps t = w / NFE (mod 4 / NFE).
+template <int NE, int NX, bool HASY>
+__global__ __launch_bounds__(NT, 2) void sc2_wgrad_rect_kernel(const SwArgs g) {
+  constexpr int NFE = NE / 16, NFX = (NX + 15) / 16, NXP = NFX * 16, NVE = NE / 8, NVX = NXP / 8, PT = 64;
+  constexpr int RPE = NT / NVE, NPE = (PT + RPE - 1) / RPE, RPX = NT / NVX, NPX = (PT + RPX - 1) / RPX;
+  constexpr int NCH = NVE + 9 * NVX, NIMG = (NCH + 15) / 16, BUF = NIMG * PT * 256, NKS = PT / 32;
+  constexpr int TSTEP = 4 / NFE, NTW = (9 + TSTEP - 1) / TSTEP;          // taps per wave
+  static_assert(NFE == 1 || NFE == 2 || NFE == 4, "output fragments over the four waves");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int cve = tid % NVE, re_ = tid / NVE, cvx = tid % NVX, rx_ = tid / NVX;
+
+  float ca[8], cb[HASY ? 8 : 1], cc[HASY ? 8 : 1], as[8], ab[8];
+  const bool gplain = !HASY && !g.ga, aplain = !g.xs && !g.xm && !g.xb && !g.x_relu;
+  {
+    const float* safe = reinterpret_cast<const float*>(g.e);
+    const int cx = cvx * 8 < NX ? cvx * 8 : 0;
+    float v0[8], v1[8], v2[8], v3[8], w0[8], w1[8], w2[8];
+    const float* p0 = g.ga ? g.ga + cve * 8 : safe; const float* p1 = (HASY && g.gb) ? g.gb + cve * 8 : safe;
+    const float* p2 = (HASY && g.gce) ? g.gce + cve * 8 : safe; const float* p3 = (HASY && g.gmu) ? g.gmu + cve * 8 : safe;
+    const float* q0 = g.xs ? g.xs + cx : safe; const float* q1 = g.xm ? g.xm + cx : safe; const float* q2 = g.xb ? g.xb + cx : safe;
+#pragma unroll
+    for (int h = 0; h < 8; h += 4) {
+      V4<float>::load(p0 + h, v0 + h); V4<float>::load(p1 + h, v1 + h); V4<float>::load(p2 + h, v2 + h); V4<float>::load(p3 + h, v3 + h);
+      V4<float>::load(q0 + h, w0 + h); V4<float>::load(q1 + h, w1 + h); V4<float>::load(q2 + h, w2 + h);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float gav = g.ga ? v0[j] : 1.f;
+      ca[j] = gav;
+      if (HASY) { cb[j] = v1[j]; cc[j] = -(gav * v2[j]) - v1[j] * v3[j]; }
+      const float sc = g.xs ? w0[j] : 1.f;
+      as[j] = sc; ab[j] = (g.xb ? w2[j] : 0.f) - (g.xm ? w1[j] : 0.f) * sc;
+    }
+  }
+  const float relu_lo = g.x_relu ? 0.f : -TSS_INF;
+
+  const int fi = wave % NFE, t0 = wave / NFE;
+  int troffG[2], troffA[NTW][NFX][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = fq * 8 + 4 * h + (fr >> 2);
+    troffG[h] = img_off(row, fi * 2 + ((fr & 3) >> 1)) + 8 * (fr & 1);
+#pragma unroll
+    for (int k = 0; k < NTW; ++k)
+#pragma unroll
+      for (int j = 0; j < NFX; ++j) {
+        const int t = t0 + k * TSTEP;
+        const int gc = NVE + (t < 9 ? t : 0) * NVX + j * 2 + ((fr & 3) >> 1);      // 16-byte column chunk of (tap, fragment j)
+        troffA[k][j][h] = (gc >> 4) * PT * 256 + img_off(row, gc & 15) + 8 * (fr & 1);
+      }
+  }
+  f32x4 acc[NTW][NFX];
+#pragma unroll
+  for (int k = 0; k < NTW; ++k)
+#pragma unroll
+    for (int j = 0; j < NFX; ++j) acc[k][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long nstage = (g.P + PT - 1) / PT;
+  const long per = (nstage + gridDim.x - 1) / gridDim.x;
+  const long s_begin = (long)blockIdx.x * per;
+  long s_end = s_begin + per;
+  if (s_end > nstage) s_end = nstage;
+
+  uint4 re[NPE], ry[HASY ? NPE : 1], rx[NPX][9];
+  uint32_t oke = 0, okx[NPX];
+#define SR_ISSUE(S)                                                                                      \
+  {                                                                                                        \
+    oke = 0;                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < NPE; ++u) {                                                     \
+      const int rr = re_ + u * RPE;                                                                        \
+      const long p = (S) * PT + rr;                                                                        \
+      const bool in = rr < PT && p < g.P;                                                                  \
+      const long pcl = in ? p : 0;                                                                         \
+      oke |= in ? (1u << u) : 0u;                                                                          \
+      re[u] = *reinterpret_cast<const uint4*>(g.e + pcl * g.lde + cve * 8);                                \
+      if (HASY) ry[u] = *reinterpret_cast<const uint4*>(g.y + pcl * g.ldyr + cve * 8);                     \
+    }                                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < NPX; ++u) {                                                     \
+      const int rr = rx_ + u * RPX;                                                                        \
+      const long p = (S) * PT + rr;                                                                        \
+      const bool in = rr < PT && p < g.P && cvx * 8 < NX;                                                  \
+      const long pcl = (rr < PT && p < g.P) ? p : 0;                                                       \
+      const int xo = (int)(pcl % g.Wo);                                                                    \
+      const long byo = pcl / g.Wo;                                                                         \
+      const int yo = (int)(byo % g.Ho);                                                                    \
+      const long bi = (byo / g.Ho) * g.Hi;                                                                 \
+      okx[u] = 0;                                                                                          \
+      _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                     \
+        const int yi = 2 * yo + t / 3 - 1, xi = 2 * xo + t % 3 - 1;                                        \
+        const bool ok = in && yi >= 0 && yi < g.Hi && xi >= 0 && xi < g.Wi;                                \
+        okx[u] |= ok ? (1u << t) : 0u;                                                                     \
+        const long q = ok ? (bi + yi) * g.Wi + xi : (bi + 2 * yo) * g.Wi + 2 * xo;                         \
+        rx[u][t] = *reinterpret_cast<const uint4*>(g.x + q * g.ldx + (cvx * 8 < NX ? cvx * 8 : 0));       \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+
+  if (s_begin < s_end) SR_ISSUE(s_begin);
+  int b = 0;
+  for (long s = s_begin; s < s_end; ++s) {
+    unsigned char* img = smem + b * BUF;
+#pragma unroll
+    for (int u = 0; u < NPE; ++u) {
+      const int rr = re_ + u * RPE;
+      if (rr < PT) {
+        uint4 og = re[u];
+        if (!gplain) {
+          const uint32_t* ue = reinterpret_cast<const uint32_t*>(&re[u]);
+          const uint32_t* uy = reinterpret_cast<const uint32_t*>(&ry[HASY ? u : 0]);
+          bf16x8 o;
+#pragma unroll
+          for (int h = 0; h < 4; ++h) {
+            float lo = ca[2 * h] * blo(ue[h]), hi = ca[2 * h + 1] * bhi(ue[h]);
+            if (HASY) { lo += cb[2 * h] * blo(uy[h]) + cc[2 * h]; hi += cb[2 * h + 1] * bhi(uy[h]) + cc[2 * h + 1]; }
+            o[2 * h] = (T)lo; o[2 * h + 1] = (T)hi;
+          }
+          og = *reinterpret_cast<const uint4*>(&o);
+        }
+        if (!((oke >> u) & 1u)) og = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(img + img_off(rr, cve)) = og;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPX; ++u) {
+      const int rr = rx_ + u * RPX;
+      if (rr < PT) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          uint4 oa = rx[u][t];
+          if (!aplain) {
+            const uint32_t* ux = reinterpret_cast<const uint32_t*>(&rx[u][t]);
+            bf16x8 o;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+              o[2 * h] = (T)fmaxf(blo(ux[h]) * as[2 * h] + ab[2 * h], relu_lo);
+              o[2 * h + 1] = (T)fmaxf(bhi(ux[h]) * as[2 * h + 1] + ab[2 * h + 1], relu_lo);
+            }
+            oa = *reinterpret_cast<const uint4*>(&o);
+          }
+          if (!((okx[u] >> t) & 1u)) oa = make_uint4(0u, 0u, 0u, 0u);
+          const int gc = NVE + t * NVX + cvx;
+          *reinterpret_cast<uint4*>(img + (gc >> 4) * PT * 256 + img_off(rr, gc & 15)) = oa;
+        }
+      }
+    }
+    if (s + 1 < s_end) SR_ISSUE(s + 1);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const unsigned char* base = img + ks * 32 * 256;
+      const bf16x8 gA = tr_pair(base + troffG[0], base + troffG[1]);
+#pragma unroll
+      for (int k = 0; k < NTW; ++k) {
+        if (t0 + k * TSTEP < 9) {
+#pragma unroll
+          for (int j = 0; j < NFX; ++j) {
+            const bf16x8 aB = tr_pair(base + troffA[k][j][0], base + troffA[k][j][1]);
+            acc[k][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gA, aB, acc[k][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    b ^= 1;
+  }
+#undef SR_ISSUE
+  float* row = g.ws + (long)blockIdx.x * (9 * NE * NX);
+#pragma unroll
+  for (int k = 0; k < NTW; ++k) {
+    const int t = t0 + k * TSTEP;
+    if (t < 9) {
+#pragma unroll
+      for (int j = 0; j < NFX; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 16 * j + fr;
+          if (c < NX) row[((long)(16 * fi + 4 * fq + q) * NX + c) * 9 + t] = acc[k][j][q];
+        }
+    }
+  }
+}
+
+template <int NE, int NX> constexpr int swr_smem() { return 2 * (((NE / 8 + 9 * (((NX + 15) / 16) * 2) + 15) / 16) * 64 * 256); }
+
+template <int NE, int NX, bool HASY>
+void launch_swr(const SwArgs& g, int grid, hipStream_t stream) {
+  constexpr int smem = swr_smem<NE, NX>();
+  static tss::DevOnce attr;
+  if (attr.first())
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc2_wgrad_rect_kernel<NE, NX, HASY>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipLaunchKernelGGL((sc2_wgrad_rect_kernel<NE, NX, HASY>), dim3(grid), dim3(NT), smem, stream, g);
+}
+
 template <int C> constexpr int sw_smem() { return 2 * (((10 * (C / 8) + 15) / 16) * (C == 64 ? 32 : 64) * 256); }
 
 int sw_rows(long P, int C) {
@@ -732,10 +928,22 @@ bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   return true;
 }
 
+bool rect_covered(int Hin, int Win, int Cin, int N) {      // (N channels on the output grid, Cin on the input grid): ESNet's transposed layers
+  return sc_enabled() && Hin >= 2 && Win >= 2 && ((N == 64 && Cin == 16) || (N == 16 && Cin == 24) || (N == 16 && Cin == 16));
+}
+
 extern "C" int tss_sconv_bwd_weight_rows(int B, int Hin, int Win, int Cin, int N, int dtype) {
   extern int g_tss_disable_fast;
-  if (dtype != TSS_BF16 || g_tss_disable_fast || !covered(Hin, Win, Cin, N) || B <= 0) return 0;
-  return sw_rows((long)B * ((Hin - 1) / 2 + 1) * ((Win - 1) / 2 + 1), N);
+  if (dtype != TSS_BF16 || g_tss_disable_fast || B <= 0) return 0;
+  const long P = (long)B * ((Hin - 1) / 2 + 1) * ((Win - 1) / 2 + 1);
+  if (covered(Hin, Win, Cin, N)) return sw_rows(P, N);
+  if (rect_covered(Hin, Win, Cin, N)) {
+    const long nstage = (P + 63) / 64;
+    long grid = 512;
+    if (grid > (nstage + 7) / 8) grid = (nstage + 7) / 8;
+    return (int)(grid < 1 ? 1 : grid);
+  }
+  return 0;
 }
 
 extern "C" int tss_sconv_bwd_weight_sweep(const void* e, long lde, const void* yraw, long ldyr,
@@ -743,7 +951,8 @@ extern "C" int tss_sconv_bwd_weight_sweep(const void* e, long lde, const void* y
                                           const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias,
                                           int in_relu, float* ws, int B, int Hin, int Win, int Cin, int N, int dtype, void* stream) {
   TSS_REQUIRE(dtype == TSS_BF16, TSS_ERR_DTYPE);
-  TSS_REQUIRE(covered(Hin, Win, Cin, N) && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin && e && xraw && ws && B > 0, TSS_ERR_SHAPE);
+  TSS_REQUIRE((covered(Hin, Win, Cin, N) || rect_covered(Hin, Win, Cin, N)) && (lde % 8) == 0 && lde >= N && (ldx % 8) == 0 && ldx >= Cin && e &&
+              xraw && ws && B > 0, TSS_ERR_SHAPE);
   TSS_REQUIRE(!yraw || ((ldyr % 8) == 0 && ldyr >= N && ga && gb && gce && gmu), TSS_ERR_SHAPE);
   TSS_REQUIRE(tss::aligned16(e) && tss::aligned16(xraw) && (!yraw || tss::aligned16(yraw)), TSS_ERR_ALIGN);
   SwArgs g = {};
@@ -751,9 +960,16 @@ extern "C" int tss_sconv_bwd_weight_sweep(const void* e, long lde, const void* y
   g.e = (const T*)e; g.lde = lde; g.y = (const T*)yraw; g.ldyr = ldyr; g.ga = ga; g.gb = gb; g.gce = gce; g.gmu = gmu;
   g.x = (const T*)xraw; g.ldx = ldx; g.xm = in_mean; g.xs = in_scale; g.xb = in_bias; g.x_relu = in_relu;
   g.ws = ws;
-  const int grid = sw_rows(g.P, N);
+  const int grid = tss_sconv_bwd_weight_rows(B, Hin, Win, Cin, N, dtype);
+  TSS_REQUIRE(grid > 0, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_CONV3X3_BWD_WEIGHT, (hipStream_t)stream, ((double)g.P * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin) * 2.0,
                       2.0 * g.P * 9.0 * N * Cin);
+  if (Cin != N) {
+    if (N == 64 && Cin == 16) { if (yraw) launch_swr<64, 16, true>(g, grid, (hipStream_t)stream); else launch_swr<64, 16, false>(g, grid, (hipStream_t)stream); }
+    else if (N == 16 && Cin == 24) { if (yraw) launch_swr<16, 24, true>(g, grid, (hipStream_t)stream); else launch_swr<16, 24, false>(g, grid, (hipStream_t)stream); }
+    return tss::check_last("sconv_wgrad_rect");
+  }
+  if (N == 16) { if (yraw) launch_swr<16, 16, true>(g, grid, (hipStream_t)stream); else launch_swr<16, 16, false>(g, grid, (hipStream_t)stream); return tss::check_last("sconv_wgrad_rect"); }
   if (N == 64) { if (yraw) launch_sw<64, true>(g, grid, (hipStream_t)stream); else launch_sw<64, false>(g, grid, (hipStream_t)stream); }
   else { if (yraw) launch_sw<32, true>(g, grid, (hipStream_t)stream); else launch_sw<32, false>(g, grid, (hipStream_t)stream); }
   return tss::check_last("sconv_wgrad");

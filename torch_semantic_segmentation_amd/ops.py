@@ -2450,8 +2450,15 @@ class ConvTransposeFn(Function):
                  B, H * s, W * s, Co, Ci, kh, kw, s, 1, dt, st)
         if ctx.needs_input_grad[1]:        # that convolution's weight gradient with the roles of activation and gradient swapped
             dw = torch.zeros_like(weight)
-            call('tss_convkxk_bwd_weight', ptr(x), ld(x), None, 0, None, None, None, None, ptr(g), ld(g), None, None, None, 0,
-                 ptr(dw), B, H * s, W * s, Co, Ci, kh, kw, s, 1, dt, st)
+            rows = N.lib().tss_sconv_bwd_weight_rows(B, H * s, W * s, Co, Ci, dt) if (kh == 3 and kw == 3 and s == 2) else 0
+            if rows:      # one sweep over x and g (csrc/sconv.hip, rectangular form), then the row reduction
+                ws = torch.empty((rows, Ci * Co * 9), dtype=torch.float32, device=dev)
+                call('tss_sconv_bwd_weight_sweep', ptr(x), ld(x), None, 0, None, None, None, None, ptr(g), ld(g), None, None, None, 0,
+                     ptr(ws), B, H * s, W * s, Co, Ci, dt, st)
+                _reduce_rows_now(ws, dw, Ci * Co * 9, rows)
+            else:
+                call('tss_convkxk_bwd_weight', ptr(x), ld(x), None, 0, None, None, None, None, ptr(g), ld(g), None, None, None, 0,
+                     ptr(dw), B, H * s, W * s, Co, Ci, kh, kw, s, 1, dt, st)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = _colsum(g, Co, st)
         return dx, dw, dbias, None
