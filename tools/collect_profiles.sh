@@ -42,6 +42,8 @@ TRACE_MARK=upsample_head tools/trace_step.sh --mode eval --model fastscnn_aspp
 cp gpurun_out/gaps.txt $out/${tag}_eval_c5_aspp_kernels.txt
 tools/trace_step.sh --model lednet
 cp gpurun_out/gaps.txt $out/${tag}_step_kernels_lednet.txt
+tools/trace_step.sh --model esnet
+cp gpurun_out/gaps.txt $out/${tag}_step_kernels_esnet.txt
 echo "trace done"
 # 4. the bench lines themselves
 python3 bench.py --host-batch > $out/${tag}_bench_default.json 2> $out/default.err     # the driver's command + the PCIe-inclusive legs; extras = configs 3 and 5
@@ -57,6 +59,8 @@ python3 bench.py --model lednet --steps 20 --warmup 3 --no-cpu-baseline --no-ext
 python3 bench.py --stock --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_stock.json 2> $out/stock.err
 python3 tools/micro_sweep.py > $out/${tag}_micro_sweep.txt 2>&1
 python3 tools/micro_fc1d.py 2>&1 | grep -v "amdgpu\|Warn" > $out/${tag}_micro_fc1d.txt
+python3 tools/micro_sconv.py 2>&1 | grep -v "amdgpu\|Warn" > $out/${tag}_micro_sconv.txt
+python3 bench.py --model esnet --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $out/${tag}_bench_esnet.json 2> $out/esnet.err
 echo "bench done"
 # 5. the parity table of the benchmarked kernels against the f64 oracle, written by the test itself: the tracked copy can not lag the code
 python3 -m pytest tests/test_gpu_lean_vs_oracle.py -q -x > $out/lean_parity_pytest.log 2>&1 || true
