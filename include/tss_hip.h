@@ -306,6 +306,10 @@ int tss_mul_addrows_bwd(const void* g, long ldg, const void* u, long ldu, const 
 int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream);
 int tss_cat2_add(const void* gl, long ldl, const void* gr, long ldr, const void* gs, long lds, void* out, long ldo, long P, int half,
                  int dtype, void* stream);
+/* out[p][c] = c < C ? g[p][c] : 0 for c < CP: the gradient of the channel slice x[:, :C] of a tensor computed with CP channels (19 classes
+ * padded to 24: UpsamplingBlock(16, num_classes) TSS/models/esnet.py:45, the `level` layers of APNModule TSS/models/lednet.py:65-69);
+ * g may have any pitch >= C. */
+int tss_pad_channels(const void* g, long ldg, int C, void* out, long ldo, int CP, long P, int dtype, void* stream);
 /* ---- tail of LEDNet's SS-nbt unit in one pass each way (csrc/ssnbt.hip) ------------------------------------------------------------
  * replaces: cat([left(l), right(r)]) -> Dropout2d -> activation(input + x) -> channel_shuffle(x, 2) of SSnbtBlock.forward,
  *           TSS/models/lednet.py:112-124.  left / right: the branches' raw convolution outputs [P][C/2] with their pending BatchNorm as

@@ -232,6 +232,26 @@ __global__ __launch_bounds__(NT) void cat2_add_kernel(const T* gl, long ldl, con
   }
 }
 
+// gradient of a channel slice x[:, :C] of a tensor that was computed with CP >= C channels (a ragged class count padded to whole
+// 8-channel vectors): out[p][c] = c < C ? g[p][c] : 0, one pass (autograd's own route: a zero-filled tensor + a strided copy).
+// g has an arbitrary (possibly odd) pitch, so it is read element by element; out is written as whole vectors.
+template <typename T>
+__global__ __launch_bounds__(NT) void pad_channels_kernel(const T* g, long ldg, int C, T* out, long ldo, int CP, long P) {
+  const int CV = CP >> 3;
+  const long total = P * CV;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const int cv = (int)(i % CV);
+    const long p = i / CV;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cv * 8 + j;
+      v[j] = c < C ? (float)g[p * ldg + c] : 0.f;
+    }
+    V8<T>::store(out + p * ldo + cv * 8, v);
+  }
+}
+
 inline int grid_for(long total) {
   long g = (total + NT - 1) / NT;
   return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
@@ -365,6 +385,21 @@ int tss_cat2_add(const void* gl, long ldl, const void* gr, long ldr, const void*
     hipLaunchKernelGGL(cat2_add_kernel<float>, dim3(grid_for(P * (half / 4))), dim3(NT), 0, (hipStream_t)stream, (const float*)gl, ldl,
                        (const float*)gr, ldr, (const float*)gs, lds, (float*)out, ldo, P, half);
   return tss::check_last("cat2_add");
+}
+
+int tss_pad_channels(const void* g, long ldg, int C, void* out, long ldo, int CP, long P, int dtype, void* stream) {
+  TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
+  TSS_REQUIRE(C > 0 && CP >= C && (CP % 8) == 0 && ldg >= C && (ldo % 8) == 0 && ldo >= CP && g && out, TSS_ERR_SHAPE);
+  TSS_REQUIRE(tss::aligned16(out), TSS_ERR_ALIGN);
+  if (P == 0) return TSS_OK;
+  tss::ProfScope prof(TSS_K_JOIN_BWD, (hipStream_t)stream, (double)P * (C + CP) * esz(dtype), 0);
+  if (dtype == TSS_BF16)
+    hipLaunchKernelGGL(pad_channels_kernel<bf16_t>, dim3(grid_for(P * (CP / 8))), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)g, ldg, C,
+                       (bf16_t*)out, ldo, CP, P);
+  else
+    hipLaunchKernelGGL(pad_channels_kernel<float>, dim3(grid_for(P * (CP / 8))), dim3(NT), 0, (hipStream_t)stream, (const float*)g, ldg, C,
+                       (float*)out, ldo, CP, P);
+  return tss::check_last("pad_channels");
 }
 
 int tss_scale_rows(const void* x, long ldx, const float* m, void* out, long ldo, int B, long HW, int C, int dtype, void* stream) {

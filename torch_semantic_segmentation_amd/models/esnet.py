@@ -75,7 +75,7 @@ class UpsamplingBlock(nn.Sequential):
         out = ops.materialize(ops.batch_norm(y, sh, relu=True, gamma=F.pad(bn.weight, (0, cp - C), value=1.0),
                                              beta=F.pad(bn.bias, (0, cp - C))))
         pad.leave(bn)
-        return out[:, :C]
+        return ops.channel_slice(out, C)
 
 
 class DownsamplingBlock(nn.Module):

@@ -153,7 +153,7 @@ class APNModule(nn.Module):
         pooled = ops.adaptive_avg_pool(x, 1)
         l5 = _padded_block(pooled, self.level5, cp, pads[4])
         out = ops.mul_addrows(up, l4, l5)
-        return out if cp == C else out[:, :C]
+        return ops.channel_slice(out, C)
 
 
 class DownsamplingBlock(nn.Module):

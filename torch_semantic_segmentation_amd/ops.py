@@ -2060,6 +2060,30 @@ class ChannelShuffleFn(Function):
         return dx, None
 
 
+def channel_slice(x, C):
+    """x[:, :C] of an NHWC tensor computed with padded channels: a view; its gradient is padded back in one pass (tss_pad_channels)."""
+    if C == x.shape[1]:
+        return x
+    return ChannelSliceFn.apply(x, int(C))
+
+
+class ChannelSliceFn(Function):
+    @staticmethod
+    def forward(ctx, x, C):
+        ctx.cp = x.shape[1]
+        return x[:, :C]
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, H, W = g.shape
+        pitch = g.stride(3)
+        if not (g.is_cuda and g.stride(1) == 1 and pitch >= C and g.stride(2) == W * pitch and g.stride(0) == H * W * pitch):
+            g = to_nhwc(g)          # (any pitch is fine for the kernel; only a non-channels-last gradient is re-laid out)
+        out = new_nhwc(B, ctx.cp, H, W, g.dtype, g.device)
+        call('tss_pad_channels', ptr(g), g.stride(3), C, ptr(out), ld(out), ctx.cp, B * H * W, N.dtype_code(g.dtype), stream())
+        return out, None
+
+
 def split_fork(x):
     """(x[:, :C/2], x[:, C/2:], x) for a unit that runs two branches on torch.chunk(input, 2, 1) and adds the whole input back
     (SSnbtBlock, TSS/models/lednet.py:112-124): three views, no copy; the gradient is cat(g_left, g_right) + g_skip in ONE pass
