@@ -46,6 +46,62 @@ __global__ __launch_bounds__(NT) void tensor_stats_kernel(const T* z, long ldz, 
   }
 }
 
+// The same sums with 16-byte (bf16) / 32-byte (f32) vectors when the channel count is a multiple of 8: a lane owns 8 channels of every
+// (256 / (C / 8))-th pixel of the block's range, four pixels requested per trip; per-lane partials in f32 for bf16 data (a lane sums a few
+// hundred values), f64 across the lanes and for f32 data.  (The element-wise kernel above reads 2 bytes per load with one load in flight:
+// 0.5 TB/s -- 1.6 ms for the bias gradient of ESNet's full-resolution classifier.)
+template <typename T> struct SAcc { typedef float type; };
+template <> struct SAcc<float> { typedef double type; };
+template <typename T>
+__global__ __launch_bounds__(NT) void tensor_stats_vec_kernel(const T* z, long ldz, long P, int C, double* stats) {
+  typedef typename SAcc<T>::type A;
+  __shared__ double red[2][NT * 8 / 2];              // [sum | squares][lane-row][C] for C <= 1024... sized below: npl * C <= NT * 8
+  const int CV = C >> 3, npl = NT / CV;
+  const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV;
+  const long per = (P + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
+  A s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s[j] = 0; q[j] = 0; }
+  if (pl < npl) {
+    constexpr int JU = 4;
+    for (long pa = p0 + pl; pa < p1; pa += (long)npl * JU) {
+      typename V8<T>::Raw r[JU];
+#pragma unroll
+      for (int u = 0; u < JU; ++u) {
+        const long p = pa + (long)u * npl;
+        r[u] = V8<T>::load_raw(z + (p < p1 ? p : pa) * ldz + cv * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < JU; ++u) {
+        if (pa + (long)u * npl < p1) {
+          float v[8];
+          V8<T>::unpack(r[u], v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[j] += (A)v[j]; q[j] += (A)v[j] * (A)v[j]; }
+        }
+      }
+    }
+  }
+  // lanes of one channel vector meet in LDS: two passes (sums, squares) through the same [npl][C] array
+  double* buf = &red[0][0];
+  double* row = stats + (long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    __syncthreads();
+    if (pl < npl) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) buf[pl * C + cv * 8 + j] = (double)(which ? q[j] : s[j]);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+      double a = 0.0;
+      for (int l = 0; l < npl; ++l) a += buf[l * C + c];
+      row[which * C + c] = a;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* e, long lde, const T* z, long ldz, const float* ga, const float* gb,
                                                           const float* gce, const float* gmu, T* dz, long lddz, long P, int C) {
@@ -266,7 +322,12 @@ int tss_tensor_stats(const void* z, long ldz, long P, int C, double* stats, int 
   TSS_REQUIRE(dtype == TSS_F32 || dtype == TSS_BF16, TSS_ERR_DTYPE);
   TSS_REQUIRE(P >= 0 && C > 0 && ldz >= C && z && stats, TSS_ERR_SHAPE);
   tss::ProfScope prof(TSS_K_JOIN_FWD, (hipStream_t)stream, (double)P * C * esz(dtype), 0);
-  if (dtype == TSS_BF16)
+  const bool vec = (C % 8) == 0 && C <= NT * 8 / 2 && (ldz % 8) == 0 && tss::aligned16(z) && P >= 4 * TSS_STAT_SLABS;
+  if (vec && dtype == TSS_BF16)
+    hipLaunchKernelGGL(tensor_stats_vec_kernel<bf16_t>, dim3(TSS_STAT_SLABS), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, P, C, stats);
+  else if (vec)
+    hipLaunchKernelGGL(tensor_stats_vec_kernel<float>, dim3(TSS_STAT_SLABS), dim3(NT), 0, (hipStream_t)stream, (const float*)z, ldz, P, C, stats);
+  else if (dtype == TSS_BF16)
     hipLaunchKernelGGL(tensor_stats_kernel<bf16_t>, dim3(TSS_STAT_SLABS), dim3(NT), 0, (hipStream_t)stream, (const bf16_t*)z, ldz, P, C, stats);
   else
     hipLaunchKernelGGL(tensor_stats_kernel<float>, dim3(TSS_STAT_SLABS), dim3(NT), 0, (hipStream_t)stream, (const float*)z, ldz, P, C, stats);
