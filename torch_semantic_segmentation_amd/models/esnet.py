@@ -39,11 +39,17 @@ class ESNet(HipModel):
         self.layer5 = FusedSequential(UpsamplingBlock(64, 16), *[FCUBlock(16, 16, 3) for _ in range(3)])
         self.classifier = FusedSequential(UpsamplingBlock(16, out_channels))
 
-    def forward(self, input):
+    logit_scale = 1      # the classifier already works at full resolution: engine.Trainer takes the loss straight from the NHWC logits
+                         # (the fused head + loss operator at scale 1: no NCHW copy of the 8 x 19 x 1024 x 2048 logits, no layout copy back)
+
+    def forward_lowres(self, input):
         x = self.image_in(input)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4, self.layer5, self.classifier):
             x = stage(x)
-        return self.logits_out(x, input)
+        return x
+
+    def forward(self, input):
+        return self.logits_out(self.forward_lowres(input), input)
 
 
 class UpsamplingBlock(nn.Sequential):
