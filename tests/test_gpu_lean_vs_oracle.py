@@ -375,6 +375,7 @@ FC_CASES = [
 DOWN_CASES = [
     ('down_32_64', [('down', 32, 64, {}), ('pw', 64, 48, {})], (2, 32, 38, 70)),
     ('down_64_128', [('down', 64, 128, {}), ('pw', 128, 64, {})], (3, 64, 22, 36)),
+    ('down_16_64', [('down', 16, 64, {}), ('pw', 64, 32, {})], (2, 16, 26, 44)),      # ESNet's second downsampling block: 16 -> 48 convolution channels
     ('baseline_down_32_64', [('down', 32, 64, {}), ('pw', 64, 64, {})], (2, 32, 256, 512)),
 ]
 
@@ -403,6 +404,7 @@ def test_split_shuffle_unit_vs_f64_oracle(case, train):
 ES_CASES = [
     ('up_64_16', [('esup', 64, 16, {}), ('fcu', 16, 16, {'k': 3})], (2, 64, 11, 19)),
     ('up_16_19', [('esup', 16, 19, {})], (2, 16, 13, 20)),
+    ('up_128_64', [('esup', 128, 64, {})], (3, 128, 10, 14)),
     ('fcu_64_k5', [('fcu', 64, 64, {'k': 5})], (2, 64, 21, 38)),
     ('pfcu_128', [('pfcu', 128, 128, {'dil': [2, 5, 9]})], (2, 128, 19, 26)),
     ('fcu_16_k3', [('fcu', 16, 16, {'k': 3}), ('fcu', 16, 16, {'k': 3})], (2, 16, 22, 40)),

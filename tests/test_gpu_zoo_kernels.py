@@ -160,7 +160,7 @@ def test_strided_3x3_kernels_match_the_generic_kernels(B, H, W, C):
     assert rl(dw1, dw0) < 1e-4
 
 
-@pytest.mark.parametrize('ci,co,B,h,w', [(64, 16, 2, 11, 19), (16, 24, 2, 13, 20), (16, 16, 1, 5, 7)])
+@pytest.mark.parametrize('ci,co,B,h,w', [(64, 16, 2, 11, 19), (16, 24, 2, 13, 20), (16, 16, 1, 5, 7), (128, 64, 2, 9, 13)])
 def test_transposed_3x3_operator_matches_torch(ci, co, B, h, w):
     """ops.conv_transpose (ConvTranspose2d(3, stride 2, padding 1, output_padding 1) + bias, TSS/models/esnet.py:71-80) on the rectangular
     instances of csrc/sconv.hip: forward, input gradient and weight / bias gradients against torch autograd on the same bf16 operands."""

@@ -691,7 +691,7 @@ int tss_conv3x3_fwd(const void* x, long ldx, const float* in_mean, const float* 
       return tss::check_last("conv3x3_lean_fwd");
   }
   TSS_REQUIRE(w_tnc, TSS_ERR_SHAPE);
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && stride == 2 && dil == 1 && Cin <= 64 && N <= 64) {   // sconv.hip
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && stride == 2 && dil == 1 && Cin <= 64 && N <= 128) {   // sconv.hip
     tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, bytes, 18.0 * (double)g.P * Cin * N);
     if (tss_sconv_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, nullptr, y, ldy, stats, B, Hin, Win, Cin, N, (hipStream_t)stream))
       return tss::check_last("sconv_fwd");
@@ -823,7 +823,7 @@ int tss_convkxk_fwd(const void* x, long ldx, const float* in_mean, const float* 
                     (hipStream_t)stream))
       return tss::check_last("fcg_fwd");
   }
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin <= 64 && N <= 64) {   // sconv.hip
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin <= 64 && N <= 128) {   // sconv.hip
     tss::ProfScope prof(TSS_K_CONV3X3_FWD, (hipStream_t)stream, ((double)B * Hin * Win * Cin + (double)g.P * N) * 2.0, 18.0 * (double)g.P * Cin * N);
     if (tss_sconv_fwd(x, ldx, in_mean, in_scale, in_bias, in_relu, w_tnc, bias, y, ldy, stats, B, Hin, Win, Cin, N, (hipStream_t)stream))
       return tss::check_last("sconv_fwd");
@@ -849,7 +849,7 @@ int tss_convkxk_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                          B, Hin, Win, Cin, N, 5, kh == 1 ? 0 : 1, dil, (hipStream_t)stream))
       return tss::check_last("fcg_bwd_data");
   }
-  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && Cin == N && (N == 32 || N == 64)) {
+  if (dtype == TSS_BF16 && !g_tss_disable_fast && kh == 3 && kw == 3 && stride == 2 && dil == 1 && ((Cin == N && (N == 32 || N == 64)) || (Cin == 16 && N == 48))) {
     const double po = (double)B * ((Hin - 1) / 2 + 1) * ((Win - 1) / 2 + 1);
     tss::ProfScope prof(TSS_K_CONV3X3_BWD_DATA, (hipStream_t)stream, (po * N * (yraw ? 2 : 1) + (double)B * Hin * Win * Cin * (xraw ? 2 : 1)) * 2.0,
                         18.0 * po * Cin * N);

@@ -903,6 +903,8 @@ bool tss_sconv_fwd(const void* x, long ldx, const float* in_mean, const float* i
   else if (N == 64 && Cin == 16) launch_fwd<16, 64, 2>(g, stream);      // input gradient of ConvTranspose2d(64, 16)
   else if (N == 16 && Cin == 24) launch_fwd<24, 16, 4>(g, stream);      // ... of ConvTranspose2d(16, 19 padded to 24)
   else if (N == 16 && Cin == 16) launch_fwd<16, 16, 4>(g, stream);
+  else if (N == 48 && Cin == 16) launch_fwd<16, 48, 2>(g, stream);      // DownsamplingBlock(16, 64) of ESNet
+  else if (N == 128 && Cin == 64) launch_fwd<64, 128, 1>(g, stream);    // input gradient of ConvTranspose2d(128, 64): 147 KB of weights, one block per CU
   else return false;
   return true;
 }
@@ -912,7 +914,8 @@ bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
                         const float* ga, const float* gb, const float* gce, const float* gmu, const float* w_tcn,
                         const void* xraw, long ldx, const float* in_mean, const float* in_scale, const float* in_bias, int in_relu,
                         void* e_in, long ldei, double* bstats, int B, int Hin, int Win, int Cin, int N, hipStream_t stream) {
-  if (!covered(Hin, Win, Cin, N) || (lde % 8) || (ldei % 4) || !tss::aligned16(e) || (reinterpret_cast<uintptr_t>(e_in) & 7u) || !w_tcn || B <= 0)
+  if (!(covered(Hin, Win, Cin, N) || (sc_enabled() && Hin >= 2 && Win >= 2 && Cin == 16 && N == 48)) || (lde % 8) || (ldei % 4) || !tss::aligned16(e) ||
+      (reinterpret_cast<uintptr_t>(e_in) & 7u) || !w_tcn || B <= 0)
     return false;
   if (yraw) return false;      // a BatchNorm directly behind the layer (two operands per tap): not instantiated (the form with all four taps of a
                                // tile in registers spills; DownsamplingBlock's BatchNorm sits behind the concat, not behind the convolution)
@@ -924,7 +927,9 @@ bool tss_sconv_bwd_data(const void* e, long lde, const void* yraw, long ldyr,
   g.w = w_tcn; g.w_os = N; g.w_ks = 1; g.w_t9 = (long)Cin * N;
   g.y = (T*)e_in; g.ldy = ldei; g.stats = bstats;
   g.xm = (const T*)xraw; g.ldxm = ldx; g.mm = in_mean; g.ms = in_scale; g.mb = in_bias; g.m_relu = in_relu;
-  if (N == 64) launch_bwd<64, 64, 1, 2>(g, stream); else launch_bwd<32, 32, 1, 4>(g, stream);
+  if (N == 48) launch_bwd<48, 16, 1, 2>(g, stream);                     // DownsamplingBlock(16, 64) of ESNet: 48 gradient channels -> 16
+  else if (N == 64) launch_bwd<64, 64, 1, 2>(g, stream);
+  else launch_bwd<32, 32, 1, 4>(g, stream);
   return true;
 }
 
@@ -990,6 +995,7 @@ bool tss_sconv_transposed_fwd(const void* x, long ldx, const float* w_tcn, const
   if (Cin_t == 64 && Cout == 16) launch_bwd<64, 16, 1, 2>(g, stream);
   else if (Cin_t == 16 && Cout == 24) launch_bwd<16, 24, 1, 4>(g, stream);
   else if (Cin_t == 16 && Cout == 16) launch_bwd<16, 16, 1, 4>(g, stream);
+  else if (Cin_t == 128 && Cout == 64) launch_bwd<128, 64, 1, 1>(g, stream);      // 147 KB of weights: one block per CU
   else return false;
   return true;
 }
