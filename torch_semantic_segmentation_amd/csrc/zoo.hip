@@ -163,6 +163,85 @@ __global__ __launch_bounds__(NT) void pool_concat_fwd_kernel(const PoolArgs g, c
   }
 }
 
+// The same operator on an NHWC activation of the output's dtype with whole 8-channel vectors on both sides (N1, Cin multiples of 8): a lane
+// owns one 16-byte (bf16) vector of an output pixel -- a copy of y1 (+ bias) or the channel-wise maximum of the four window vectors, first
+// maximum wins as above.  (The element-wise kernel: 1.2 TB/s on the 470 MB of LEDNet's second downsampling block.)
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_concat_fwd_vec_kernel(const PoolArgs g, const T* y1, long ld1, const float* bias, T* z, long ldz) {
+  const int V1 = g.N1 >> 3, VT = V1 + (g.Cin >> 3);
+  const long total = (long)g.B * g.Ho * g.Wo * VT;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const int cv = (int)(i % VT);
+    const long p = i / VT;
+    float v[8];
+    if (cv < V1) {
+      V8<T>::load(y1 + p * ld1 + cv * 8, v);
+      if (bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias[cv * 8 + j];
+      }
+    } else {
+      const int ox = (int)(p % g.Wo);
+      const long t = p / g.Wo;
+      const int oy = (int)(t % g.Ho);
+      const long base = (t / g.Ho) * g.sxb + (long)(2 * oy) * g.sxh + (long)(2 * ox) * g.sxw + (cv - V1) * 8;
+      typename V8<T>::Raw r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[q] = V8<T>::load_raw(x + base + (q >> 1) * g.sxh + (q & 1) * g.sxw);
+      V8<T>::unpack(r[0], v);
+#pragma unroll
+      for (int q = 1; q < 4; ++q) {
+        float u[8];
+        V8<T>::unpack(r[q], u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (u[j] > v[j] || u[j] != u[j]) v[j] = u[j];
+      }
+    }
+    V8<T>::store(z + p * ldz + cv * 8, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_concat_bwd_vec_kernel(const PoolArgs g, const T* dz, long lddz, T* dx, long lddx) {
+  const int VC = g.Cin >> 3;
+  const long total = (long)g.B * g.Ho * g.Wo * VC;
+  const T* x = reinterpret_cast<const T*>(g.x);
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const int cv = (int)(i % VC);
+    const long p = i / VC;
+    const int ox = (int)(p % g.Wo);
+    const long t = p / g.Wo;
+    const int oy = (int)(t % g.Ho);
+    const long b = t / g.Ho;
+    const long base = b * g.sxb + (long)(2 * oy) * g.sxh + (long)(2 * ox) * g.sxw + cv * 8;
+    typename V8<T>::Raw r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = V8<T>::load_raw(x + base + (q >> 1) * g.sxh + (q & 1) * g.sxw);
+    float gv[8], best[8];
+    int at[8];
+    V8<T>::load(dz + p * lddz + g.N1 + cv * 8, gv);
+    V8<T>::unpack(r[0], best);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) at[j] = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      float u[8];
+      V8<T>::unpack(r[q], u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (u[j] > best[j] || u[j] != u[j]) { best[j] = u[j]; at[j] = q; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = at[j] == q ? gv[j] : 0.f;
+      const long pin = (b * (2 * g.Ho) + 2 * oy + (q >> 1)) * (long)(2 * g.Wo) + 2 * ox + (q & 1);
+      V8<T>::store(dx + pin * lddx + cv * 8, o);
+    }
+  }
+}
+
 // dx[b][2 oy + dy][2 ox + dx][ci] = dz[p][N1 + ci] at the window's arg-max, 0 at its three other pixels (H, W even: every input
 // pixel lies in exactly one window)
 template <typename T>
@@ -360,6 +439,19 @@ int tss_pool_concat_fwd(const void* y1, long ld1, const float* bias, int N1, con
   const long total = (long)B * g.Ho * g.Wo * (N1 + Cin);
   if (total == 0) return TSS_OK;
   tss::ProfScope prof(TSS_K_JOIN_FWD, (hipStream_t)stream, (double)B * g.Ho * g.Wo * (2.0 * N1 + 5.0 * Cin) * esz(dtype), 0);
+  // an NHWC activation of the output's dtype, whole vectors everywhere: the vectorised kernel
+  const bool vec = (x_f32 != 0) == (dtype == TSS_F32) && sxc == 1 && (N1 % 8) == 0 && (Cin % 8) == 0 && (ld1 % 8) == 0 && (ldz % 8) == 0 &&
+                   (sxb % 8) == 0 && (sxh % 8) == 0 && (sxw % 8) == 0 && tss::aligned16(x) && tss::aligned16(z) && (N1 == 0 || tss::aligned16(y1));
+  if (vec) {
+    const long tv = total / 8;
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(pool_concat_fwd_vec_kernel<bf16_t>, dim3(grid_for(tv)), dim3(NT), 0, (hipStream_t)stream, g, (const bf16_t*)y1, ld1, bias,
+                         (bf16_t*)z, ldz);
+    else
+      hipLaunchKernelGGL(pool_concat_fwd_vec_kernel<float>, dim3(grid_for(tv)), dim3(NT), 0, (hipStream_t)stream, g, (const float*)y1, ld1, bias,
+                         (float*)z, ldz);
+    return tss::check_last("pool_concat_fwd");
+  }
   if (dtype == TSS_BF16)
     hipLaunchKernelGGL(pool_concat_fwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g, (const bf16_t*)y1, ld1, bias,
                        (bf16_t*)z, ldz);
@@ -378,6 +470,17 @@ int tss_pool_concat_bwd(const void* dz, long lddz, int N1, const void* x, int x_
   const long total = (long)B * g.Ho * g.Wo * Cin;
   if (total == 0) return TSS_OK;
   tss::ProfScope prof(TSS_K_JOIN_BWD, (hipStream_t)stream, (double)total * 9.0 * esz(dtype), 0);
+  const bool vec = (x_f32 != 0) == (dtype == TSS_F32) && sxc == 1 && (N1 % 8) == 0 && (Cin % 8) == 0 && (lddz % 8) == 0 && (lddx % 8) == 0 &&
+                   (sxb % 8) == 0 && (sxh % 8) == 0 && (sxw % 8) == 0 && tss::aligned16(x) && tss::aligned16(dz) && tss::aligned16(dx);
+  if (vec) {
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(pool_concat_bwd_vec_kernel<bf16_t>, dim3(grid_for(total / 8)), dim3(NT), 0, (hipStream_t)stream, g, (const bf16_t*)dz, lddz,
+                         (bf16_t*)dx, lddx);
+    else
+      hipLaunchKernelGGL(pool_concat_bwd_vec_kernel<float>, dim3(grid_for(total / 8)), dim3(NT), 0, (hipStream_t)stream, g, (const float*)dz, lddz,
+                         (float*)dx, lddx);
+    return tss::check_last("pool_concat_bwd");
+  }
   if (dtype == TSS_BF16)
     hipLaunchKernelGGL(pool_concat_bwd_kernel<bf16_t>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, g, (const bf16_t*)dz, lddz,
                        (bf16_t*)dx, lddx);
