@@ -202,6 +202,46 @@ __global__ __launch_bounds__(NT) void pool_concat_fwd_vec_kernel(const PoolArgs 
   }
 }
 
+// ... and on the f32 NCHW IMAGE (the first downsampling block: 3 input channels, N1 = 29 / 13 convolution channels, a ragged boundary inside
+// an 8-channel vector): a lane owns one output vector; its convolution channels come from one 16-byte load of y1 (computed with channels
+// padded to whole vectors), its pool channels from four scalar image loads each.
+template <typename T>
+__global__ __launch_bounds__(NT) void pool_concat_fwd_img_kernel(const PoolArgs g, const T* y1, long ld1, const float* bias, T* z, long ldz) {
+  const int Ct = g.N1 + g.Cin, VT = Ct >> 3;
+  const long total = (long)g.B * g.Ho * g.Wo * VT;
+  const float* x = reinterpret_cast<const float*>(g.x);
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const int cv = (int)(i % VT);
+    const long p = i / VT;
+    float v[8];
+    if (cv * 8 < g.N1) {
+      V8<T>::load(y1 + p * ld1 + cv * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (bias && cv * 8 + j < g.N1) v[j] += bias[cv * 8 + j];
+    }
+    if (cv * 8 + 8 > g.N1) {
+      const int ox = (int)(p % g.Wo);
+      const long t = p / g.Wo;
+      const int oy = (int)(t % g.Ho);
+      const long base = (t / g.Ho) * g.sxb + (long)(2 * oy) * g.sxh + (long)(2 * ox) * g.sxw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ci = cv * 8 + j - g.N1;
+        if (ci >= 0) {
+          const float* px = x + base + (long)ci * g.sxc;
+          float best = px[0];
+          const float u1 = px[g.sxw], u2 = px[g.sxh], u3 = px[g.sxh + g.sxw];
+          if (u1 > best || u1 != u1) best = u1;
+          if (u2 > best || u2 != u2) best = u2;
+          if (u3 > best || u3 != u3) best = u3;
+          v[j] = best;
+        }
+      }
+    }
+    V8<T>::store(z + p * ldz + cv * 8, v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void pool_concat_bwd_vec_kernel(const PoolArgs g, const T* dz, long lddz, T* dx, long lddx) {
   const int VC = g.Cin >> 3;
@@ -449,6 +489,18 @@ int tss_pool_concat_fwd(const void* y1, long ld1, const float* bias, int N1, con
                          (bf16_t*)z, ldz);
     else
       hipLaunchKernelGGL(pool_concat_fwd_vec_kernel<float>, dim3(grid_for(tv)), dim3(NT), 0, (hipStream_t)stream, g, (const float*)y1, ld1, bias,
+                         (float*)z, ldz);
+    return tss::check_last("pool_concat_fwd");
+  }
+  const bool img = x_f32 != 0 && ((N1 + Cin) % 8) == 0 && (ldz % 8) == 0 && tss::aligned16(z) && N1 > 0 && (ld1 % 8) == 0 && ld1 >= (N1 + 7) / 8 * 8 &&
+                   tss::aligned16(y1);
+  if (img) {
+    const long tv = total / 8;
+    if (dtype == TSS_BF16)
+      hipLaunchKernelGGL(pool_concat_fwd_img_kernel<bf16_t>, dim3(grid_for(tv)), dim3(NT), 0, (hipStream_t)stream, g, (const bf16_t*)y1, ld1, bias,
+                         (bf16_t*)z, ldz);
+    else
+      hipLaunchKernelGGL(pool_concat_fwd_img_kernel<float>, dim3(grid_for(tv)), dim3(NT), 0, (hipStream_t)stream, g, (const float*)y1, ld1, bias,
                          (float*)z, ldz);
     return tss::check_last("pool_concat_fwd");
   }
