@@ -1160,10 +1160,13 @@ class _F32Buffers:
 def _colsum(e, C, st):
     """Per-channel sums of an NHWC tensor over its pixels (f32 [C]) through the statistics slab rows: fixed order, any C."""
     P = npix(e)
-    slab = torch.empty((N.stat_slabs(), 2 * C), dtype=torch.float64, device=e.device)
-    vec = torch.empty(2 * C + 1, dtype=torch.float64, device=e.device)
-    call('tss_tensor_stats', ptr(e), ld(e), P, C, ptr(slab), N.dtype_code(e.dtype), st)
-    call('tss_slab_reduce', ptr(slab), float(P), ptr(vec), C, st)
+    Cw = C
+    if C % 8 and ld(e) >= round_up(C, 8) and e.data_ptr() % 16 == 0:
+        Cw = round_up(C, 8)       # whole 8-channel vectors (the vectorised kernel): the neighbouring columns of the buffer are summed too, and dropped
+    slab = torch.empty((N.stat_slabs(), 2 * Cw), dtype=torch.float64, device=e.device)
+    vec = torch.empty(2 * Cw + 1, dtype=torch.float64, device=e.device)
+    call('tss_tensor_stats', ptr(e), ld(e), P, Cw, ptr(slab), N.dtype_code(e.dtype), st)
+    call('tss_slab_reduce', ptr(slab), float(P), ptr(vec), Cw, st)
     return vec[:C].float()
 
 
